@@ -1,0 +1,138 @@
+/*
+ * quadrace.h -- C ABI of libquadrace.so: the MI355X-native (gfx950) vectorised quadrotor race
+ * environment that replaces the NumPy hot path of tudelft/optimal_quad_control_RL.
+ *
+ * What each entry point replaces (R: = "3D quad race.ipynb", I: = "3D quad race INDI inner loop.ipynb",
+ * raw .ipynb line numbers as in SURVEY.md section 0):
+ *
+ *   qr_create / qr_set_track      Quadcopter3DGates.__init__            R:288-360   I:143-214
+ *   qr_set_residual               torch.load(NNDroneModel/*.pt)         R:227-245   (c_code/nn_thrust.c, nn_moment.c layout)
+ *   qr_set_disturbance            env.disturbance_ranges / _scale       R:355-358, R:772-781
+ *   qr_set_limits                 env.max_steps / env.dt                R:345-346, I:648
+ *   qr_set_pause                  env.pause                             R:360, R:570-572
+ *   qr_seed                       VecEnv.seed (no-op upstream)          R:600-601
+ *   qr_reset                      reset() / reset_(dones)               R:452-496   I:267-299
+ *   qr_step                       step_async() + step_wait()            R:498-595   I:301-385
+ *   qr_observe                    update_states_gate()                  R:365-450   I:218-265
+ *   qr_get_state / qr_set_state   direct attribute access to world_states, disturbances, target_gates,
+ *                                 step_counts                           R:803, R:4499-4500
+ *   qr_get_track_tables           gate_pos_rel / gate_yaw_rel           R:307-319   (pinned by c_code/nn_controller.c:40-60)
+ *
+ * Conventions (precedent: the reference's own ctypes use, R:4395-4417 -- POINTER(c_float) arguments,
+ * caller-allocated outputs):
+ *   - every function returns 0 on success, <0 on error (see QR_E_*); qr_last_error() gives text
+ *     (thread-local). No exception crosses this boundary.
+ *   - all buffer arguments named *_dev are DEVICE pointers (HBM of the GPU the env was created on) owned
+ *     by the caller (e.g. torch tensor .data_ptr()); the library never frees or retains them beyond the
+ *     kernels it enqueues in that call.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). Calls enqueue work and return
+ *     without synchronising; results are ordered on that stream.
+ *   - a handle is bound to one GPU and is not thread-safe.
+ *   - there is NO CPU fallback: qr_create fails with QR_E_NO_DEVICE when no gfx950 device is visible.
+ *
+ * Layouts at the boundary are the reference's row-major arrays: actions [N][4], obs [N][obs_len],
+ * rewards [N] f32, dones [N] u8, world [N][S] (S = 16 E2E / 13 INDI), disturbances [N][6].
+ * Internally the state lives in HBM as planar float4 structure-of-arrays.
+ */
+#ifndef QUADRACE_H
+#define QUADRACE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QR_ABI_VERSION 1
+
+enum {
+    QR_OK = 0,
+    QR_E_INVALID = -1,   /* bad argument */
+    QR_E_NO_DEVICE = -2, /* no HIP device / not gfx950 */
+    QR_E_HIP = -3,       /* a HIP runtime call failed */
+    QR_E_STATE = -4      /* call not valid in the current state (e.g. step before set_track) */
+};
+
+enum { QR_VARIANT_E2E = 0, QR_VARIANT_INDI = 1 };
+
+#define QR_MAX_GATES 32
+#define QR_MAX_GATES_AHEAD 4
+#define QR_RESIDUAL_FLOATS 740 /* 289 thrust + 451 moment */
+
+typedef struct qr_env qr_env;
+
+typedef struct qr_config {
+    int32_t variant;            /* QR_VARIANT_E2E | QR_VARIANT_INDI */
+    int32_t num_envs;           /* N >= 1 (envs simulated by this handle / this GPU) */
+    int32_t gates_ahead;        /* 0..QR_MAX_GATES_AHEAD (R:292) */
+    int32_t device;             /* HIP device ordinal */
+    int32_t pause_if_collision; /* R:293, R:573-578 */
+    int32_t reserved0;
+    uint64_t env_id_base;       /* global index of local env 0 (multi-GPU sharding: RNG stream id) */
+} qr_config;
+
+int qr_abi_version(void);
+const char* qr_last_error(void);
+
+int qr_create(const qr_config* cfg, qr_env** out);
+int qr_destroy(qr_env* env);
+
+/* sizes: S (world-state length) and obs_len = S + 4*gates_ahead (+4 disturbance terms for E2E) */
+int qr_state_len(const qr_env* env);
+int qr_obs_len(const qr_env* env);
+int qr_num_envs(const qr_env* env);
+
+/* Host arrays: gate_pos [G][3], gate_yaw [G], start_pos [3]. Computes the relative-gate tables. */
+int qr_set_track(qr_env* env, const float* gate_pos, const float* gate_yaw, int32_t num_gates,
+                 const float* start_pos);
+/* Host outputs (any may be NULL): gate_pos_rel [G][3], gate_yaw_rel [G]. */
+int qr_get_track_tables(const qr_env* env, float* gate_pos_rel, float* gate_yaw_rel);
+
+/* Host array of QR_RESIDUAL_FLOATS f32 (thrust W1[32][7] b1[32] W2[1][32] b2[1]; moment W1[32][10]
+ * b1[32] W2[3][32] b2[3]) or NULL to disable the residual model (BASELINE config 1). E2E only. */
+int qr_set_residual(qr_env* env, const float* blob, size_t n_floats);
+
+/* Host array ranges[6][2] = (min,max) for (Mx,My,Mz,Fx,Fy,Fz); scale = disturbance_scale. E2E only. */
+int qr_set_disturbance(qr_env* env, const float* ranges, float scale);
+
+int qr_set_limits(qr_env* env, int32_t max_steps, float dt);
+int qr_set_pause(qr_env* env, int32_t pause);
+
+/* Philox4x32-10 key for the in-kernel reset RNG; also zeroes the per-env episode counters. */
+int qr_seed(qr_env* env, uint64_t seed);
+
+/* reset_(mask): mask_dev = NULL resets every env (reset()). Writes the gate-frame observation of ALL
+ * envs to obs_out_dev [N][obs_len] (may be NULL). */
+int qr_reset(qr_env* env, const uint8_t* mask_dev, float* obs_out_dev, void* stream);
+
+/* One env step for all N envs (one fused kernel): residual MLP -> Euler integration -> reward ->
+ * gate pass / collision / ground / bounds / max-steps -> (auto-reset) -> gate-frame observation.
+ * trunc_out_dev (may be NULL) receives max_steps_reached per env ("TimeLimit.truncated").
+ * With pause set, obs_out_dev is left untouched (the reference does not refresh it, R:570-572). */
+int qr_step(qr_env* env, const float* actions_dev, float* obs_out_dev, float* rew_out_dev,
+            uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream);
+
+/* K consecutive steps with pre-recorded actions [K][N][4]; outputs are [K][N][...] (trunc may be NULL).
+ * Semantically identical to K calls of qr_step; enqueued without host round trips. */
+int qr_step_many(qr_env* env, int32_t num_steps, const float* actions_dev, float* obs_out_dev,
+                 float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream);
+
+/* update_states(): recompute the observation from the current state. */
+int qr_observe(qr_env* env, float* obs_out_dev, void* stream);
+
+/* Row-major copies of the internal state (device pointers; any may be NULL).
+ * dist is ignored for INDI. target/steps are int32. episode = per-env reset counter (RNG stream position). */
+int qr_get_state(qr_env* env, float* world_dev, float* dist_dev, int32_t* target_dev, int32_t* steps_dev,
+                 uint32_t* episode_dev, void* stream);
+int qr_set_state(qr_env* env, const float* world_dev, const float* dist_dev, const int32_t* target_dev,
+                 const int32_t* steps_dev, const uint32_t* episode_dev, void* stream);
+
+/* Timing hook for benchmarks: mean duration (ms) of the step kernels launched by the last
+ * qr_step_many call, measured with hipEvents on the launch stream. Blocks until that work is done. */
+int qr_last_step_many_ms(qr_env* env, float* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUADRACE_H */

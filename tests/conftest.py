@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def residual_blob():
+    import numpy as np
+
+    return np.fromfile(os.path.join(ROOT, "optimal_quad_control_rl_amd", "data", "residual_mlp_f32.bin"), np.float32)

@@ -1,0 +1,112 @@
+"""Shared parity machinery: replays the committed reference trajectories (tests/golden, generated from the
+real reference by tools/gen_golden.py) on any implementation of the env -- the CPU oracle in the
+`not gpu` suite and the HIP product in the `gpu` suite -- so both are held to the same bar.
+
+An implementation is wrapped as an object with:
+    set_state(world[N,S], dist[N,6] or None, target[N], steps[N]);  get_state() -> (world, dist, target, steps)
+    step(actions[N,4]) -> (obs[N,L], reward[N], done[N] bool, trunc[N] bool);  observe() -> obs
+"""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TRAIN_DIST_RANGES = np.array([[-0.03, 0.03], [-0.03, 0.03], [-0.01, 0.01], [0, 0], [0, 0], [-0.5, 0.5]], np.float32)
+
+# Tolerances (float32 path; BASELINE.json north_star: 1e-5 relative on state vectors).
+#   one teacher-forced step: the reference's own lambdified expression has ~1e-5 absolute rounding noise
+#   in the angular accelerations (cancellation of +-100-sized terms), i.e. ~1e-7 on a state after *dt.
+TOL_STEP_STATE = 2e-6   # |d state| / max(1,|state|) after ONE step from identical state
+TOL_STEP_OBS = 4e-6
+TOL_STEP_REWARD = 2e-5  # absolute; rewards are differences of O(1..10) distances
+TOL_FREE_RUN = 1e-5     # north_star: free-running 100 steps, max |d state| / max(1,|state|)
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def tracks():
+    d = load("tracks")
+    return {t: (d[t + "_gate_pos"], d[t + "_gate_yaw"], d[t + "_start_pos"]) for t in ("zigzag", "square")}
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+class TrajectoryReport:
+    def __init__(self):
+        self.max_state = 0.0
+        self.max_obs = 0.0
+        self.max_reward = 0.0
+        self.steps = 0
+        self.dones = 0
+        self.passes = 0
+
+    def __repr__(self):
+        return (f"steps={self.steps} dones={self.dones} passes={self.passes} max_state={self.max_state:.3g} "
+                f"max_obs={self.max_obs:.3g} max_reward={self.max_reward:.3g}")
+
+
+def teacher_forced(env, traj, prefix, has_dist, tol_state=TOL_STEP_STATE, tol_obs=TOL_STEP_OBS,
+                   tol_rew=TOL_STEP_REWARD, stride=1):
+    """Per step: inject the reference's state k, step with action k, compare with the reference's state k+1."""
+    g = lambda k: traj[prefix + k]
+    acts = g("actions")
+    H = acts.shape[0]
+    world, target, steps = g("world0"), g("target0"), g("steps0")
+    dist = g("dist0") if has_dist else None
+    rep = TrajectoryReport()
+    for k in range(0, H):
+        if k % stride == 0:
+            env.set_state(world, dist, target, steps)
+            obs, rew, done, trunc = env.step(acts[k])
+            w_new, d_new, t_new, s_new = env.get_state()
+            ref_done = g("done")[k].astype(bool)
+            ref_rew = g("reward")[k]
+            np.testing.assert_array_equal(done, ref_done, err_msg=f"done mismatch at step {k}")
+            rep.max_reward = max(rep.max_reward, float(np.abs(rew - ref_rew).max()))
+            assert np.abs(rew - ref_rew).max() <= tol_rew, f"reward mismatch at step {k}: {rew} vs {ref_rew}"
+            np.testing.assert_array_equal(t_new, g("target")[k], err_msg=f"target mismatch at step {k}")
+            np.testing.assert_array_equal(s_new, g("steps")[k], err_msg=f"step_counts mismatch at step {k}")
+            np.testing.assert_array_equal(trunc, (steps + 1) >= 1200, err_msg=f"trunc mismatch at step {k}")
+            live = ~ref_done
+            if live.any():
+                es = rel_err(w_new[live], g("world")[k][live]).max()
+                eo = rel_err(obs[live], g("obs")[k][live]).max()
+                rep.max_state, rep.max_obs = max(rep.max_state, float(es)), max(rep.max_obs, float(eo))
+                assert es <= tol_state, f"state mismatch at step {k}: {es}"
+                assert eo <= tol_obs, f"obs mismatch at step {k}: {eo}"
+            rep.steps += 1
+            rep.dones += int(ref_done.sum())
+            rep.passes += int((ref_rew > 1).sum())
+        world, target, steps = g("world")[k], g("target")[k], g("steps")[k]
+        if has_dist:
+            dist = g("dist")[k]
+    return rep
+
+
+def free_run(env, traj, prefix, has_dist, horizon=100, tol=TOL_FREE_RUN):
+    """Inject the initial state once, then replay the recorded action sequence without correction."""
+    g = lambda k: traj[prefix + k]
+    acts = g("actions")
+    assert not g("done")[:horizon].any(), "free-run window must not contain a reference reset"
+    env.set_state(g("world0"), g("dist0") if has_dist else None, g("target0"), g("steps0"))
+    rep = TrajectoryReport()
+    for k in range(horizon):
+        obs, rew, done, trunc = env.step(acts[k])
+        w_new, _, t_new, s_new = env.get_state()
+        es = rel_err(w_new, g("world")[k]).max()
+        rep.max_state = max(rep.max_state, float(es))
+        rep.max_obs = max(rep.max_obs, float(rel_err(obs, g("obs")[k]).max()))
+        rep.max_reward = max(rep.max_reward, float(np.abs(rew - g("reward")[k]).max()))
+        assert not done.any(), f"unexpected termination at free-run step {k}"
+        np.testing.assert_array_equal(t_new, g("target")[k])
+        rep.steps += 1
+        rep.passes += int((g("reward")[k] > 1).sum())
+    assert rep.max_state <= tol, f"free-run drift {rep.max_state} > {tol} over {horizon} steps"
+    return rep
