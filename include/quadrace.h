@@ -6,7 +6,7 @@
  * raw .ipynb line numbers as in SURVEY.md section 0):
  *
  *   qr_create / qr_set_track      Quadcopter3DGates.__init__            R:288-360   I:143-214
- *   qr_set_residual               torch.load(NNDroneModel/*.pt)         R:227-245   (c_code/nn_thrust.c, nn_moment.c layout)
+ *   qr_set_residual               torch.load(NNDroneModel .pt)          R:227-245   (c_code/nn_thrust.c, nn_moment.c layout)
  *   qr_set_disturbance            env.disturbance_ranges / _scale       R:355-358, R:772-781
  *   qr_set_limits                 env.max_steps / env.dt                R:345-346, I:648
  *   qr_set_pause                  env.pause                             R:360, R:570-572

@@ -1,0 +1,345 @@
+// quadrace_abi.hip -- host side of libquadrace.so: the extern "C" boundary declared in include/quadrace.h.
+// Owns the planar HBM state of one env shard, the constant tables, and enqueues the gfx950 kernels on the
+// caller's stream.  There is deliberately no CPU execution path: without a gfx950 device qr_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/quadrace.h"
+#include "quadrace_device.hpp"
+
+namespace qr {
+hipError_t launch_step(int variant, const Params& P, const float* actions, float* obs, float* rew, uint8_t* done,
+                       uint8_t* trunc, hipStream_t st);
+hipError_t launch_reset(int variant, const Params& P, const uint8_t* mask, float* obs, hipStream_t st);
+hipError_t launch_observe(int variant, const Params& P, float* obs, hipStream_t st);
+hipError_t launch_get_state(int variant, const Params& P, float* world, float* dist, int32_t* target, int32_t* steps,
+                            uint32_t* episode, hipStream_t st);
+hipError_t launch_set_state(int variant, const Params& P, const float* world, const float* dist,
+                            const int32_t* target, const int32_t* steps, const uint32_t* episode, hipStream_t st);
+}  // namespace qr
+
+struct qr_env {
+    qr_config cfg{};
+    int S = 0, L = 0;
+    qr::Params P{};
+    void* slab = nullptr;       // one HBM allocation holding every state plane
+    float* d_tables = nullptr;  // [gate rows | fused MLP table]
+    int num_gates = 0;
+    bool has_track = false;
+    std::vector<float> gate_pos, gate_yaw, gate_pos_rel, gate_yaw_rel;
+    float mlp_table[qr::kMlpFloats] = {};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_valid = false;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define QR_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(QR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int upload_tables(qr_env* e) {
+    const int gate_floats = e->num_gates * qr::kGateStride;
+    std::vector<float> host(gate_floats + qr::kMlpFloats, 0.0f);
+    for (int g = 0; g < e->num_gates; ++g) {
+        float* row = host.data() + g * qr::kGateStride;
+        row[0] = e->gate_pos[3 * g + 0];
+        row[1] = e->gate_pos[3 * g + 1];
+        row[2] = e->gate_pos[3 * g + 2];
+        row[3] = e->gate_yaw[g];
+        row[4] = cosf(e->gate_yaw[g]);  // the reference evaluates np.cos/np.sin on the f32 yaw every step (R:372-375,528)
+        row[5] = sinf(e->gate_yaw[g]);
+        row[8] = e->gate_pos_rel[3 * g + 0];
+        row[9] = e->gate_pos_rel[3 * g + 1];
+        row[10] = e->gate_pos_rel[3 * g + 2];
+        row[11] = e->gate_yaw_rel[g];
+    }
+    std::memcpy(host.data() + gate_floats, e->mlp_table, sizeof(e->mlp_table));
+    QR_HIP(hipMemcpy(e->d_tables, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return QR_OK;
+}
+
+int check_ready(const qr_env* e) {
+    if (!e) return fail(QR_E_INVALID, "null env handle");
+    if (!e->has_track) return fail(QR_E_STATE, "qr_set_track has not been called");
+    return QR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qr_abi_version(void) { return QR_ABI_VERSION; }
+const char* qr_last_error(void) { return g_err.c_str(); }
+
+int qr_create(const qr_config* cfg, qr_env** out) {
+    if (!cfg || !out) return fail(QR_E_INVALID, "qr_create: null argument");
+    *out = nullptr;
+    if (cfg->variant != QR_VARIANT_E2E && cfg->variant != QR_VARIANT_INDI)
+        return fail(QR_E_INVALID, "qr_create: unknown variant");
+    if (cfg->num_envs < 1) return fail(QR_E_INVALID, "qr_create: num_envs must be >= 1");
+    if (cfg->gates_ahead < 0 || cfg->gates_ahead > QR_MAX_GATES_AHEAD)
+        return fail(QR_E_INVALID, "qr_create: gates_ahead out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(QR_E_NO_DEVICE, "qr_create: no HIP device visible (libquadrace has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(QR_E_INVALID, "qr_create: bad device ordinal");
+    hipDeviceProp_t prop;
+    QR_HIP(hipGetDeviceProperties(&prop, cfg->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(QR_E_NO_DEVICE, std::string("qr_create: device is ") + prop.gcnArchName + ", kernels are gfx950-only");
+    QR_HIP(hipSetDevice(cfg->device));
+
+    qr_env* e = new qr_env();
+    e->cfg = *cfg;
+    const bool e2e = cfg->variant == QR_VARIANT_E2E;
+    e->S = e2e ? 16 : 13;
+    e->L = e->S + 4 * cfg->gates_ahead + (e2e ? 4 : 0);  // R:330 / I:185
+    const int n = cfg->num_envs;
+    const size_t ns = align_up((size_t)n, qr::kBlock);
+    // slab layout (every region 256-byte aligned)
+    const size_t sz_ws = align_up(sizeof(float4) * ns * (e2e ? 4 : 3), 256);
+    const size_t sz_tn = e2e ? 0 : align_up(sizeof(float) * ns, 256);
+    const size_t sz_dA = e2e ? align_up(sizeof(float4) * ns, 256) : 0;
+    const size_t sz_dB = e2e ? align_up(sizeof(float2) * ns, 256) : 0;
+    const size_t sz_ts = align_up(sizeof(int2) * ns, 256);
+    const size_t sz_ep = align_up(sizeof(uint32_t) * ns, 256);
+    const size_t total = sz_ws + sz_tn + sz_dA + sz_dB + sz_ts + sz_ep;
+    if (hipMalloc(&e->slab, total) != hipSuccess) {
+        delete e;
+        return fail(QR_E_HIP, "qr_create: hipMalloc of the state slab failed");
+    }
+    if (hipMalloc((void**)&e->d_tables, sizeof(float) * (qr::kMaxGates * qr::kGateStride + qr::kMlpFloats)) != hipSuccess) {
+        (void)hipFree(e->slab);
+        delete e;
+        return fail(QR_E_HIP, "qr_create: hipMalloc of the table buffer failed");
+    }
+    (void)hipMemset(e->slab, 0, total);
+    char* p = static_cast<char*>(e->slab);
+    qr::Params& P = e->P;
+    P.ws = reinterpret_cast<float4*>(p); p += sz_ws;
+    P.tn = e2e ? nullptr : reinterpret_cast<float*>(p); p += sz_tn;
+    P.dA = e2e ? reinterpret_cast<float4*>(p) : nullptr; p += sz_dA;
+    P.dB = e2e ? reinterpret_cast<float2*>(p) : nullptr; p += sz_dB;
+    P.ts = reinterpret_cast<int2*>(p); p += sz_ts;
+    P.episode = reinterpret_cast<uint32_t*>(p);
+    P.tables = e->d_tables;
+    P.n = n;
+    P.n_stride = (int)ns;
+    P.num_gates = 0;
+    P.gates_ahead = cfg->gates_ahead;
+    P.max_steps = 1200;  // R:345
+    P.dt = 0.01f;        // R:346
+    P.flags = cfg->pause_if_collision ? qr::kFlagPauseIfCollision : 0;
+    P.seed_lo = P.seed_hi = 0;
+    P.gid_lo = (uint32_t)cfg->env_id_base;
+    P.gid_hi = (uint32_t)(cfg->env_id_base >> 32);
+    P.dist_scale = 1.0f;  // R:358
+    (void)hipEventCreate(&e->ev0);
+    (void)hipEventCreate(&e->ev1);
+    *out = e;
+    return QR_OK;
+}
+
+int qr_destroy(qr_env* e) {
+    if (!e) return QR_OK;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->slab) (void)hipFree(e->slab);
+    if (e->d_tables) (void)hipFree(e->d_tables);
+    delete e;
+    return QR_OK;
+}
+
+int qr_state_len(const qr_env* e) { return e ? e->S : QR_E_INVALID; }
+int qr_obs_len(const qr_env* e) { return e ? e->L : QR_E_INVALID; }
+int qr_num_envs(const qr_env* e) { return e ? e->cfg.num_envs : QR_E_INVALID; }
+
+int qr_set_track(qr_env* e, const float* gate_pos, const float* gate_yaw, int32_t G, const float* start_pos) {
+    if (!e || !gate_pos || !gate_yaw || !start_pos) return fail(QR_E_INVALID, "qr_set_track: null argument");
+    if (G < 1 || G > QR_MAX_GATES) return fail(QR_E_INVALID, "qr_set_track: num_gates must be in 1..QR_MAX_GATES");
+    QR_HIP(hipSetDevice(e->cfg.device));
+    e->num_gates = G;
+    e->gate_pos.assign(gate_pos, gate_pos + 3 * G);
+    e->gate_yaw.assign(gate_yaw, gate_yaw + G);
+    e->gate_pos_rel.assign(3 * G, 0.0f);
+    e->gate_yaw_rel.assign(G, 0.0f);
+    // gate i expressed in the frame of gate i-1, looped track (R:307-319), float32 like the reference
+    for (int i = 0; i < G; ++i) {
+        const int j = (i + G - 1) % G;
+        const float dx = gate_pos[3 * i + 0] - gate_pos[3 * j + 0];
+        const float dy = gate_pos[3 * i + 1] - gate_pos[3 * j + 1];
+        const float c = cosf(gate_yaw[j]), s = sinf(gate_yaw[j]);
+        volatile float cx = c * dx, sy = s * dy, sx = -s * dx, cy = c * dy;  // no host FMA contraction
+        e->gate_pos_rel[3 * i + 0] = cx + sy;
+        e->gate_pos_rel[3 * i + 1] = sx + cy;
+        e->gate_pos_rel[3 * i + 2] = gate_pos[3 * i + 2] - gate_pos[3 * j + 2];
+        e->gate_yaw_rel[i] = gate_yaw[i] - gate_yaw[j];
+    }
+    for (int k = 0; k < 3; ++k) e->P.start[k] = start_pos[k];
+    e->P.num_gates = G;
+    e->has_track = true;
+    return upload_tables(e);
+}
+
+int qr_get_track_tables(const qr_env* e, float* gate_pos_rel, float* gate_yaw_rel) {
+    if (int rc = check_ready(e)) return rc;
+    if (gate_pos_rel) std::memcpy(gate_pos_rel, e->gate_pos_rel.data(), sizeof(float) * 3 * e->num_gates);
+    if (gate_yaw_rel) std::memcpy(gate_yaw_rel, e->gate_yaw_rel.data(), sizeof(float) * e->num_gates);
+    return QR_OK;
+}
+
+int qr_set_residual(qr_env* e, const float* blob, size_t n_floats) {
+    if (!e) return fail(QR_E_INVALID, "qr_set_residual: null env");
+    if (e->cfg.variant != QR_VARIANT_E2E) return fail(QR_E_INVALID, "qr_set_residual: E2E variant only");
+    QR_HIP(hipSetDevice(e->cfg.device));
+    if (!blob) {
+        e->P.flags &= ~qr::kFlagResidual;
+        return QR_OK;
+    }
+    if (n_floats != QR_RESIDUAL_FLOATS) return fail(QR_E_INVALID, "qr_set_residual: expected 740 floats");
+    // reference order (c_code/nn_thrust.c, nn_moment.c): W1[out][in], b1, W2[out][in], b2 per network
+    const float* tW1 = blob;         const float* tb1 = tW1 + 224;
+    const float* tW2 = tb1 + 32;     const float* tb2 = tW2 + 32;
+    const float* mW1 = tb2 + 1;      const float* mb1 = mW1 + 320;
+    const float* mW2 = mb1 + 32;     const float* mb2 = mW2 + 96;
+    float* T = e->mlp_table;
+    for (int i = 0; i < 7; ++i)
+        for (int j = 0; j < 32; ++j) {
+            T[64 * i + j] = tW1[j * 7 + i];
+            T[64 * i + 32 + j] = mW1[j * 10 + i];
+        }
+    for (int i = 7; i < 10; ++i)
+        for (int j = 0; j < 32; ++j) T[qr::kOffW1m + 32 * (i - 7) + j] = mW1[j * 10 + i];
+    for (int j = 0; j < 32; ++j) {
+        T[qr::kOffB1 + j] = tb1[j];
+        T[qr::kOffB1 + 32 + j] = mb1[j];
+        T[qr::kOffW2 + j] = tW2[j];
+        for (int o = 0; o < 3; ++o) T[qr::kOffW2 + 32 * (1 + o) + j] = mW2[o * 32 + j];
+    }
+    T[qr::kOffB2 + 0] = tb2[0];
+    for (int o = 0; o < 3; ++o) T[qr::kOffB2 + 1 + o] = mb2[o];
+    e->P.flags |= qr::kFlagResidual;
+    if (e->has_track) return upload_tables(e);
+    return QR_OK;
+}
+
+int qr_set_disturbance(qr_env* e, const float* ranges, float scale) {
+    if (!e || !ranges) return fail(QR_E_INVALID, "qr_set_disturbance: null argument");
+    if (e->cfg.variant != QR_VARIANT_E2E) return fail(QR_E_INVALID, "qr_set_disturbance: E2E variant only");
+    for (int k = 0; k < 6; ++k) {
+        e->P.dist_lo[k] = ranges[2 * k + 0];
+        e->P.dist_hi[k] = ranges[2 * k + 1];
+    }
+    e->P.dist_scale = scale;
+    return QR_OK;
+}
+
+int qr_set_limits(qr_env* e, int32_t max_steps, float dt) {
+    if (!e) return fail(QR_E_INVALID, "qr_set_limits: null env");
+    e->P.max_steps = max_steps;
+    e->P.dt = dt;
+    return QR_OK;
+}
+
+int qr_set_pause(qr_env* e, int32_t pause) {
+    if (!e) return fail(QR_E_INVALID, "qr_set_pause: null env");
+    if (pause) e->P.flags |= qr::kFlagPause; else e->P.flags &= ~qr::kFlagPause;
+    return QR_OK;
+}
+
+int qr_seed(qr_env* e, uint64_t seed) {
+    if (!e) return fail(QR_E_INVALID, "qr_seed: null env");
+    QR_HIP(hipSetDevice(e->cfg.device));
+    e->P.seed_lo = (uint32_t)seed;
+    e->P.seed_hi = (uint32_t)(seed >> 32);
+    QR_HIP(hipMemset(e->P.episode, 0, sizeof(uint32_t) * (size_t)e->P.n_stride));
+    return QR_OK;
+}
+
+int qr_reset(qr_env* e, const uint8_t* mask_dev, float* obs_out_dev, void* stream) {
+    if (int rc = check_ready(e)) return rc;
+    QR_HIP(qr::launch_reset(e->cfg.variant, e->P, mask_dev, obs_out_dev, (hipStream_t)stream));
+    return QR_OK;
+}
+
+int qr_step(qr_env* e, const float* actions_dev, float* obs_out_dev, float* rew_out_dev, uint8_t* done_out_dev,
+            uint8_t* trunc_out_dev, void* stream) {
+    if (int rc = check_ready(e)) return rc;
+    if (!actions_dev || !obs_out_dev || !rew_out_dev || !done_out_dev)
+        return fail(QR_E_INVALID, "qr_step: actions/obs/rew/done buffers are required");
+    QR_HIP(qr::launch_step(e->cfg.variant, e->P, actions_dev, obs_out_dev, rew_out_dev, done_out_dev, trunc_out_dev,
+                           (hipStream_t)stream));
+    return QR_OK;
+}
+
+int qr_step_many(qr_env* e, int32_t K, const float* actions_dev, float* obs_out_dev, float* rew_out_dev,
+                 uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream) {
+    if (int rc = check_ready(e)) return rc;
+    if (K < 1) return fail(QR_E_INVALID, "qr_step_many: num_steps must be >= 1");
+    if (!actions_dev || !obs_out_dev || !rew_out_dev || !done_out_dev)
+        return fail(QR_E_INVALID, "qr_step_many: actions/obs/rew/done buffers are required");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)e->cfg.num_envs;
+    QR_HIP(hipEventRecord(e->ev0, st));
+    for (int k = 0; k < K; ++k) {
+        QR_HIP(qr::launch_step(e->cfg.variant, e->P, actions_dev + (size_t)k * n * 4, obs_out_dev + (size_t)k * n * e->L,
+                               rew_out_dev + (size_t)k * n, done_out_dev + (size_t)k * n,
+                               trunc_out_dev ? trunc_out_dev + (size_t)k * n : nullptr, st));
+    }
+    QR_HIP(hipEventRecord(e->ev1, st));
+    e->timing_valid = true;
+    return QR_OK;
+}
+
+int qr_observe(qr_env* e, float* obs_out_dev, void* stream) {
+    if (int rc = check_ready(e)) return rc;
+    if (!obs_out_dev) return fail(QR_E_INVALID, "qr_observe: null output");
+    QR_HIP(qr::launch_observe(e->cfg.variant, e->P, obs_out_dev, (hipStream_t)stream));
+    return QR_OK;
+}
+
+int qr_get_state(qr_env* e, float* world_dev, float* dist_dev, int32_t* target_dev, int32_t* steps_dev,
+                 uint32_t* episode_dev, void* stream) {
+    if (!e) return fail(QR_E_INVALID, "qr_get_state: null env");
+    QR_HIP(qr::launch_get_state(e->cfg.variant, e->P, world_dev, dist_dev, target_dev, steps_dev, episode_dev,
+                                (hipStream_t)stream));
+    return QR_OK;
+}
+
+int qr_set_state(qr_env* e, const float* world_dev, const float* dist_dev, const int32_t* target_dev,
+                 const int32_t* steps_dev, const uint32_t* episode_dev, void* stream) {
+    if (int rc = check_ready(e)) return rc;  // target is reduced modulo num_gates
+    QR_HIP(qr::launch_set_state(e->cfg.variant, e->P, world_dev, dist_dev, target_dev, steps_dev, episode_dev,
+                                (hipStream_t)stream));
+    return QR_OK;
+}
+
+int qr_last_step_many_ms(qr_env* e, float* total_ms) {
+    if (!e || !total_ms) return fail(QR_E_INVALID, "qr_last_step_many_ms: null argument");
+    if (!e->timing_valid) return fail(QR_E_STATE, "qr_last_step_many_ms: no qr_step_many call recorded");
+    QR_HIP(hipEventSynchronize(e->ev1));
+    QR_HIP(hipEventElapsedTime(total_ms, e->ev0, e->ev1));
+    return QR_OK;
+}
+
+}  // extern "C"

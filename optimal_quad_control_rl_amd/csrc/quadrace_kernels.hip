@@ -1,0 +1,273 @@
+// quadrace_kernels.hip -- gfx950 kernels: fused env step, reset, observe, state import/export.
+//
+// Launch shape: 1 lane = 1 env, 256-thread workgroups (4 wave64).  At N = 65 536 that is 256 workgroups
+// = one per CU; larger N simply adds workgroups (block b lands on XCD b % 8, and consecutive blocks touch
+// consecutive 4 KiB slabs of every plane, so each XCD's L2 sees disjoint, fully-used lines).
+// Per workgroup the gate table and the residual-MLP weights (<= 4.5 KiB) are staged once into LDS.
+#include "quadrace_device.hpp"
+
+namespace qr {
+
+__device__ __forceinline__ void stage_tables(const Params& P, float* lds, int n_floats) {
+    // n_floats is a multiple of 4; tables pointer is 16-byte aligned
+    const float4* src = reinterpret_cast<const float4*>(P.tables);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = threadIdx.x; i < n_floats / 4; i += kBlock) dst[i] = src[i];
+}
+
+template <int V>
+__device__ __forceinline__ void load_env(const Params& P, int i, Env<V>& e) {
+    const float4 a = P.ws[i], b = P.ws[P.n_stride + i], c = P.ws[2 * P.n_stride + i];
+    e.s[0] = a.x; e.s[1] = a.y; e.s[2] = a.z; e.s[3] = a.w;
+    e.s[4] = b.x; e.s[5] = b.y; e.s[6] = b.z; e.s[7] = b.w;
+    e.s[8] = c.x; e.s[9] = c.y; e.s[10] = c.z; e.s[11] = c.w;
+    if constexpr (V == kE2E) {
+        const float4 d = P.ws[3 * P.n_stride + i];
+        e.s[12] = d.x; e.s[13] = d.y; e.s[14] = d.z; e.s[15] = d.w;
+        const float4 dA = P.dA[i];
+        const float2 dB = P.dB[i];
+        e.d[0] = dA.x; e.d[1] = dA.y; e.d[2] = dA.z; e.d[5] = dA.w;
+        e.d[3] = dB.x; e.d[4] = dB.y;
+    } else {
+        e.s[12] = P.tn[i];
+    }
+    const int2 ts = P.ts[i];
+    e.target = ts.x;
+    e.steps = ts.y;
+}
+
+template <int V>
+__device__ __forceinline__ void store_world(const Params& P, int i, const Env<V>& e) {
+    P.ws[i] = make_float4(e.s[0], e.s[1], e.s[2], e.s[3]);
+    P.ws[P.n_stride + i] = make_float4(e.s[4], e.s[5], e.s[6], e.s[7]);
+    P.ws[2 * P.n_stride + i] = make_float4(e.s[8], e.s[9], e.s[10], e.s[11]);
+    if constexpr (V == kE2E) {
+        P.ws[3 * P.n_stride + i] = make_float4(e.s[12], e.s[13], e.s[14], e.s[15]);
+    } else {
+        P.tn[i] = e.s[12];
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void store_dist(const Params& P, int i, const Env<V>& e) {
+    if constexpr (V == kE2E) {
+        P.dA[i] = make_float4(e.d[0], e.d[1], e.d[2], e.d[5]);
+        P.dB[i] = make_float2(e.d[3], e.d[4]);
+    }
+}
+
+template <int V, int GA>
+constexpr int obs_len() { return (V == kE2E) ? 16 + 4 * GA + 4 : 13 + 4 * GA; }
+
+// obs row -> caller's row-major [N][L] buffer.  E2E rows (20+4*GA floats) are 16-byte aligned.
+template <int V, int GA>
+__device__ __forceinline__ void store_obs(float* __restrict__ obs_out, int i, const float* o) {
+    constexpr int L = obs_len<V, GA>();
+    float* row = obs_out + (size_t)i * L;
+    if constexpr (V == kE2E) {
+        float4* r4 = reinterpret_cast<float4*>(row);
+#pragma unroll
+        for (int k = 0; k < L / 4; ++k) r4[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < L; ++k) row[k] = o[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused step: residual MLP -> EoM -> Euler -> reward/termination -> auto-reset -> gate-frame observation
+// ---------------------------------------------------------------------------------------------------
+template <int V, int GA>
+__global__ void __launch_bounds__(kBlock)
+step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ obs_out,
+            float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+    __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride + kMlpFloats];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = i < P.n;
+    const int ii = active ? i : 0;
+
+    // issue this lane's HBM loads first; the LDS staging below overlaps their latency
+    Env<V> e;
+    load_env<V>(P, ii, e);
+    const float4 act = actions[ii];
+
+    const int gate_floats = P.num_gates * kGateStride;
+    stage_tables(P, lds, gate_floats + ((V == kE2E && (P.flags & kFlagResidual)) ? kMlpFloats : 0));
+    __syncthreads();
+    if (!active) return;
+
+    const float u[4] = {act.x, act.y, act.z, act.w};
+    const uint32_t gid_lo = P.gid_lo + (uint32_t)i;
+    const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
+    bool done, trunc, did_reset;
+    const float reward = step_env<V>(P, lds, lds + gate_floats, e, u, gid_lo, gid_hi, P.episode + i, done, trunc,
+                                     did_reset);
+
+    rew_out[i] = reward;
+    done_out[i] = done ? 1 : 0;
+    if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
+    P.ts[i] = make_int2(e.target, e.steps);
+    if (P.flags & kFlagPause) return;  // world state and observation untouched (R:570-572)
+    store_world<V>(P, i, e);
+    if (did_reset) store_dist<V>(P, i, e);
+    float o[obs_len<V, GA>()];
+    observe<V, GA>(P, lds, e, o);
+    store_obs<V, GA>(obs_out, i, o);
+}
+
+// reset_(mask) + update_states for ALL envs (R:452-496)
+template <int V, int GA>
+__global__ void __launch_bounds__(kBlock)
+reset_kernel(Params P, const uint8_t* __restrict__ mask, float* __restrict__ obs_out) {
+    __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    stage_tables(P, lds, P.num_gates * kGateStride);
+    __syncthreads();
+    if (i >= P.n) return;
+    Env<V> e;
+    load_env<V>(P, i, e);
+    if (!mask || mask[i]) {
+        const uint32_t gid_lo = P.gid_lo + (uint32_t)i;
+        const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
+        const uint32_t ep = P.episode[i];
+        P.episode[i] = ep + 1u;
+        reset_env<V>(P, e, gid_lo, gid_hi, ep);
+        store_world<V>(P, i, e);
+        store_dist<V>(P, i, e);
+        P.ts[i] = make_int2(e.target, e.steps);
+    }
+    if (obs_out) {
+        float o[obs_len<V, GA>()];
+        observe<V, GA>(P, lds, e, o);
+        store_obs<V, GA>(obs_out, i, o);
+    }
+}
+
+// update_states(): observation from the current state
+template <int V, int GA>
+__global__ void __launch_bounds__(kBlock)
+observe_kernel(Params P, float* __restrict__ obs_out) {
+    __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    stage_tables(P, lds, P.num_gates * kGateStride);
+    __syncthreads();
+    if (i >= P.n) return;
+    Env<V> e;
+    load_env<V>(P, i, e);
+    float o[obs_len<V, GA>()];
+    observe<V, GA>(P, lds, e, o);
+    store_obs<V, GA>(obs_out, i, o);
+}
+
+// planar <-> row-major state export / import (attribute access in the adapter; parity injection)
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+get_state_kernel(Params P, float* __restrict__ world, float* __restrict__ dist, int32_t* __restrict__ target,
+                 int32_t* __restrict__ steps, uint32_t* __restrict__ episode) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P.n) return;
+    Env<V> e;
+    load_env<V>(P, i, e);
+    constexpr int S = Env<V>::S;
+    if (world) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) world[(size_t)i * S + k] = e.s[k];
+    }
+    if (V == kE2E && dist) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dist[(size_t)i * 6 + k] = e.d[k];
+    }
+    if (target) target[i] = e.target;
+    if (steps) steps[i] = e.steps;
+    if (episode) episode[i] = P.episode[i];
+}
+
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+set_state_kernel(Params P, const float* __restrict__ world, const float* __restrict__ dist,
+                 const int32_t* __restrict__ target, const int32_t* __restrict__ steps,
+                 const uint32_t* __restrict__ episode) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P.n) return;
+    Env<V> e;
+    load_env<V>(P, i, e);
+    constexpr int S = Env<V>::S;
+    if (world) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) e.s[k] = world[(size_t)i * S + k];
+        store_world<V>(P, i, e);
+    }
+    if (V == kE2E && dist) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) e.d[k] = dist[(size_t)i * 6 + k];
+        store_dist<V>(P, i, e);
+    }
+    if (target) {  // the reference indexes with target % num_gates (R:367-368); keep the invariant 0 <= t < G
+        int t = target[i] % P.num_gates;
+        if (t < 0) t += P.num_gates;
+        e.target = t;
+    }
+    if (steps) e.steps = steps[i];
+    P.ts[i] = make_int2(e.target, e.steps);
+    if (episode) P.episode[i] = episode[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host-callable launchers (used by quadrace_abi.hip)
+// ---------------------------------------------------------------------------------------------------
+static inline dim3 grid_for(int n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+// compile-time (variant, gates_ahead) dispatch: keeps every observation index static (registers, no scratch)
+#define QR_DISPATCH_GA(V, KERNEL, ...)                                                                  \
+    switch (P.gates_ahead) {                                                                            \
+        case 0: hipLaunchKernelGGL((KERNEL<V, 0>), grid_for(P.n), dim3(kBlock), 0, st, __VA_ARGS__); break; \
+        case 1: hipLaunchKernelGGL((KERNEL<V, 1>), grid_for(P.n), dim3(kBlock), 0, st, __VA_ARGS__); break; \
+        case 2: hipLaunchKernelGGL((KERNEL<V, 2>), grid_for(P.n), dim3(kBlock), 0, st, __VA_ARGS__); break; \
+        case 3: hipLaunchKernelGGL((KERNEL<V, 3>), grid_for(P.n), dim3(kBlock), 0, st, __VA_ARGS__); break; \
+        case 4: hipLaunchKernelGGL((KERNEL<V, 4>), grid_for(P.n), dim3(kBlock), 0, st, __VA_ARGS__); break; \
+        default: return hipErrorInvalidValue;                                                           \
+    }
+
+hipError_t launch_step(int variant, const Params& P, const float* actions, float* obs, float* rew, uint8_t* done,
+                       uint8_t* trunc, hipStream_t st) {
+    const float4* a4 = reinterpret_cast<const float4*>(actions);
+    if (variant == kE2E) { QR_DISPATCH_GA(kE2E, step_kernel, P, a4, obs, rew, done, trunc) }
+    else { QR_DISPATCH_GA(kINDI, step_kernel, P, a4, obs, rew, done, trunc) }
+    return hipGetLastError();
+}
+
+hipError_t launch_reset(int variant, const Params& P, const uint8_t* mask, float* obs, hipStream_t st) {
+    if (variant == kE2E) { QR_DISPATCH_GA(kE2E, reset_kernel, P, mask, obs) }
+    else { QR_DISPATCH_GA(kINDI, reset_kernel, P, mask, obs) }
+    return hipGetLastError();
+}
+
+hipError_t launch_observe(int variant, const Params& P, float* obs, hipStream_t st) {
+    if (variant == kE2E) { QR_DISPATCH_GA(kE2E, observe_kernel, P, obs) }
+    else { QR_DISPATCH_GA(kINDI, observe_kernel, P, obs) }
+    return hipGetLastError();
+}
+
+hipError_t launch_get_state(int variant, const Params& P, float* world, float* dist, int32_t* target, int32_t* steps,
+                            uint32_t* episode, hipStream_t st) {
+    if (variant == kE2E)
+        hipLaunchKernelGGL(get_state_kernel<kE2E>, grid_for(P.n), dim3(kBlock), 0, st, P, world, dist, target, steps,
+                           episode);
+    else
+        hipLaunchKernelGGL(get_state_kernel<kINDI>, grid_for(P.n), dim3(kBlock), 0, st, P, world, dist, target, steps,
+                           episode);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_state(int variant, const Params& P, const float* world, const float* dist,
+                            const int32_t* target, const int32_t* steps, const uint32_t* episode, hipStream_t st) {
+    if (variant == kE2E)
+        hipLaunchKernelGGL(set_state_kernel<kE2E>, grid_for(P.n), dim3(kBlock), 0, st, P, world, dist, target, steps,
+                           episode);
+    else
+        hipLaunchKernelGGL(set_state_kernel<kINDI>, grid_for(P.n), dim3(kBlock), 0, st, P, world, dist, target, steps,
+                           episode);
+    return hipGetLastError();
+}
+
+}  // namespace qr

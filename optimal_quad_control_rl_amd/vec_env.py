@@ -1,0 +1,434 @@
+"""Host-side mirror of the reference's `Quadcopter3DGates` VecEnv (R:287-620, I:142-410) on top of libquadrace.
+
+Same constructor, methods and public attributes as the reference class, so the reference's training cell
+(SB3 `VecMonitor` + `PPO`, R:765-795), `animate_policy` (R:800-810) and the C-controller test (R:4487-4519)
+can consume it unchanged -- but every step is one fused HIP kernel over all envs on the MI355X, and a
+device-tensor fast path (`step_device`, `rollout_device`) avoids any host round trip.
+
+There is no NumPy fallback: constructing an env without a gfx950 GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import QR_VARIANT_E2E, QR_VARIANT_INDI
+
+try:  # the reference imports `gymnasium.spaces` (R:284) / `gym.spaces` (I:139); neither is required here
+    from gymnasium import spaces as _spaces  # type: ignore
+except Exception:  # pragma: no cover - depends on the environment
+    try:
+        from gym import spaces as _spaces  # type: ignore
+    except Exception:
+        _spaces = None
+
+try:
+    from stable_baselines3.common.vec_env import VecEnv as _SB3VecEnv  # type: ignore
+except Exception:  # pragma: no cover
+    _SB3VecEnv = None
+
+
+class Box:
+    """Minimal stand-in for gymnasium.spaces.Box when gymnasium is not installed."""
+
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        self.shape = tuple(shape) if shape is not None else tuple(np.shape(low))
+        self.low = np.broadcast_to(np.asarray(low, dtype=dtype), self.shape).copy()
+        self.high = np.broadcast_to(np.asarray(high, dtype=dtype), self.shape).copy()
+        self.dtype = np.dtype(dtype)
+
+    def sample(self):
+        lo = np.where(np.isfinite(self.low), self.low, -1.0)
+        hi = np.where(np.isfinite(self.high), self.high, 1.0)
+        return np.random.uniform(lo, hi).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+def _make_box(low, high, shape=None):
+    if _spaces is not None:
+        if shape is not None:
+            return _spaces.Box(low=low, high=high, shape=shape, dtype=np.float32)
+        return _spaces.Box(low=np.asarray(low, np.float32), high=np.asarray(high, np.float32), dtype=np.float32)
+    return Box(low, high, shape)
+
+
+class _VecEnvBase:
+    """What SB3's abstract VecEnv provides to the reference class: the constructor contract and step()."""
+
+    def __init__(self, num_envs, observation_space, action_space):
+        self.num_envs = num_envs
+        self.observation_space = observation_space
+        self.action_space = action_space
+        self.render_mode = None
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+
+_Base = _SB3VecEnv if _SB3VecEnv is not None else _VecEnvBase
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def default_residual_blob():
+    """The reference's trained residual thrust/moment MLP weights (NNDroneModel/*.pt, R:227-229) as 740 f32."""
+    return np.fromfile(os.path.join(_DATA, "residual_mlp_f32.bin"), dtype=np.float32)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Quadcopter3DGates(_Base):
+    """End-to-end (motor command) Bebop race environment, vectorised on one MI355X.  Mirrors R:287-620.
+
+    Extra keyword-only arguments (not in the reference): `device` (cuda ordinal), `seed`, `residual`
+    ('default' = the reference's NNDroneModel weights, None = no residual model, or a 740-float blob),
+    `env_id_base` (global index of env 0 when sharding over GPUs), `infos_mode` ('reference' reproduces the
+    shared-dict behaviour of R:589-594, 'per_env' gives one dict per done env, 'none' skips the list).
+    """
+
+    VARIANT = QR_VARIANT_E2E
+    STATE_LEN = 16
+    _RENDER_KEYS = ['x', 'y', 'z', 'vx', 'vy', 'vz', 'phi', 'theta', 'psi', 'p', 'q', 'r', 'w1', 'w2', 'w3', 'w4']
+
+    def __init__(self, num_envs, gates_pos, gate_yaw, start_pos, gates_ahead=0, pause_if_collision=False, *,
+                 device=None, seed=0, residual="default", env_id_base=0, infos_mode="reference"):
+        self._h = None
+        self._L = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("Quadcopter3DGates needs a gfx950 GPU: libquadrace has no CPU fallback")
+        self._dev_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self._dev_index)
+
+        # Define the race track (R:298-302)
+        self.start_pos = np.asarray(start_pos).astype(np.float32)
+        self.gate_pos = np.asarray(gates_pos).astype(np.float32)
+        self.gate_yaw = np.asarray(gate_yaw).astype(np.float32)
+        self.num_gates = int(self.gate_pos.shape[0])
+        self.gates_ahead = int(gates_ahead)
+        self.pause_if_collision = bool(pause_if_collision)
+        self.infos_mode = infos_mode
+
+        cfg = _lib.QrConfig(self.VARIANT, int(num_envs), self.gates_ahead, self._dev_index,
+                            int(self.pause_if_collision), 0, int(env_id_base))
+        h = C.c_void_p()
+        _lib.check(self._L.qr_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        gp = np.ascontiguousarray(self.gate_pos)
+        gy = np.ascontiguousarray(self.gate_yaw)
+        sp = np.ascontiguousarray(self.start_pos)
+        _lib.check(self._L.qr_set_track(self._h, _f32p(gp), _f32p(gy), self.num_gates, _f32p(sp)))
+        # relative gates as computed by the library (R:307-319)
+        self.gate_pos_rel = np.zeros((self.num_gates, 3), dtype=np.float32)
+        self.gate_yaw_rel = np.zeros(self.num_gates, dtype=np.float32)
+        _lib.check(self._L.qr_get_track_tables(self._h, _f32p(self.gate_pos_rel), _f32p(self.gate_yaw_rel)))
+
+        self.state_len = int(self._L.qr_obs_len(self._h))  # R:330 / I:185
+        action_space = _make_box(-1, 1, shape=(4,))
+        observation_space = _make_box(np.array([-np.inf] * self.state_len), np.array([np.inf] * self.state_len))
+        _Base.__init__(self, int(num_envs), observation_space, action_space)
+
+        n, dev = self.num_envs, self.device
+        self._obs = torch.zeros((n, self.state_len), dtype=torch.float32, device=dev)
+        self._rew = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._done = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self._trunc = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self._act = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+        self.actions = np.zeros((n, 4), dtype=np.float32)
+        self.dones = np.zeros(n, dtype=bool)
+        self.final_gate_passed = np.zeros(n, dtype=bool)
+
+        self._max_steps = 1200          # R:345
+        self._dt = np.float32(0.01)     # R:346
+        self._pause = False             # R:360
+        self._disturbance_ranges = np.zeros((6, 2), dtype=np.float32)  # R:355
+        self._disturbance_scale = 1     # R:358
+        if self.VARIANT == QR_VARIANT_E2E:
+            if isinstance(residual, str):
+                if residual != "default":
+                    raise ValueError("residual must be 'default', None or a 740-float array")
+                residual = default_residual_blob()
+            self.set_residual(residual)
+        self.seed(seed)
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self._L.qr_destroy(self._h)
+            self._h = None
+
+    def set_residual(self, blob):
+        if blob is None:
+            _lib.check(self._L.qr_set_residual(self._h, None, 0))
+        else:
+            b = np.ascontiguousarray(blob, dtype=np.float32)
+            _lib.check(self._L.qr_set_residual(self._h, _f32p(b), b.size))
+
+    def _to_dev(self, a, dtype):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
+
+    # ------------------------------------------------------------------ reference attributes
+    @property
+    def max_steps(self):
+        return self._max_steps
+
+    @max_steps.setter
+    def max_steps(self, v):  # `test_env.max_steps = 10000` (I:648)
+        self._max_steps = int(v)
+        _lib.check(self._L.qr_set_limits(self._h, self._max_steps, float(self._dt)))
+
+    @property
+    def dt(self):
+        return self._dt
+
+    @dt.setter
+    def dt(self, v):
+        self._dt = np.float32(v)
+        _lib.check(self._L.qr_set_limits(self._h, self._max_steps, float(self._dt)))
+
+    @property
+    def pause(self):
+        return self._pause
+
+    @pause.setter
+    def pause(self, v):
+        self._pause = bool(v)
+        _lib.check(self._L.qr_set_pause(self._h, int(self._pause)))
+
+    @property
+    def disturbance_ranges(self):
+        return self._disturbance_ranges
+
+    @disturbance_ranges.setter
+    def disturbance_ranges(self, v):  # `env.venv.disturbance_ranges = ...` (R:780-781)
+        self._disturbance_ranges = np.array(v)
+        self._push_disturbance()
+
+    @property
+    def disturbance_scale(self):
+        return self._disturbance_scale
+
+    @disturbance_scale.setter
+    def disturbance_scale(self, v):
+        self._disturbance_scale = v
+        self._push_disturbance()
+
+    def _push_disturbance(self):
+        if self.VARIANT != QR_VARIANT_E2E:
+            return
+        r = np.ascontiguousarray(self._disturbance_ranges, dtype=np.float32).reshape(6, 2)
+        _lib.check(self._L.qr_set_disturbance(self._h, _f32p(r), float(self._disturbance_scale)))
+
+    def get_state_tensors(self):
+        """(world[N,S], disturbances[N,6] or None, target[N] i32, steps[N] i32, episode[N] u32->i64) on device."""
+        n, dev = self.num_envs, self.device
+        world = torch.empty((n, self.STATE_LEN), dtype=torch.float32, device=dev)
+        dist = torch.empty((n, 6), dtype=torch.float32, device=dev) if self.VARIANT == QR_VARIANT_E2E else None
+        target = torch.empty(n, dtype=torch.int32, device=dev)
+        steps = torch.empty(n, dtype=torch.int32, device=dev)
+        episode = torch.empty(n, dtype=torch.int32, device=dev)
+        _lib.check(self._L.qr_get_state(self._h, _ptr(world), _ptr(dist), _ptr(target), _ptr(steps), _ptr(episode),
+                                        self._stream()))
+        return world, dist, target, steps, episode
+
+    def set_state_tensors(self, world=None, dist=None, target=None, steps=None, episode=None):
+        w = None if world is None else self._to_dev(world, torch.float32)
+        d = None if dist is None or self.VARIANT != QR_VARIANT_E2E else self._to_dev(dist, torch.float32)
+        t = None if target is None else self._to_dev(target, torch.int32)
+        s = None if steps is None else self._to_dev(steps, torch.int32)
+        ep = None if episode is None else self._to_dev(episode, torch.int32)
+        if w is not None:
+            assert tuple(w.shape) == (self.num_envs, self.STATE_LEN), w.shape
+        _lib.check(self._L.qr_set_state(self._h, _ptr(w), _ptr(d), _ptr(t), _ptr(s), _ptr(ep), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()  # staging tensors may be freed after return
+
+    @property
+    def world_states(self):
+        return self.get_state_tensors()[0].cpu().numpy()
+
+    @world_states.setter
+    def world_states(self, v):
+        self.set_state_tensors(world=v)
+
+    @property
+    def disturbances(self):
+        d = self.get_state_tensors()[1]
+        return None if d is None else d.cpu().numpy()
+
+    @disturbances.setter
+    def disturbances(self, v):
+        self.set_state_tensors(dist=v)
+
+    @property
+    def target_gates(self):
+        return self.get_state_tensors()[2].cpu().numpy().astype(np.int64)
+
+    @target_gates.setter
+    def target_gates(self, v):
+        self.set_state_tensors(target=np.asarray(v, dtype=np.int32))
+
+    @property
+    def step_counts(self):
+        return self.get_state_tensors()[3].cpu().numpy().astype(np.int64)
+
+    @step_counts.setter
+    def step_counts(self, v):
+        self.set_state_tensors(steps=np.asarray(v, dtype=np.int32))
+
+    @property
+    def states(self):
+        """Observation array [N, state_len] of the last reset()/step() (R:343, read by animate_policy R:803)."""
+        return self._obs.cpu().numpy()
+
+    @property
+    def states_tensor(self):
+        return self._obs
+
+    # ------------------------------------------------------------------ reference methods
+    def update_states(self):
+        """update_states_gate (R:365-450)."""
+        _lib.check(self._L.qr_observe(self._h, _ptr(self._obs), self._stream()))
+
+    update_states_gate = update_states
+
+    def reset_(self, dones):
+        mask = self._to_dev(np.asarray(dones, dtype=np.uint8), torch.uint8)
+        _lib.check(self._L.qr_reset(self._h, _ptr(mask), _ptr(self._obs), self._stream()))
+        return self.states
+
+    def reset(self):
+        self.reset_device()
+        return self.states
+
+    def step_async(self, actions):
+        self.actions = actions
+
+    def step_wait(self):
+        act = self._to_dev(self.actions, torch.float32)
+        obs, rew, done, trunc = self.step_device(act)
+        done_np = done.cpu().numpy().astype(bool)
+        self.dones = done_np
+        rew_np = rew.cpu().numpy()
+        obs_np = obs.cpu().numpy()
+        infos = self._make_infos(obs_np, done_np, trunc)
+        return obs_np, rew_np, done_np, infos
+
+    def _make_infos(self, obs_np, done_np, trunc):
+        if self.infos_mode == "none":
+            return []
+        if self.infos_mode == "reference":
+            # R:589-594: `[{}] * N` aliases ONE dict, so every env sees terminal_observation (the post-reset row
+            # of the last done env) as soon as any env is done, and TimeLimit.truncated if any env timed out.
+            shared = {}
+            if done_np.any():
+                shared["terminal_observation"] = obs_np[np.nonzero(done_np)[0][-1]]
+            if trunc.any().item():
+                shared["TimeLimit.truncated"] = True
+            return [shared] * self.num_envs
+        infos = [{} for _ in range(self.num_envs)]
+        if done_np.any():
+            trunc_np = trunc.cpu().numpy().astype(bool)
+            for i in np.nonzero(done_np)[0]:
+                infos[i]["terminal_observation"] = obs_np[i]
+                if trunc_np[i]:
+                    infos[i]["TimeLimit.truncated"] = True
+        return infos
+
+    def seed(self, seed=None):
+        """Upstream seed() is a no-op (R:600-601); here it keys the in-kernel Philox reset stream."""
+        _lib.check(self._L.qr_seed(self._h, int(0 if seed is None else seed)))
+        return [seed] * self.num_envs
+
+    def get_attr(self, attr_name, indices=None):
+        raise AttributeError()  # R:603-604: makes SB3 >= 2.0 fall back to render_mode=None
+
+    def set_attr(self, attr_name, value, indices=None):
+        pass
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        pass
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * self.num_envs
+
+    def render(self, mode='human'):
+        """Dict of per-env arrays consumed by quadcopter_animation (R:615-620)."""
+        state_dict = dict(zip(self._RENDER_KEYS, self.world_states.T))
+        a = self.actions.detach().cpu().numpy() if isinstance(self.actions, torch.Tensor) else np.array(self.actions)
+        action_dict = dict(zip(['u1', 'u2', 'u3', 'u4'], (a.T + 1) / 2))
+        return {**state_dict, **action_dict}
+
+    # ------------------------------------------------------------------ device fast path (no host sync)
+    def reset_device(self):
+        _lib.check(self._L.qr_reset(self._h, None, _ptr(self._obs), self._stream()))
+        return self._obs
+
+    def step_device(self, actions):
+        """actions: float32 CUDA tensor [N,4].  Returns (obs, reward, done u8, trunc u8) device tensors; they are
+        the env's own buffers and are overwritten by the next step (clone them to keep a copy)."""
+        assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
+        assert tuple(actions.shape) == (self.num_envs, 4)
+        obs, rew, done, trunc = self._obs, self._rew, self._done, self._trunc
+        _lib.check(self._L.qr_step(self._h, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(trunc),
+                                   self._stream()))
+        return obs, rew, done, trunc
+
+    def rollout_device(self, actions, out=None):
+        """K steps with pre-recorded actions [K,N,4] -> (obs[K,N,L], reward[K,N], done[K,N], trunc[K,N])."""
+        assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
+        K = actions.shape[0]
+        assert tuple(actions.shape) == (K, self.num_envs, 4)
+        n, dev = self.num_envs, self.device
+        if out is None:
+            out = (torch.empty((K, n, self.state_len), dtype=torch.float32, device=dev),
+                   torch.empty((K, n), dtype=torch.float32, device=dev),
+                   torch.empty((K, n), dtype=torch.uint8, device=dev),
+                   torch.empty((K, n), dtype=torch.uint8, device=dev))
+        obs, rew, done, trunc = out
+        _lib.check(self._L.qr_step_many(self._h, int(K), _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(trunc),
+                                        self._stream()))
+        if not self._pause:
+            self._obs.copy_(obs[K - 1])
+        return out
+
+    def last_rollout_ms(self):
+        ms = C.c_float()
+        _lib.check(self._L.qr_last_step_many_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+
+class Quadcopter3DGatesINDI(Quadcopter3DGates):
+    """INDI inner-loop variant: actions are (p_cmd, q_cmd, r_cmd, T_cmd), 13-state model.  Mirrors I:142-410."""
+
+    VARIANT = QR_VARIANT_INDI
+    STATE_LEN = 13
+    _RENDER_KEYS = ['x', 'y', 'z', 'vx', 'vy', 'vz', 'phi', 'theta', 'psi', 'p', 'q', 'r', 'T']
+
+    def __init__(self, num_envs, gates_pos, gate_yaw, start_pos, gates_ahead=0, pause_if_collision=False, **kw):
+        kw.pop("residual", None)
+        super().__init__(num_envs, gates_pos, gate_yaw, start_pos, gates_ahead, pause_if_collision, residual=None, **kw)
+
+    def get_attr(self, attr_name, indices=None):
+        return None  # I:393-394

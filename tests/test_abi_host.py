@@ -1,0 +1,88 @@
+"""CPU-side checks (no GPU needed): the C-ABI library builds, loads and exports every symbol that
+include/quadrace.h declares; the ctypes table matches the header; host-side helpers behave like the
+reference's; and -- on a box without a GPU -- the product fails loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "quadrace.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(qr_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_header_symbol():
+    from optimal_quad_control_rl_amd import _lib, build
+
+    build.build_native()
+    L = C.CDLL(build.LIB)
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/quadrace.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    assert _lib.load().qr_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product must refuse to run (the oracle is test infrastructure, never a fallback)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from optimal_quad_control_rl_amd import _lib
+
+    L = _lib.load()
+    cfg = _lib.QrConfig(0, 16, 1, 0, 0, 0, 0)
+    h = C.c_void_p()
+    rc = L.qr_create(C.byref(cfg), C.byref(h))
+    assert rc == _lib.QR_E_NO_DEVICE, rc
+    assert b"no HIP device" in L.qr_last_error()
+    from optimal_quad_control_rl_amd import Quadcopter3DGates, zigzag_track
+
+    with pytest.raises(RuntimeError):
+        Quadcopter3DGates(4, *zigzag_track())
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "optimal_quad_control_rl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("CPU oracle", "").replace("the oracle", "") or f == "build.py", \
+                    f"{f} mentions the oracle"
+
+
+def test_tracks_match_reference_constants():
+    from optimal_quad_control_rl_amd import TRAIN_DISTURBANCE_RANGES, square_track, zigzag_track
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", "tracks.npz"))
+    for name, fn in (("zigzag", zigzag_track), ("square", square_track)):
+        gp, gy, sp = fn()
+        np.testing.assert_array_equal(gp, d[name + "_gate_pos"])
+        np.testing.assert_array_equal(gy, d[name + "_gate_yaw"])
+        np.testing.assert_array_equal(sp, d[name + "_start_pos"])
+    assert TRAIN_DISTURBANCE_RANGES.shape == (6, 2)
+
+
+def test_residual_blob_is_the_reference_weights():
+    from optimal_quad_control_rl_amd.vec_env import default_residual_blob
+
+    b = default_residual_blob()
+    assert b.shape == (740,) and b.dtype == np.float32
+    # first weights of nn_thrust_weights_fc1 (c_code/nn_thrust.c:6)
+    np.testing.assert_allclose(b[:3], [0.6684572696685791, 0.27626726031303406, -0.14709796011447906], rtol=1e-7)
+
+
+def test_box_stub():
+    from optimal_quad_control_rl_amd.vec_env import Box
+
+    b = Box(-1, 1, shape=(4,))
+    assert b.shape == (4,) and b.contains(b.sample())

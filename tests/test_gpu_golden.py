@@ -1,0 +1,233 @@
+"""GPU parity tests proper: the HIP product, called through the C ABI (ctypes adapter), replays the golden
+vectors generated from the real reference (tests/golden, tools/gen_golden.py) -- the same bar the CPU oracle
+is held to in tests/test_oracle_golden.py.  Tolerances are written in tests/parity.py (float32 path;
+north_star: 1e-5 relative on state vectors)."""
+import numpy as np
+import pytest
+
+import parity as P
+
+pytestmark = pytest.mark.gpu
+
+E2E, INDI = 0, 1
+
+
+@pytest.fixture(scope="module")
+def PA():
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from product_adapter import ProductAdapter
+
+    return ProductAdapter
+
+
+def test_native_library_is_loaded(PA):
+    """The product must run through libquadrace.so (hand-written HIP), never a fallback."""
+    from optimal_quad_control_rl_amd import _lib
+
+    a = PA(E2E, 4, P.tracks()["zigzag"])
+    with open("/proc/self/maps") as f:
+        assert "libquadrace.so" in f.read()
+    assert _lib.load().qr_num_envs(a.env._h) == 4
+
+
+@pytest.mark.parametrize("tname", ["zigzag", "square"])
+def test_track_tables(PA, tname):
+    d = P.load("tracks")
+    a = PA(E2E, 1, P.tracks()[tname])
+    np.testing.assert_allclose(a.env.gate_pos_rel, d[tname + "_gate_pos_rel"], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(a.env.gate_yaw_rel, d[tname + "_gate_yaw_rel"], rtol=0, atol=5e-7)
+
+
+# ---- F1/F2/F3: residual + equations of motion observed through one Euler step -------------------------
+def _euler_check(PA, variant, state, control, dist, dstate, residual):
+    n = state.shape[0]
+    a = PA(variant, n, P.tracks()["zigzag"], gates_ahead=0, residual=residual)
+    a.env.max_steps = 10 ** 6
+    a.set_state(state, dist, np.zeros(n, np.int32), np.zeros(n, np.int32))
+    obs, rew, done, trunc = a.step(control)
+    w = a.get_state()[0]
+    expect = (state + np.float32(0.01) * dstate).astype(np.float32)
+    live = ~done
+    assert live.sum() > 0.3 * n
+    err = P.rel_err(w[live], expect[live])
+    return err
+
+
+def test_f_func_e2e_through_step(PA):
+    d = P.load("f2_ffunc_e2e")
+    err = _euler_check(PA, E2E, d["state"], d["control"], d["disturbance"], d["dstate"], None)
+    assert err.max() < P.TOL_STEP_STATE, err.max(0)
+
+
+def test_f_func_indi_through_step(PA):
+    d = P.load("f3_ffunc_indi")
+    err = _euler_check(PA, INDI, d["state"], d["control"], None, d["dstate"], None)
+    assert err.max() < P.TOL_STEP_STATE, err.max(0)
+
+
+def test_residual_known_answer_through_step(PA, residual_blob):
+    """R:248-267 known answer: thrust 36.098232, moment [0.2847767,-0.22512697,-0.05896095] for state [0..15].
+    Observed through the accelerations they cause (F_ext_z -> vz, M_ext -> p,q,r)."""
+    d = P.load("f1_residual")
+    s = d["states"]
+    n = s.shape[0]
+    u = np.zeros((n, 4), np.float32)
+    with_res = PA(E2E, n, P.tracks()["zigzag"], gates_ahead=0, residual=residual_blob)
+    without = PA(E2E, n, P.tracks()["zigzag"], gates_ahead=0, residual=None)
+    out = []
+    for a in (with_res, without):
+        a.env.max_steps = 10 ** 6
+        a.env.pause_if_collision = False
+        a.set_state(s, np.zeros((n, 6), np.float32), np.zeros(n, np.int32), np.zeros(n, np.int32))
+        _, _, done, _ = a.step(u)
+        out.append((a.get_state()[0].astype(np.float64), done))
+    live = ~(out[0][1] | out[1][1])
+    dw = (out[0][0] - out[1][0]) / 0.01  # difference of derivatives = contribution of the residual model
+    # p,q,r accelerations: M / I  (R:144-146 constants)
+    inv_I = np.array([1103.7527593819, 805.152979066023, 486.854917234664])
+    m_est = dw[:, 9:12] / inv_I
+    assert live.sum() > 100
+    np.testing.assert_allclose(m_est[live], d["moment"][live], rtol=0, atol=2e-3)
+    i = 0  # the notebook's own row: identity attitude -> thrust acts on vz directly
+    if live[0]:
+        assert abs(dw[0, 5] - 36.098232) < 0.05
+
+
+# ---- F4: observation transform ----------------------------------------------------------------------------
+@pytest.mark.parametrize("tname", ["zigzag", "square"])
+@pytest.mark.parametrize("ga", [0, 1, 2])
+def test_obs_transform(PA, tname, ga):
+    d = P.load("f4_obs")
+    trk = P.tracks()[tname]
+    key = f"{tname}_e2e_ga{ga}"
+    n = d[key + "_world"].shape[0]
+    for rname, ranges in (("zero", np.zeros((6, 2), np.float32)), ("train", P.TRAIN_DIST_RANGES)):
+        a = PA(E2E, n, trk, gates_ahead=ga, dist_ranges=ranges)
+        a.set_state(d[key + "_world"], d[key + f"_dist_{rname}"], d[key + "_target"], np.zeros(n, np.int32))
+        obs = a.observe()
+        assert obs.shape == d[key + f"_obs_{rname}"].shape
+        assert P.rel_err(obs, d[key + f"_obs_{rname}"]).max() < P.TOL_STEP_OBS
+    key = f"{tname}_indi_ga{ga}"
+    a = PA(INDI, n, trk, gates_ahead=ga)
+    a.set_state(d[key + "_world"], None, d[key + "_target"], np.zeros(n, np.int32))
+    obs = a.observe()
+    assert obs.shape == d[key + "_obs"].shape
+    assert P.rel_err(obs, d[key + "_obs"]).max() < P.TOL_STEP_OBS
+
+
+# ---- F5: BASELINE config 1 ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("ga", [0, 1])
+@pytest.mark.parametrize("tag", ["ctrl", "hover", "random"])
+def test_config1_teacher_forced(PA, ga, tag):
+    traj = P.load("f5_traj_e2e_noresidual")
+    a = PA(E2E, 1, P.tracks()["zigzag"], gates_ahead=ga, residual=None)
+    rep = P.teacher_forced(a, traj, f"ga{ga}_{tag}_", has_dist=True)
+    print(tag, rep)
+    assert rep.steps == traj[f"ga{ga}_{tag}_actions"].shape[0]
+
+
+@pytest.mark.parametrize("tag", ["ctrl", "hover"])
+def test_config1_free_run_100(PA, tag):
+    """north_star correctness: single trajectory vs the reference's step() on an identical action sequence,
+    max |d state| / max(1,|state|) <= 1e-5 over 100 free-running steps."""
+    traj = P.load("f5_traj_e2e_noresidual")
+    a = PA(E2E, 1, P.tracks()["zigzag"], gates_ahead=1, residual=None)
+    rep = P.free_run(a, traj, f"ga1_{tag}_", has_dist=True, horizon=100)
+    print(tag, rep)
+
+
+# ---- F6: E2E + residual + disturbances (config 2 physics, small batch) ------------------------------------------
+@pytest.mark.parametrize("tname", ["zigzag", "square"])
+def test_e2e_residual_teacher_forced(PA, tname, residual_blob):
+    traj = P.load("f6_traj_e2e_residual")
+    n = traj[tname + "_world0"].shape[0]
+    a = PA(E2E, n, P.tracks()[tname], gates_ahead=1, residual=residual_blob, dist_ranges=P.TRAIN_DIST_RANGES)
+    rep = P.teacher_forced(a, traj, tname + "_", has_dist=True)
+    print(tname, rep)
+    assert rep.dones > 0 and rep.passes > 0
+
+
+# ---- F7: branch known-answers ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant,vname", [(E2E, "e2e"), (INDI, "indi")])
+def test_branches(PA, variant, vname, residual_blob):
+    d = P.load("f7_branches")
+    n = d[vname + "_world0"].shape[0]
+    a = PA(variant, n, P.tracks()["zigzag"], gates_ahead=1, residual=residual_blob)
+    a.set_state(d[vname + "_world0"], np.zeros((n, 6), np.float32), d[vname + "_target0"], d[vname + "_steps0"])
+    obs, rew, done, trunc = a.step(d[vname + "_actions"])
+    names = list(d[vname + "_names"])
+    np.testing.assert_array_equal(done, d[vname + "_done"].astype(bool), err_msg=str(names))
+    np.testing.assert_allclose(rew, d[vname + "_reward"], rtol=0, atol=2e-5)
+    w, _, t, s = a.get_state()
+    np.testing.assert_array_equal(t, d[vname + "_target"])
+    np.testing.assert_array_equal(s, d[vname + "_steps"])
+    assert trunc[names.index("max_steps")] and trunc.sum() == 1
+    live = ~done
+    assert P.rel_err(w[live], d[vname + "_world"][live]).max() < P.TOL_STEP_STATE
+    assert P.rel_err(obs[live], d[vname + "_obs"][live]).max() < P.TOL_STEP_OBS
+    i = names.index("pass_clean")
+    assert abs(rew[i] - 9.95) < 1e-4 and t[i] == 1
+
+
+# ---- F8: INDI (config 3 physics, small batch) ---------------------------------------------------------------------
+@pytest.mark.parametrize("key", ["zigzag", "square", "single"])
+def test_indi_teacher_forced(PA, key):
+    traj = P.load("f8_traj_indi")
+    n = traj[key + "_world0"].shape[0]
+    trk = P.tracks()["square" if key == "single" else key]
+    a = PA(INDI, n, trk, gates_ahead=1)
+    rep = P.teacher_forced(a, traj, key + "_", has_dist=False)
+    print(key, rep)
+    assert rep.passes > 0
+
+
+def test_indi_free_run_100(PA):
+    traj = P.load("f8_traj_indi")
+    a = PA(INDI, 1, P.tracks()["square"], gates_ahead=1)
+    rep = P.free_run(a, traj, "single_", has_dist=False, horizon=100)
+    print(rep)
+
+
+# ---- F9: pause_if_collision / pause -------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant,vname", [(E2E, "e2e"), (INDI, "indi")])
+def test_modes(PA, variant, vname, residual_blob):
+    d = P.load("f9_modes")
+    acts = d[vname + "_actions"]
+    n = acts.shape[1]
+    a = PA(variant, n, P.tracks()["zigzag"], gates_ahead=1, residual=residual_blob, pause_if_collision=True)
+    a.set_state(d[vname + "_world0"], d[vname + "_dist0"] if variant == E2E else None, d[vname + "_target0"],
+                d[vname + "_steps0"])
+    a.observe()
+    pause_from = int(d[vname + "_pause_from_step"])
+    for k in range(acts.shape[0]):
+        if k == pause_from:
+            a.set_pause(True)
+        obs, rew, done, trunc = a.step(acts[k])
+        w, _, t, s = a.get_state()
+        np.testing.assert_array_equal(done, d[vname + "_done"][k].astype(bool), err_msg=f"step {k}")
+        np.testing.assert_array_equal(t, d[vname + "_target"][k])
+        np.testing.assert_array_equal(s, d[vname + "_steps"][k])
+        assert np.abs(rew - d[vname + "_reward"][k]).max() < 1e-4, k
+        assert P.rel_err(w, d[vname + "_world"][k]).max() < 1e-4, k
+        assert P.rel_err(obs, d[vname + "_obs"][k]).max() < 1e-4, k
+
+
+# ---- reset distribution (reference ranges; this build's Philox stream) ----------------------------------------------
+@pytest.mark.parametrize("variant,vname", [(E2E, "e2e"), (INDI, "indi")])
+def test_reset_distribution(PA, variant, vname):
+    stats = P.load("reset_stats")
+    n = 20000
+    a = PA(variant, n, P.tracks()["zigzag"], gates_ahead=1, dist_ranges=P.TRAIN_DIST_RANGES, seed=123)
+    a.reset()
+    w, dist, t, s = a.get_state()
+    assert (t == 0).all() and (s == 0).all()
+    lo, hi = stats[vname + "_world_min"], stats[vname + "_world_max"]
+    span = hi - lo
+    assert (w.min(0) >= lo - 0.01 * span).all() and (w.max(0) <= hi + 0.01 * span).all()
+    np.testing.assert_allclose(w.mean(0), stats[vname + "_world_mean"], atol=0.03 * span.max(), rtol=0)
+    np.testing.assert_allclose(w.std(0), stats[vname + "_world_std"], rtol=0.03)
+    if variant == E2E:
+        assert (np.abs(dist[:, 3:5]) == 0).all()
+        np.testing.assert_allclose(dist.std(0)[[0, 1, 2, 5]], stats["e2e_dist_std"][[0, 1, 2, 5]], rtol=0.03)
