@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the MI355X-native quadrotor race environment (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--variant e2e|indi] [--envs 65536]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one env.step() of the whole batch: ONE fused HIP kernel over all envs of the rank
+(residual MLPs -> Euler -> reward / gate logic -> auto-reset -> gate-frame observation), launched through
+the C ABI (qr_step_many).  Workload at N=1 = BASELINE.json configs[1]: 65 536 envs, Bebop E2E + NNDroneModel
+residual MLPs + training disturbance ranges, gates_ahead = 1, 7-gate zigzag track, random U(-1,1) actions
+pre-generated on the device [K][N][4] (Philox seed 0); outputs go to a full rollout buffer [K][N][...]
+(what PPO's collect phase stores), so every step writes fresh HBM.  Inputs are resident in HBM before the
+timed region.  With --gpus N each rank simulates its own 65 536-env shard (weak scaling, no data-path
+collective); the rollout-boundary RCCL all-gather of [obs|reward|done] is measured separately ("exchange").
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (HBM-bound kernel, algorithmic bytes/launch from
+SURVEY 8(d) / DESIGN.md divided by the mean kernel duration from per-launch hipEvents on the launch stream),
+"cpu_baseline" (the CPU oracle -- a C port of the reference, parity-pinned -- timed on this box's host cores
+on a bounded sample), "parity" (north_star single-trajectory max |d state| vs the reference's recorded step()).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+BYTES_PER_ENV_STEP = {"e2e": lambda ga: 189 + 4 * (20 + 4 * ga), "indi": lambda ga: 141 + 4 * (13 + 4 * ga)}
+# e2e: read world 64 + dist 24 + action 16 + target 4 + steps 4 = 112; write world 64 + obs 4*(20+4G) + reward 4
+#      + done 1 + target 4 + steps 4  -> 285 B at G=1.  indi: read 52+16+4+4 = 76; write 52 + 4*(13+4G) + 13 -> 209 B.
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--variant", default="e2e", choices=["e2e", "indi"])
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--gates-ahead", type=int, default=1)
+    ap.add_argument("--repeats", type=int, default=5, help="timed repetitions of the K-step region (median reported)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exchange", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_env(variant, n, ga, env_id_base, seed=0):
+    from optimal_quad_control_rl_amd import (Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES,
+                                             square_track, zigzag_track)
+
+    if variant == "e2e":
+        env = Quadcopter3DGates(n, *zigzag_track(), gates_ahead=ga, seed=seed, env_id_base=env_id_base,
+                                residual="default", infos_mode="none")
+        env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES  # R:772-781
+    else:
+        env = Quadcopter3DGatesINDI(n, *square_track(), gates_ahead=ga, seed=seed, env_id_base=env_id_base,
+                                    infos_mode="none")
+    return env
+
+
+def parity_probe():
+    """north_star correctness: 1 env, E2E, no residual, recorded action sequence (tests/golden F5, generated
+    from the real reference): free-running 100 steps, max |d state| / max(1,|state|)."""
+    import torch
+    from optimal_quad_control_rl_amd import Quadcopter3DGates, zigzag_track
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", "f5_traj_e2e_noresidual.npz"))
+    p = "ga1_ctrl_"
+    env = Quadcopter3DGates(1, *zigzag_track(), gates_ahead=1, residual=None, infos_mode="none")
+    env.set_state_tensors(world=d[p + "world0"], dist=d[p + "dist0"], target=d[p + "target0"], steps=d[p + "steps0"])
+    worst = 0.0
+    for k in range(100):
+        env.step_device(torch.as_tensor(d[p + "actions"][k]).cuda())
+        w = env.get_state_tensors()[0].cpu().numpy().astype(np.float64)
+        ref = d[p + "world"][k].astype(np.float64)
+        worst = max(worst, float((np.abs(w - ref) / np.maximum(1.0, np.abs(ref))).max()))
+    return {"max_rel_dstate_100_steps": worst, "tolerance": 1e-5, "reference": "tests/golden/f5 (ref step(), 1 env, no residual)"}
+
+
+def cpu_baseline(variant, n, ga, seconds):
+    """The oracle (C port of the reference, parity-pinned against reference fixtures) on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+    from optimal_quad_control_rl_amd import TRAIN_DISTURBANCE_RANGES, square_track, zigzag_track
+    from optimal_quad_control_rl_amd.vec_env import default_residual_blob
+
+    cores = len(os.sched_getaffinity(0))
+    trk = zigzag_track() if variant == "e2e" else square_track()
+    env = O.OracleEnv(O.E2E if variant == "e2e" else O.INDI, n, *trk, gates_ahead=ga)
+    if variant == "e2e":
+        env.set_residual(default_residual_blob())
+        env.set_disturbance(TRAIN_DISTURBANCE_RANGES, 1.0)
+    env.seed(0)
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, size=(8, n, 4)).astype(np.float32)
+    out = {}
+    for threads in (1, cores):
+        env.set_threads(threads)
+        env.reset()
+        env.step(acts[0])
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < seconds / 2 and steps < 2000:
+            env.step(acts[steps % 8])
+            steps += 1
+        dt = time.perf_counter() - t0
+        out[threads] = (n * steps / dt, steps)
+    best_threads = max(out, key=lambda k: out[k][0])
+    return {"value": out[best_threads][0], "unit": "env-steps/s", "cores": best_threads, "kind": "port",
+            "sample": f"{out[best_threads][1]} steps x {n} envs, same workload ({variant}, random actions), oracle/quadrace_oracle.c"
+                      f" with OpenMP over envs; {out[1][1]} steps single-thread",
+            "value_1core": out[1][0], "host_cores": cores}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n, K, W, ga = args.envs, args.steps, args.warmup, args.gates_ahead
+    env = make_env(args.variant, n, ga, env_id_base=rank * n, seed=0)
+    L = env.state_len
+    dev = env.device
+    gen = torch.Generator(device=dev).manual_seed(rank)  # torch Philox, seed = rank
+    KB = max(K, W, 1)
+    actions = torch.rand((KB, n, 4), device=dev, generator=gen) * 2 - 1
+    out = (torch.empty((KB, n, L), dtype=torch.float32, device=dev), torch.empty((KB, n), dtype=torch.float32, device=dev),
+           torch.empty((KB, n), dtype=torch.uint8, device=dev), torch.empty((KB, n), dtype=torch.uint8, device=dev))
+
+    def view(k):
+        return tuple(t[:k] for t in out)
+
+    env.reset_device()
+    if W > 0:
+        env.rollout_device(actions[:W], view(W))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    times = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        env.rollout_device(actions[:K], view(K))  # EXACTLY K steps
+        barrier()
+        times.append(time.perf_counter() - t0)
+    elapsed = float(np.median(times))
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    dones_frac = float(out[2][:K].float().mean().item())
+
+    # --- roofline of the dominant kernel: per-launch hipEvents on the launch stream -----------------------------
+    Kp = min(K, 500)
+    mean_kernel_ms, region_ms = env.profile_rollout(actions[:Kp], view(Kp))
+    bytes_per_launch = BYTES_PER_ENV_STEP[args.variant](ga) * n
+    achieved = bytes_per_launch / (mean_kernel_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            traffic = pmc.get(f"{args.variant}_n{n}_ga{ga}", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel": f"qr::step_kernel<{args.variant},ga={ga}>", "kernel_us": mean_kernel_ms * 1e3,
+                "bytes_per_launch": bytes_per_launch, "launches_timed": Kp,
+                "region_us_per_step": region_ms * 1e3 / Kp}
+
+    # --- rollout-boundary exchange (config 4): RCCL all-gather of [obs | reward | done] --------------------------
+    exchange = None
+    if world > 1 and not args.no_exchange:
+        from optimal_quad_control_rl_amd.sharded import pack_rollout
+
+        Kx = min(K, 64)
+        packed = pack_rollout(out[0][:Kx], out[1][:Kx], out[2][:Kx])
+        gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=dev)
+        dist.all_gather_into_tensor(gathered, packed)
+        barrier()
+        t0 = time.perf_counter()
+        dist.all_gather_into_tensor(gathered, packed)
+        barrier()
+        dt = time.perf_counter() - t0
+        exchange = {"op": "all_gather_into_tensor(RCCL)", "steps": Kx, "bytes_per_rank": packed.numel() * 4,
+                    "ms": dt * 1e3, "GBps_in_per_gpu": packed.numel() * 4 * (world - 1) / dt / 1e9}
+
+    if rank == 0:
+        total_steps = n * world * K
+        result = {
+            "metric": "env-steps/sec at N=65536 envs per GPU (Quadcopter3DGates.step, "
+                      + ("E2E + residual MLPs" if args.variant == "e2e" else "INDI inner loop") + ")",
+            "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n} envs/GPU, " + ("Bebop E2E (motor-cmd actions) + NNDroneModel residual MLPs + "
+                                                         "training disturbance ranges, 7-gate zigzag"
+                                                         if args.variant == "e2e" else "INDI inner-loop variant, 4-gate square (x2)")
+                       + f", gates_ahead={ga}, U(-1,1) actions pre-generated on device, outputs to a [K][N] rollout buffer",
+                       "envs_per_gpu": n, "variant": args.variant, "gates_ahead": ga, "obs_len": L,
+                       "sharding": f"{world} independent shard(s), env_id_base = rank*N"},
+            "repeats": len(times), "all_ms_per_step": [t * 1e3 / K for t in times], "done_fraction": dones_frac,
+            "roofline": roofline,
+        }
+        if exchange:
+            result["exchange"] = exchange
+        if world == 1:
+            try:
+                result["parity"] = parity_probe()
+            except Exception as ex:  # pragma: no cover
+                result["parity"] = {"error": repr(ex)}
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline(args.variant, n, ga, args.cpu_seconds)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -128,9 +128,15 @@ int qr_get_state(qr_env* env, float* world_dev, float* dist_dev, int32_t* target
 int qr_set_state(qr_env* env, const float* world_dev, const float* dist_dev, const int32_t* target_dev,
                  const int32_t* steps_dev, const uint32_t* episode_dev, void* stream);
 
-/* Timing hook for benchmarks: mean duration (ms) of the step kernels launched by the last
- * qr_step_many call, measured with hipEvents on the launch stream. Blocks until that work is done. */
+/* Timing hooks for benchmarks (both block until the work is done).
+ * qr_last_step_many_ms: hipEvent time (ms) from the first to after the last launch of the most recent
+ *   qr_step_many call, on its launch stream (kernels + inter-launch gaps).
+ * qr_profile_steps: like qr_step_many, but brackets EVERY step kernel with its own hipEvent pair on the
+ *   launch stream and returns the mean single-kernel duration (ms) and the whole-region time (ms). */
 int qr_last_step_many_ms(qr_env* env, float* total_ms);
+int qr_profile_steps(qr_env* env, int32_t num_steps, const float* actions_dev, float* obs_out_dev,
+                     float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream,
+                     float* mean_kernel_ms, float* region_ms);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,7 @@ SIGNATURES = {
     "qr_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qr_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qr_last_step_many_ms": (C.c_int, [_vp, _f32p]),
+    "qr_profile_steps": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _f32p, _f32p]),
 }
 
 

@@ -342,4 +342,35 @@ int qr_last_step_many_ms(qr_env* e, float* total_ms) {
     return QR_OK;
 }
 
+int qr_profile_steps(qr_env* e, int32_t K, const float* actions_dev, float* obs_out_dev, float* rew_out_dev,
+                     uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream, float* mean_kernel_ms,
+                     float* region_ms) {
+    if (int rc = check_ready(e)) return rc;
+    if (K < 1 || !mean_kernel_ms || !region_ms) return fail(QR_E_INVALID, "qr_profile_steps: bad argument");
+    if (!actions_dev || !obs_out_dev || !rew_out_dev || !done_out_dev)
+        return fail(QR_E_INVALID, "qr_profile_steps: actions/obs/rew/done buffers are required");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)e->cfg.num_envs;
+    std::vector<hipEvent_t> ev(2 * (size_t)K);
+    for (auto& x : ev) QR_HIP(hipEventCreate(&x));
+    for (int k = 0; k < K; ++k) {
+        QR_HIP(hipEventRecord(ev[2 * k], st));
+        QR_HIP(qr::launch_step(e->cfg.variant, e->P, actions_dev + (size_t)k * n * 4, obs_out_dev + (size_t)k * n * e->L,
+                               rew_out_dev + (size_t)k * n, done_out_dev + (size_t)k * n,
+                               trunc_out_dev ? trunc_out_dev + (size_t)k * n : nullptr, st));
+        QR_HIP(hipEventRecord(ev[2 * k + 1], st));
+    }
+    QR_HIP(hipEventSynchronize(ev[2 * K - 1]));
+    double sum = 0.0;
+    for (int k = 0; k < K; ++k) {
+        float ms = 0.0f;
+        QR_HIP(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
+        sum += ms;
+    }
+    QR_HIP(hipEventElapsedTime(region_ms, ev[0], ev[2 * K - 1]));
+    *mean_kernel_ms = (float)(sum / K);
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    return QR_OK;
+}
+
 }  // extern "C"

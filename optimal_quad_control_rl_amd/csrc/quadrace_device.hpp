@@ -76,9 +76,22 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }
-// lo + (hi-lo)*u with separately rounded operations (bit-identical to the CPU oracle; no FMA contraction)
+// Separately rounded operations (bit-identical to the CPU oracle).  NB: HIP's __fadd_rn/__fmul_rn are plain
+// operators that hipcc may still contract into an FMA, so contraction is switched off with the pragma.
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+// lo + (hi-lo)*u
 __device__ __forceinline__ float uni(float lo, float hi, float u) {
-    return __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), u));
+#pragma clang fp contract(off)
+    const float span = hi - lo;
+    const float prod = span * u;
+    return lo + prod;
 }
 
 template <int V>
@@ -103,9 +116,9 @@ __device__ __forceinline__ void reset_env(const Params& P, Env<V>& e, uint32_t g
         for (int k = 0; k < 4; ++k) u[4 * b + k] = u01(o[k]);
     }
     const float pi9 = 0.3490658503988659f, pi = 3.141592653589793f;
-    e.s[0] = __fadd_rn(uni(-0.5f, 0.5f, u[0]), P.start[0]);
-    e.s[1] = __fadd_rn(uni(-0.5f, 0.5f, u[1]), P.start[1]);
-    e.s[2] = __fadd_rn(uni(-0.5f, 0.5f, u[2]), P.start[2]);
+    e.s[0] = add_rn(uni(-0.5f, 0.5f, u[0]), P.start[0]);
+    e.s[1] = add_rn(uni(-0.5f, 0.5f, u[1]), P.start[1]);
+    e.s[2] = add_rn(uni(-0.5f, 0.5f, u[2]), P.start[2]);
     e.s[3] = uni(-0.5f, 0.5f, u[3]);
     e.s[4] = uni(-0.5f, 0.5f, u[4]);
     e.s[5] = uni(-0.5f, 0.5f, u[5]);
@@ -119,7 +132,7 @@ __device__ __forceinline__ void reset_env(const Params& P, Env<V>& e, uint32_t g
 #pragma unroll
         for (int k = 0; k < 4; ++k) e.s[12 + k] = uni(-1.0f, 1.0f, u[12 + k]);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) e.d[k] = __fmul_rn(P.dist_scale, uni(P.dist_lo[k], P.dist_hi[k], u[16 + k]));
+        for (int k = 0; k < 6; ++k) e.d[k] = mul_rn(P.dist_scale, uni(P.dist_lo[k], P.dist_hi[k], u[16 + k]));
     } else {
         e.s[12] = uni(-0.1f, 0.1f, u[12]);
     }

@@ -413,6 +413,16 @@ class Quadcopter3DGates(_Base):
             self._obs.copy_(obs[K - 1])
         return out
 
+    def profile_rollout(self, actions, out):
+        """Like rollout_device but every step kernel is bracketed by its own hipEvent pair on the launch stream.
+        Returns (mean single-kernel duration in ms, whole-region ms).  Blocks."""
+        K = actions.shape[0]
+        obs, rew, done, trunc = out
+        mean_ms, region_ms = C.c_float(), C.c_float()
+        _lib.check(self._L.qr_profile_steps(self._h, int(K), _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done),
+                                            _ptr(trunc), self._stream(), C.byref(mean_ms), C.byref(region_ms)))
+        return float(mean_ms.value), float(region_ms.value)
+
     def last_rollout_ms(self):
         ms = C.c_float()
         _lib.check(self._L.qr_last_step_many_ms(self._h, C.byref(ms)))

@@ -46,6 +46,7 @@ def lib():
         L.qro_set_disturbance.argtypes = [C.c_void_p, _f32p, C.c_float]
         L.qro_set_limits.argtypes = [C.c_void_p, C.c_int, C.c_float]
         L.qro_set_pause.argtypes = [C.c_void_p, C.c_int]
+        L.qro_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.qro_seed.argtypes = [C.c_void_p, C.c_uint64]
         L.qro_reset.argtypes = [C.c_void_p, _u8p, _f32p]
         L.qro_step.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _u8p, _u8p]
@@ -178,6 +179,10 @@ class OracleEnv:
 
     def set_pause(self, pause):
         self.L.qro_set_pause(self.h, int(bool(pause)))
+
+    def set_threads(self, threads):
+        """cpu_baseline only: spread the independent envs over OpenMP threads (results are unchanged)."""
+        return self.L.qro_set_threads(self.h, int(threads))
 
     def seed(self, seed):
         self.L.qro_seed(self.h, int(seed))

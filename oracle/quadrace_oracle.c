@@ -25,6 +25,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define QRO_MAX_GATES 32
 #define QRO_E2E 0
@@ -44,6 +47,7 @@ typedef struct qro_env {
     float *world, *dist, *obs;
     int32_t *target, *steps;
     uint32_t* episode;
+    int threads; /* cpu_baseline only: OpenMP threads over the (independent) envs; 1 = scalar loop */
 } qro_env;
 
 /* ------------------------------------------------------------------------------------------------
@@ -308,6 +312,9 @@ static void observe_one(const qro_env* e, int i, float* o) {
 }
 
 void qro_observe(qro_env* e, float* obs_out) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(e->threads) if (e->threads > 1)
+#endif
     for (int i = 0; i < e->n; ++i) observe_one(e, i, e->obs + (size_t)i * e->obs_len);
     if (obs_out) memcpy(obs_out, e->obs, sizeof(float) * (size_t)e->n * e->obs_len);
 }
@@ -327,6 +334,7 @@ qro_env* qro_create(int variant, int n, int gates_ahead, int pause_if_collision,
     e->dt = 0.01f;                                                              /* R:346 */
     e->dist_scale = 1.0f;                                                       /* R:358 */
     e->env_id_base = env_id_base;
+    e->threads = 1;
     e->world = (float*)calloc((size_t)n * e->state_len, sizeof(float));
     e->dist = (float*)calloc((size_t)n * 6, sizeof(float));
     e->obs = (float*)calloc((size_t)n * e->obs_len, sizeof(float));
@@ -372,6 +380,15 @@ void qro_set_disturbance(qro_env* e, const float* ranges, float scale) {
 }
 void qro_set_limits(qro_env* e, int max_steps, float dt) { e->max_steps = max_steps; e->dt = dt; }
 void qro_set_pause(qro_env* e, int pause) { e->pause = pause; }
+int qro_set_threads(qro_env* e, int threads) {
+#ifdef _OPENMP
+    e->threads = threads < 1 ? 1 : threads;
+#else
+    (void)threads;
+    e->threads = 1;
+#endif
+    return e->threads;
+}
 void qro_seed(qro_env* e, uint64_t seed) {
     e->seed = seed;
     memset(e->episode, 0, sizeof(uint32_t) * (size_t)e->n);
@@ -403,6 +420,9 @@ void qro_reset(qro_env* e, const uint8_t* mask, float* obs_out) {
 void qro_step(qro_env* e, const float* actions, float* obs_out, float* rew_out, uint8_t* done_out,
               uint8_t* trunc_out) {
     const int S = e->state_len, G = e->num_gates;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(e->threads) if (e->threads > 1)
+#endif
     for (int i = 0; i < e->n; ++i) {
         float* w = e->world + (size_t)i * S;
         const float* a = actions + (size_t)i * 4;

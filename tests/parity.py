@@ -18,7 +18,7 @@ TRAIN_DIST_RANGES = np.array([[-0.03, 0.03], [-0.03, 0.03], [-0.01, 0.01], [0, 0
 #   one teacher-forced step: the reference's own lambdified expression has ~1e-5 absolute rounding noise
 #   in the angular accelerations (cancellation of +-100-sized terms), i.e. ~1e-7 on a state after *dt.
 TOL_STEP_STATE = 2e-6   # |d state| / max(1,|state|) after ONE step from identical state
-TOL_STEP_OBS = 4e-6
+TOL_STEP_OBS = 8e-6   # gate-frame positions reach ~10 m: a rotation (2 products + add) is a few ulp(10)=9.5e-7
 TOL_STEP_REWARD = 2e-5  # absolute; rewards are differences of O(1..10) distances
 TOL_FREE_RUN = 1e-5     # north_star: free-running 100 steps, max |d state| / max(1,|state|)
 
@@ -36,6 +36,19 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+def obs_err(a, b):
+    """Observation error.  Columns 0..5 are 2-D rotations of (pos - gate, vel) into the gate frame: a small
+    component can come from cancellation of large operands, so its rounding noise scales with the length of the
+    rotated vector (|obs[0:2]|, |obs[3:5]| are rotation invariant), not with the component itself."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    err = np.abs(a - b)
+    scale = np.maximum(1.0, np.abs(b))
+    scale[..., 0:2] = np.maximum(1.0, np.linalg.norm(b[..., 0:2], axis=-1, keepdims=True))
+    scale[..., 3:5] = np.maximum(1.0, np.linalg.norm(b[..., 3:5], axis=-1, keepdims=True))
+    return err / scale
 
 
 class TrajectoryReport:
@@ -77,7 +90,7 @@ def teacher_forced(env, traj, prefix, has_dist, tol_state=TOL_STEP_STATE, tol_ob
             live = ~ref_done
             if live.any():
                 es = rel_err(w_new[live], g("world")[k][live]).max()
-                eo = rel_err(obs[live], g("obs")[k][live]).max()
+                eo = obs_err(obs[live], g("obs")[k][live]).max()
                 rep.max_state, rep.max_obs = max(rep.max_state, float(es)), max(rep.max_obs, float(eo))
                 assert es <= tol_state, f"state mismatch at step {k}: {es}"
                 assert eo <= tol_obs, f"obs mismatch at step {k}: {eo}"
@@ -102,7 +115,7 @@ def free_run(env, traj, prefix, has_dist, horizon=100, tol=TOL_FREE_RUN):
         w_new, _, t_new, s_new = env.get_state()
         es = rel_err(w_new, g("world")[k]).max()
         rep.max_state = max(rep.max_state, float(es))
-        rep.max_obs = max(rep.max_obs, float(rel_err(obs, g("obs")[k]).max()))
+        rep.max_obs = max(rep.max_obs, float(obs_err(obs, g("obs")[k]).max()))
         rep.max_reward = max(rep.max_reward, float(np.abs(rew - g("reward")[k]).max()))
         assert not done.any(), f"unexpected termination at free-run step {k}"
         np.testing.assert_array_equal(t_new, g("target")[k])

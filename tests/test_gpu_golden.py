@@ -108,13 +108,13 @@ def test_obs_transform(PA, tname, ga):
         a.set_state(d[key + "_world"], d[key + f"_dist_{rname}"], d[key + "_target"], np.zeros(n, np.int32))
         obs = a.observe()
         assert obs.shape == d[key + f"_obs_{rname}"].shape
-        assert P.rel_err(obs, d[key + f"_obs_{rname}"]).max() < P.TOL_STEP_OBS
+        assert P.obs_err(obs, d[key + f"_obs_{rname}"]).max() < P.TOL_STEP_OBS
     key = f"{tname}_indi_ga{ga}"
     a = PA(INDI, n, trk, gates_ahead=ga)
     a.set_state(d[key + "_world"], None, d[key + "_target"], np.zeros(n, np.int32))
     obs = a.observe()
     assert obs.shape == d[key + "_obs"].shape
-    assert P.rel_err(obs, d[key + "_obs"]).max() < P.TOL_STEP_OBS
+    assert P.obs_err(obs, d[key + "_obs"]).max() < P.TOL_STEP_OBS
 
 
 # ---- F5: BASELINE config 1 ----------------------------------------------------------------------------------
@@ -166,7 +166,7 @@ def test_branches(PA, variant, vname, residual_blob):
     assert trunc[names.index("max_steps")] and trunc.sum() == 1
     live = ~done
     assert P.rel_err(w[live], d[vname + "_world"][live]).max() < P.TOL_STEP_STATE
-    assert P.rel_err(obs[live], d[vname + "_obs"][live]).max() < P.TOL_STEP_OBS
+    assert P.obs_err(obs[live], d[vname + "_obs"][live]).max() < P.TOL_STEP_OBS
     i = names.index("pass_clean")
     assert abs(rew[i] - 9.95) < 1e-4 and t[i] == 1
 
@@ -211,7 +211,7 @@ def test_modes(PA, variant, vname, residual_blob):
         np.testing.assert_array_equal(s, d[vname + "_steps"][k])
         assert np.abs(rew - d[vname + "_reward"][k]).max() < 1e-4, k
         assert P.rel_err(w, d[vname + "_world"][k]).max() < 1e-4, k
-        assert P.rel_err(obs, d[vname + "_obs"][k]).max() < 1e-4, k
+        assert P.obs_err(obs, d[vname + "_obs"][k]).max() < 1e-4, k
 
 
 # ---- reset distribution (reference ranges; this build's Philox stream) ----------------------------------------------

@@ -45,7 +45,7 @@ def test_reset_bit_exact_vs_oracle(PA, OA, variant, residual_blob):
     np.testing.assert_array_equal(wg, wo)
     if variant == E2E:
         np.testing.assert_array_equal(dg, do)
-    assert P.rel_err(og, oo).max() < P.TOL_STEP_OBS
+    assert P.obs_err(og, oo).max() < P.TOL_STEP_OBS
     # masked reset: only masked envs change, and they draw the NEXT episode of their own stream
     mask = (np.arange(5000) % 3 == 0)
     g.reset(mask.astype(np.uint8)); o.reset(mask.astype(np.uint8))
@@ -87,7 +87,7 @@ def test_lockstep_vs_oracle(PA, OA, variant, tname, ga, residual_blob):
         if variant == E2E:
             np.testing.assert_array_equal(dg[done], do2[done])
         assert P.rel_err(wg[live], wo2[live]).max() < P.TOL_STEP_STATE
-        assert P.rel_err(og[ok], oo[ok]).max() < P.TOL_STEP_OBS
+        assert P.obs_err(og[ok], oo[ok]).max() < P.TOL_STEP_OBS
         tot_done += int(dno.sum())
     assert tot_done > n // 20
 
@@ -208,7 +208,7 @@ def test_ragged_sizes_vs_oracle(PA, OA, variant, n, residual_blob):
     og, rg, dng, _ = g.step(a)
     oo, ro, dno, _ = o.step(a)
     np.testing.assert_array_equal(dng, dno)
-    assert P.rel_err(og, oo).max() < P.TOL_STEP_OBS
+    assert P.obs_err(og, oo).max() < P.TOL_STEP_OBS
     assert og.shape == (n, g.env.state_len)
 
 
@@ -227,7 +227,7 @@ def test_gates_ahead_and_single_gate_track(PA, OA, ga, residual_blob):
             oo, ro, dno, _ = o.step(a)
         np.testing.assert_array_equal(dng, dno)
         assert og.shape == oo.shape == (300, 20 + 4 * ga)
-        assert P.rel_err(og, oo).max() < 4 * P.TOL_STEP_OBS
+        assert P.obs_err(og, oo).max() < 4 * P.TOL_STEP_OBS
 
 
 def test_large_env_count_memory_and_speed():

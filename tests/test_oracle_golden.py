@@ -121,13 +121,13 @@ def test_obs_transform(tname, ga):
         a.set_state(d[key + "_world"], d[key + f"_dist_{rname}"], d[key + "_target"], np.zeros(n, np.int32))
         obs = a.observe()
         assert obs.shape == d[key + f"_obs_{rname}"].shape
-        assert P.rel_err(obs, d[key + f"_obs_{rname}"]).max() < 2e-6
+        assert P.obs_err(obs, d[key + f"_obs_{rname}"]).max() < 2e-6
     key = f"{tname}_indi_ga{ga}"
     a = OracleAdapter(O.INDI, n, trk, gates_ahead=ga)
     a.set_state(d[key + "_world"], None, d[key + "_target"], np.zeros(n, np.int32))
     obs = a.observe()
     assert obs.shape == d[key + "_obs"].shape
-    assert P.rel_err(obs, d[key + "_obs"]).max() < 2e-6
+    assert P.obs_err(obs, d[key + "_obs"]).max() < 2e-6
 
 
 # ---- F5: BASELINE config 1 (1 env, E2E, no residual, fixed action sequence) ---------------------------
@@ -178,7 +178,7 @@ def test_branches(variant, vname, residual_blob):
     assert trunc[names.index("max_steps")] and trunc.sum() == 1
     live = ~done
     assert P.rel_err(w[live], d[vname + "_world"][live]).max() < P.TOL_STEP_STATE
-    assert P.rel_err(obs[live], d[vname + "_obs"][live]).max() < P.TOL_STEP_OBS
+    assert P.obs_err(obs[live], d[vname + "_obs"][live]).max() < P.TOL_STEP_OBS
     # the reference's own numbers for the clean pass: reward 10 - 10*|0.005| = 9.95, target 0 -> 1
     i = names.index("pass_clean")
     assert abs(rew[i] - 9.95) < 1e-4 and t[i] == 1
@@ -227,7 +227,7 @@ def test_modes(variant, vname, residual_blob):
         assert np.abs(rew - d[vname + "_reward"][k]).max() < 1e-4, k
         # frozen envs keep their state, flying envs drift apart slowly (free run, unstable open loop)
         assert P.rel_err(w, d[vname + "_world"][k]).max() < 1e-4, k
-        assert P.rel_err(obs, d[vname + "_obs"][k]).max() < 1e-4, k
+        assert P.obs_err(obs, d[vname + "_obs"][k]).max() < 1e-4, k
     assert d[vname + "_done"][:pause_from].any() and not d[vname + "_done"][pause_from:].any()
 
 
