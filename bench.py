@@ -6,7 +6,7 @@
 
 One "step" = one env.step() of the whole batch: ONE fused HIP kernel over all envs of the rank
 (residual MLPs -> Euler -> reward / gate logic -> auto-reset -> gate-frame observation), launched through
-the C ABI (qr_step_many).  Workload at N=1 = BASELINE.json configs[1]: 65 536 envs, Bebop E2E + NNDroneModel
+the C ABI (qr_step, K launches; the fused K-step rollout kernel behind qr_step_many is reported beside it).  Workload at N=1 = BASELINE.json configs[1]: 65 536 envs, Bebop E2E + NNDroneModel
 residual MLPs + training disturbance ranges, gates_ahead = 1, 7-gate zigzag track, random U(-1,1) actions
 pre-generated on the device [K][N][4] (Philox seed 0); outputs go to a full rollout buffer [K][N][...]
 (what PPO's collect phase stores), so every step writes fresh HBM.  Inputs are resident in HBM before the
@@ -46,17 +46,19 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5, help="timed repetitions of the K-step region (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exchange", action="store_true")
+    ap.add_argument("--no-residual", action="store_true", help="experiment: E2E without the residual MLPs")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def make_env(variant, n, ga, env_id_base, seed=0):
+def make_env(variant, n, ga, env_id_base, seed=0, residual="default"):
     from optimal_quad_control_rl_amd import (Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES,
                                              square_track, zigzag_track)
 
     if variant == "e2e":
         env = Quadcopter3DGates(n, *zigzag_track(), gates_ahead=ga, seed=seed, env_id_base=env_id_base,
-                                residual="default", infos_mode="none")
+                                residual=residual, infos_mode="none")
         env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES  # R:772-781
     else:
         env = Quadcopter3DGatesINDI(n, *square_track(), gates_ahead=ga, seed=seed, env_id_base=env_id_base,
@@ -135,7 +137,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n, K, W, ga = args.envs, args.steps, args.warmup, args.gates_ahead
-    env = make_env(args.variant, n, ga, env_id_base=rank * n, seed=0)
+    env = make_env(args.variant, n, ga, env_id_base=rank * n, seed=0, residual=None if args.no_residual else "default")
     L = env.state_len
     dev = env.device
     gen = torch.Generator(device=dev).manual_seed(rank)  # torch Philox, seed = rank
@@ -157,18 +159,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    times = []
-    for _ in range(max(1, args.repeats)):
-        barrier()
-        t0 = time.perf_counter()
-        env.rollout_device(actions[:K], view(K))  # EXACTLY K steps
-        barrier()
-        times.append(time.perf_counter() - t0)
-    elapsed = float(np.median(times))
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(fn):
+        ts = []
+        for _ in range(max(1, args.repeats)):
+            barrier()
+            t0 = time.perf_counter()
+            fn()  # EXACTLY K steps
+            barrier()
+            ts.append(time.perf_counter() - t0)
+        el = float(np.median(ts))
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, ts
+
+    # (1) fused rollout: qr_step_many = ONE kernel for the K steps, env state register-resident between steps
+    fused_elapsed, fused_times = timed(lambda: env.rollout_device(actions[:K], view(K)))
+    fused_kernel_ms = env.last_rollout_ms()  # hipEvents around the single launch, on the launch stream
+    # (2) per-step launches: K x qr_step, one kernel per env.step() (closed-loop calling pattern)
+    elapsed, times = timed(lambda: env.step_sequence_device(actions[:K], view(K)))
     dones_frac = float(out[2][:K].float().mean().item())
 
     # --- roofline of the dominant kernel: per-launch hipEvents on the launch stream -----------------------------
@@ -222,14 +232,22 @@ def main():
                        "sharding": f"{world} independent shard(s), env_id_base = rank*N"},
             "repeats": len(times), "all_ms_per_step": [t * 1e3 / K for t in times], "done_fraction": dones_frac,
             "roofline": roofline,
+            "fused_rollout": {
+                "what": "qr_step_many: the same K steps as ONE fused rollout kernel (state in registers between steps; "
+                        "bit-identical outputs), for pre-recorded action sequences",
+                "value": total_steps / fused_elapsed, "unit": "env-steps/s", "ms_per_step": fused_elapsed * 1e3 / K,
+                "kernel_us_per_step": fused_kernel_ms * 1e3 / K,
+                "roofline_frac_algorithmic": bytes_per_launch / (fused_kernel_ms * 1e-3 / K) / 1e9 / HBM_PEAK_GBS,
+                "all_ms_per_step": [t * 1e3 / K for t in fused_times]},
         }
         if exchange:
             result["exchange"] = exchange
         if world == 1:
-            try:
-                result["parity"] = parity_probe()
-            except Exception as ex:  # pragma: no cover
-                result["parity"] = {"error": repr(ex)}
+            if not args.no_parity:
+                try:
+                    result["parity"] = parity_probe()
+                except Exception as ex:  # pragma: no cover
+                    result["parity"] = {"error": repr(ex)}
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(args.variant, n, ga, args.cpu_seconds)
         print(json.dumps(result))

@@ -114,9 +114,15 @@ int qr_step(qr_env* env, const float* actions_dev, float* obs_out_dev, float* re
             uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream);
 
 /* K consecutive steps with pre-recorded actions [K][N][4]; outputs are [K][N][...] (trunc may be NULL).
- * Semantically identical to K calls of qr_step; enqueued without host round trips. */
+ * Bit-identical to K calls of qr_step, but executed as ONE fused rollout kernel that keeps the env state in
+ * registers between steps (no per-step launch, state traffic or end-of-kernel write-back). */
 int qr_step_many(qr_env* env, int32_t num_steps, const float* actions_dev, float* obs_out_dev,
                  float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream);
+
+/* The same K steps as K separate step-kernel launches (exactly what K calls of qr_step enqueue, without the
+ * per-call FFI cost): the calling pattern of a closed loop whose policy runs between steps. */
+int qr_step_launches(qr_env* env, int32_t num_steps, const float* actions_dev, float* obs_out_dev,
+                     float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream);
 
 /* update_states(): recompute the observation from the current state. */
 int qr_observe(qr_env* env, float* obs_out_dev, void* stream);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "qr_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "qr_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qr_step_many": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qr_step_launches": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qr_observe": (C.c_int, [_vp, _vp, _vp]),
     "qr_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qr_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -15,6 +15,8 @@
 namespace qr {
 hipError_t launch_step(int variant, const Params& P, const float* actions, float* obs, float* rew, uint8_t* done,
                        uint8_t* trunc, hipStream_t st);
+hipError_t launch_rollout(int variant, const Params& P, int K, const float* actions, float* obs, float* rew,
+                          uint8_t* done, uint8_t* trunc, hipStream_t st);
 hipError_t launch_reset(int variant, const Params& P, const uint8_t* mask, float* obs, hipStream_t st);
 hipError_t launch_observe(int variant, const Params& P, float* obs, hipStream_t st);
 hipError_t launch_get_state(int variant, const Params& P, float* world, float* dist, int32_t* target, int32_t* steps,
@@ -32,12 +34,23 @@ struct qr_env {
     int num_gates = 0;
     bool has_track = false;
     std::vector<float> gate_pos, gate_yaw, gate_pos_rel, gate_yaw_rel;
-    float mlp_table[qr::kMlpFloats] = {};
+    float mlp_table[qr::kMlpTableFloats] = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_valid = false;
 };
 
 namespace {
+
+// observation scaling of the constant disturbances (R:414-448): if min == max the range becomes (min-1, max+1)
+void update_obs_scale(qr::Params& P) {
+    static const int col[4] = {0, 1, 2, 5};
+    for (int c = 0; c < 4; ++c) {
+        float lo = P.dist_lo[col[c]], hi = P.dist_hi[col[c]];
+        if (lo == hi) { lo -= 1.0f; hi += 1.0f; }
+        P.obs_lo[c] = lo;
+        P.obs_inv[c] = 1.0f / (hi - lo);
+    }
+}
 
 thread_local std::string g_err;
 
@@ -57,9 +70,10 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int upload_tables(qr_env* e) {
     const int gate_floats = e->num_gates * qr::kGateStride;
-    std::vector<float> host(gate_floats + qr::kMlpFloats, 0.0f);
+    std::vector<float> host(qr::kMlpTableFloats + gate_floats, 0.0f);  // device image: [MLP table | gate rows]
+    std::memcpy(host.data(), e->mlp_table, sizeof(e->mlp_table));
     for (int g = 0; g < e->num_gates; ++g) {
-        float* row = host.data() + g * qr::kGateStride;
+        float* row = host.data() + qr::kMlpTableFloats + g * qr::kGateStride;
         row[0] = e->gate_pos[3 * g + 0];
         row[1] = e->gate_pos[3 * g + 1];
         row[2] = e->gate_pos[3 * g + 2];
@@ -71,7 +85,6 @@ int upload_tables(qr_env* e) {
         row[10] = e->gate_pos_rel[3 * g + 2];
         row[11] = e->gate_yaw_rel[g];
     }
-    std::memcpy(host.data() + gate_floats, e->mlp_table, sizeof(e->mlp_table));
     QR_HIP(hipMemcpy(e->d_tables, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
     return QR_OK;
 }
@@ -126,7 +139,7 @@ int qr_create(const qr_config* cfg, qr_env** out) {
         delete e;
         return fail(QR_E_HIP, "qr_create: hipMalloc of the state slab failed");
     }
-    if (hipMalloc((void**)&e->d_tables, sizeof(float) * (qr::kMaxGates * qr::kGateStride + qr::kMlpFloats)) != hipSuccess) {
+    if (hipMalloc((void**)&e->d_tables, sizeof(float) * (qr::kMlpTableFloats + qr::kMaxGates * qr::kGateStride)) != hipSuccess) {
         (void)hipFree(e->slab);
         delete e;
         return fail(QR_E_HIP, "qr_create: hipMalloc of the table buffer failed");
@@ -152,6 +165,7 @@ int qr_create(const qr_config* cfg, qr_env** out) {
     P.gid_lo = (uint32_t)cfg->env_id_base;
     P.gid_hi = (uint32_t)(cfg->env_id_base >> 32);
     P.dist_scale = 1.0f;  // R:358
+    update_obs_scale(P);
     (void)hipEventCreate(&e->ev0);
     (void)hipEventCreate(&e->ev1);
     *out = e;
@@ -222,22 +236,26 @@ int qr_set_residual(qr_env* e, const float* blob, size_t n_floats) {
     const float* tW2 = tb1 + 32;     const float* tb2 = tW2 + 32;
     const float* mW1 = tb2 + 1;      const float* mb1 = mW1 + 320;
     const float* mW2 = mb1 + 32;     const float* mb2 = mW2 + 96;
+    // device layout = consumption order, twelve 64-float chunks (see quadrace_device.hpp)
     float* T = e->mlp_table;
-    for (int i = 0; i < 7; ++i)
-        for (int j = 0; j < 32; ++j) {
-            T[64 * i + j] = tW1[j * 7 + i];
-            T[64 * i + 32 + j] = mW1[j * 10 + i];
-        }
-    for (int i = 7; i < 10; ++i)
-        for (int j = 0; j < 32; ++j) T[qr::kOffW1m + 32 * (i - 7) + j] = mW1[j * 10 + i];
+    std::memset(T, 0, sizeof(e->mlp_table));
     for (int j = 0; j < 32; ++j) {
-        T[qr::kOffB1 + j] = tb1[j];
-        T[qr::kOffB1 + 32 + j] = mb1[j];
-        T[qr::kOffW2 + j] = tW2[j];
-        for (int o = 0; o < 3; ++o) T[qr::kOffW2 + 32 * (1 + o) + j] = mW2[o * 32 + j];
+        T[j] = tb1[j];                                    // chunk 0: b1
+        T[32 + j] = mb1[j];
+        for (int i = 0; i < 7; ++i) {                     // chunks 1..7: W1t[i][64]
+            T[64 * (1 + i) + j] = tW1[j * 7 + i];
+            T[64 * (1 + i) + 32 + j] = mW1[j * 10 + i];
+        }
+        T[64 * 8 + j] = mW1[j * 10 + 7];                  // chunk 8: W1m[7] | W1m[8]
+        T[64 * 8 + 32 + j] = mW1[j * 10 + 8];
+        T[64 * 9 + j] = mW1[j * 10 + 9];                  // chunk 9: W1m[9] | W2[0]
+        T[64 * 9 + 32 + j] = tW2[j];
+        T[64 * 10 + j] = mW2[0 * 32 + j];                 // chunk 10: W2[1] | W2[2]
+        T[64 * 10 + 32 + j] = mW2[1 * 32 + j];
+        T[64 * 11 + j] = mW2[2 * 32 + j];                 // chunk 11: W2[3] | b2
     }
-    T[qr::kOffB2 + 0] = tb2[0];
-    for (int o = 0; o < 3; ++o) T[qr::kOffB2 + 1 + o] = mb2[o];
+    T[64 * 11 + 32 + 0] = tb2[0];
+    for (int o = 0; o < 3; ++o) T[64 * 11 + 32 + 1 + o] = mb2[o];
     e->P.flags |= qr::kFlagResidual;
     if (e->has_track) return upload_tables(e);
     return QR_OK;
@@ -251,6 +269,7 @@ int qr_set_disturbance(qr_env* e, const float* ranges, float scale) {
         e->P.dist_hi[k] = ranges[2 * k + 1];
     }
     e->P.dist_scale = scale;
+    update_obs_scale(e->P);
     return QR_OK;
 }
 
@@ -299,15 +318,28 @@ int qr_step_many(qr_env* e, int32_t K, const float* actions_dev, float* obs_out_
     if (!actions_dev || !obs_out_dev || !rew_out_dev || !done_out_dev)
         return fail(QR_E_INVALID, "qr_step_many: actions/obs/rew/done buffers are required");
     hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)e->cfg.num_envs;
     QR_HIP(hipEventRecord(e->ev0, st));
+    // one launch: the fused rollout kernel keeps the env state in registers across the K steps
+    QR_HIP(qr::launch_rollout(e->cfg.variant, e->P, K, actions_dev, obs_out_dev, rew_out_dev, done_out_dev,
+                              trunc_out_dev, st));
+    QR_HIP(hipEventRecord(e->ev1, st));
+    e->timing_valid = true;
+    return QR_OK;
+}
+
+int qr_step_launches(qr_env* e, int32_t K, const float* actions_dev, float* obs_out_dev, float* rew_out_dev,
+                     uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream) {
+    if (int rc = check_ready(e)) return rc;
+    if (K < 1) return fail(QR_E_INVALID, "qr_step_launches: num_steps must be >= 1");
+    if (!actions_dev || !obs_out_dev || !rew_out_dev || !done_out_dev)
+        return fail(QR_E_INVALID, "qr_step_launches: actions/obs/rew/done buffers are required");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)e->cfg.num_envs;
     for (int k = 0; k < K; ++k) {
         QR_HIP(qr::launch_step(e->cfg.variant, e->P, actions_dev + (size_t)k * n * 4, obs_out_dev + (size_t)k * n * e->L,
                                rew_out_dev + (size_t)k * n, done_out_dev + (size_t)k * n,
                                trunc_out_dev ? trunc_out_dev + (size_t)k * n : nullptr, st));
     }
-    QR_HIP(hipEventRecord(e->ev1, st));
-    e->timing_valid = true;
     return QR_OK;
 }
 
@@ -372,5 +404,14 @@ int qr_profile_steps(qr_env* e, int32_t K, const float* actions_dev, float* obs_
     for (auto& x : ev) (void)hipEventDestroy(x);
     return QR_OK;
 }
+
+#ifdef QR_PHASE_TIMING
+// profiling build only (tools/phase_timing.py): device buffer [n_waves][16] of shader-clock stamps, or NULL
+int qr_debug_set_ticks(qr_env* e, unsigned long long* ticks_dev) {
+    if (!e) return QR_E_INVALID;
+    e->P.ticks = ticks_dev;
+    return QR_OK;
+}
+#endif
 
 }  // extern "C"

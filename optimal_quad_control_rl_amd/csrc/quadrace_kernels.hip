@@ -3,16 +3,18 @@
 // Launch shape: 1 lane = 1 env, 256-thread workgroups (4 wave64).  At N = 65 536 that is 256 workgroups
 // = one per CU; larger N simply adds workgroups (block b lands on XCD b % 8, and consecutive blocks touch
 // consecutive 4 KiB slabs of every plane, so each XCD's L2 sees disjoint, fully-used lines).
-// Per workgroup the gate table and the residual-MLP weights (<= 4.5 KiB) are staged once into LDS.
+// Per workgroup the gate table (indexed per lane by the env's target gate) and the residual-MLP weight table
+// (wave-uniform addresses = LDS broadcast) are staged once into LDS (<= 4.5 KiB).
 #include "quadrace_device.hpp"
 
 namespace qr {
 
-__device__ __forceinline__ void stage_tables(const Params& P, float* lds, int n_floats) {
-    // n_floats is a multiple of 4; tables pointer is 16-byte aligned
+// copy floats [begin, end) of the device table image [MLP table (768) | gate rows] to the same LDS offsets
+__device__ __forceinline__ void stage_tables(const Params& P, float* lds, int begin, int end) {
+    // begin/end are multiples of 4; the tables pointer is 16-byte aligned
     const float4* src = reinterpret_cast<const float4*>(P.tables);
     float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = threadIdx.x; i < n_floats / 4; i += kBlock) dst[i] = src[i];
+    for (int i = begin / 4 + threadIdx.x; i < end / 4; i += kBlock) dst[i] = src[i];
 }
 
 template <int V>
@@ -74,6 +76,38 @@ __device__ __forceinline__ void store_obs(float* __restrict__ obs_out, int i, co
     }
 }
 
+// The 64 observation rows of a full wave are one contiguous [64][L] block of the caller's row-major buffer.
+// Per-lane row stores would scatter 16-byte pieces over 64 different cache lines per instruction, so the wave
+// transposes through a wave-private LDS tile and writes the block with fully coalesced 16-byte-per-lane stores
+// (1 KiB per instruction).  LDS operations of one wave execute in order; the fences only pin the compiler.
+template <int V, int GA>
+__device__ __forceinline__ void store_obs_coalesced(float* __restrict__ tile, float* __restrict__ obs_out,
+                                                    size_t wave_first_env, int lane, const float* o) {
+    constexpr int L = obs_len<V, GA>();
+    float* row = tile + lane * L;
+    if constexpr (L % 4 == 0) {
+        float4* r4 = reinterpret_cast<float4*>(row);
+#pragma unroll
+        for (int k = 0; k < L / 4; ++k) r4[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < L; ++k) row[k] = o[k];  // odd row stride: conflict-free ds_write_b32
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int kVec = 16 * L;  // float4 elements in the block (64*L floats; 64*L*4 bytes is a multiple of 16)
+    const float4* t4 = reinterpret_cast<const float4*>(tile);
+    float4* g4 = reinterpret_cast<float4*>(obs_out + wave_first_env * L);
+#pragma unroll
+    for (int t = 0; t < (kVec + 63) / 64; ++t) {
+        const int e = t * 64 + lane;
+        if ((t + 1) * 64 <= kVec || e < kVec) g4[e] = t4[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Fused step: residual MLP -> EoM -> Euler -> reward/termination -> auto-reset -> gate-frame observation
 // ---------------------------------------------------------------------------------------------------
@@ -81,47 +115,119 @@ template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ obs_out,
             float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
-    __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride + kMlpFloats];
+    __shared__ __attribute__((aligned(16))) float lds[kMlpTableFloats + kMaxGates * kGateStride +
+                                                       kBlock * obs_len<V, GA>()];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool active = i < P.n;
     const int ii = active ? i : 0;
+    QR_TICK(P, 0);
 
     // issue this lane's HBM loads first; the LDS staging below overlaps their latency
     Env<V> e;
     load_env<V>(P, ii, e);
     const float4 act = actions[ii];
+    QR_TICK(P, 1);
 
-    const int gate_floats = P.num_gates * kGateStride;
-    stage_tables(P, lds, gate_floats + ((V == kE2E && (P.flags & kFlagResidual)) ? kMlpFloats : 0));
+    const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
+    const float* mlp = lds;                       // [MLP table (768 floats) | gate rows]
+    const float* gates = lds + kMlpTableFloats;
+    stage_tables(P, lds, use_mlp ? 0 : kMlpTableFloats, kMlpTableFloats + P.num_gates * kGateStride);
     __syncthreads();
+    QR_TICK(P, 2);
     if (!active) return;
 
     const float u[4] = {act.x, act.y, act.z, act.w};
     const uint32_t gid_lo = P.gid_lo + (uint32_t)i;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
     bool done, trunc, did_reset;
-    const float reward = step_env<V>(P, lds, lds + gate_floats, e, u, gid_lo, gid_hi, P.episode + i, done, trunc,
-                                     did_reset);
+    const float reward = step_env<V>(P, gates, mlp, e, u, gid_lo, gid_hi, P.episode + i, done, trunc, did_reset);
 
     rew_out[i] = reward;
     done_out[i] = done ? 1 : 0;
     if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
     P.ts[i] = make_int2(e.target, e.steps);
     if (P.flags & kFlagPause) return;  // world state and observation untouched (R:570-572)
+    QR_TICK(P, 6);
     store_world<V>(P, i, e);
     if (did_reset) store_dist<V>(P, i, e);
     float o[obs_len<V, GA>()];
-    observe<V, GA>(P, lds, e, o);
-    store_obs<V, GA>(obs_out, i, o);
+    observe<V, GA>(P, gates, e, o);
+    const int lane = threadIdx.x & 63;
+    const int wave_first = i - lane;
+    if (wave_first + 64 <= P.n) {  // full wave (wave-uniform): coalesced block store through the LDS tile
+        float* tile = lds + kMlpTableFloats + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * obs_len<V, GA>();
+        store_obs_coalesced<V, GA>(tile, obs_out, (size_t)wave_first, lane, o);
+    } else {
+        store_obs<V, GA>(obs_out, i, o);
+    }
+    QR_TICK(P, 7);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused K-step rollout (qr_step_many): the same step_env() applied K times with the env state held in
+// registers.  Per step a lane only reads its action (prefetched one step ahead) and writes obs / reward /
+// done, so consecutive steps overlap their stores with the next step's arithmetic and there is no launch
+// boundary (and no end-of-kernel L2 write-back) per step.  Bit-identical to K calls of step_kernel.
+// ---------------------------------------------------------------------------------------------------
+template <int V, int GA>
+__global__ void __launch_bounds__(kBlock)
+rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
+               float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+    __shared__ __attribute__((aligned(16))) float lds[kMlpTableFloats + kMaxGates * kGateStride +
+                                                       kBlock * obs_len<V, GA>()];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = i < P.n;
+    const int ii = active ? i : 0;
+    Env<V> e;
+    load_env<V>(P, ii, e);
+    float4 act = actions[ii];
+    const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
+    const float* mlp = lds;
+    const float* gates = lds + kMlpTableFloats;
+    stage_tables(P, lds, use_mlp ? 0 : kMlpTableFloats, kMlpTableFloats + P.num_gates * kGateStride);
+    __syncthreads();
+    if (!active) return;
+    const uint32_t gid_lo = P.gid_lo + (uint32_t)i;
+    const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
+    const size_t n = (size_t)P.n;
+    constexpr int L = obs_len<V, GA>();
+    const int lane = threadIdx.x & 63;
+    const int wave_first = i - lane;
+    const bool full_wave = wave_first + 64 <= P.n;
+    float* tile = lds + kMlpTableFloats + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
+    bool any_reset = false;
+    for (int k = 0; k < K; ++k) {
+        const int kn = (k + 1 < K) ? k + 1 : k;
+        const float4 nxt = actions[(size_t)kn * n + i];  // prefetch the next step's action
+        const float u[4] = {act.x, act.y, act.z, act.w};
+        bool done, trunc, did_reset;
+        const float reward = step_env<V>(P, gates, mlp, e, u, gid_lo, gid_hi, P.episode + i, done, trunc, did_reset);
+        any_reset |= did_reset;
+        rew_out[(size_t)k * n + i] = reward;
+        done_out[(size_t)k * n + i] = done ? 1 : 0;
+        if (trunc_out) trunc_out[(size_t)k * n + i] = trunc ? 1 : 0;
+        if (!(P.flags & kFlagPause)) {
+            float o[L];
+            observe<V, GA>(P, gates, e, o);
+            if (full_wave) store_obs_coalesced<V, GA>(tile, obs_out + (size_t)k * n * L, (size_t)wave_first, lane, o);
+            else store_obs<V, GA>(obs_out + (size_t)k * n * L, i, o);
+        }
+        act = nxt;
+    }
+    P.ts[i] = make_int2(e.target, e.steps);
+    if (P.flags & kFlagPause) return;
+    store_world<V>(P, i, e);
+    if (any_reset) store_dist<V>(P, i, e);
 }
 
 // reset_(mask) + update_states for ALL envs (R:452-496)
 template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 reset_kernel(Params P, const uint8_t* __restrict__ mask, float* __restrict__ obs_out) {
-    __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride];
+    __shared__ __attribute__((aligned(16))) float lds_all[kMlpTableFloats + kMaxGates * kGateStride];
+    const float* lds = lds_all + kMlpTableFloats;
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    stage_tables(P, lds, P.num_gates * kGateStride);
+    stage_tables(P, lds_all, kMlpTableFloats, kMlpTableFloats + P.num_gates * kGateStride);
     __syncthreads();
     if (i >= P.n) return;
     Env<V> e;
@@ -147,9 +253,10 @@ reset_kernel(Params P, const uint8_t* __restrict__ mask, float* __restrict__ obs
 template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 observe_kernel(Params P, float* __restrict__ obs_out) {
-    __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride];
+    __shared__ __attribute__((aligned(16))) float lds_all[kMlpTableFloats + kMaxGates * kGateStride];
+    const float* lds = lds_all + kMlpTableFloats;
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    stage_tables(P, lds, P.num_gates * kGateStride);
+    stage_tables(P, lds_all, kMlpTableFloats, kMlpTableFloats + P.num_gates * kGateStride);
     __syncthreads();
     if (i >= P.n) return;
     Env<V> e;
@@ -233,6 +340,14 @@ hipError_t launch_step(int variant, const Params& P, const float* actions, float
     const float4* a4 = reinterpret_cast<const float4*>(actions);
     if (variant == kE2E) { QR_DISPATCH_GA(kE2E, step_kernel, P, a4, obs, rew, done, trunc) }
     else { QR_DISPATCH_GA(kINDI, step_kernel, P, a4, obs, rew, done, trunc) }
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout(int variant, const Params& P, int K, const float* actions, float* obs, float* rew,
+                          uint8_t* done, uint8_t* trunc, hipStream_t st) {
+    const float4* a4 = reinterpret_cast<const float4*>(actions);
+    if (variant == kE2E) { QR_DISPATCH_GA(kE2E, rollout_kernel, P, K, a4, obs, rew, done, trunc) }
+    else { QR_DISPATCH_GA(kINDI, rollout_kernel, P, K, a4, obs, rew, done, trunc) }
     return hipGetLastError();
 }
 

