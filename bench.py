@@ -206,7 +206,7 @@ def main():
 
         Kx = min(K, 64)
         packed = pack_rollout(out[0][:Kx], out[1][:Kx], out[2][:Kx])
-        gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=dev)
+        gathered = torch.empty((world * Kx,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=dev)
         dist.all_gather_into_tensor(gathered, packed)
         barrier()
         t0 = time.perf_counter()

@@ -236,26 +236,30 @@ int qr_set_residual(qr_env* e, const float* blob, size_t n_floats) {
     const float* tW2 = tb1 + 32;     const float* tb2 = tW2 + 32;
     const float* mW1 = tb2 + 1;      const float* mb1 = mW1 + 320;
     const float* mW2 = mb1 + 32;     const float* mb2 = mW2 + 96;
-    // device layout = consumption order, twelve 64-float chunks (see quadrace_device.hpp)
+    // device image: MFMA A operands, layer-2 weights per wave half, output biases (see quadrace_device.hpp)
     float* T = e->mlp_table;
     std::memset(T, 0, sizeof(e->mlp_table));
-    for (int j = 0; j < 32; ++j) {
-        T[j] = tb1[j];                                    // chunk 0: b1
-        T[32 + j] = mb1[j];
-        for (int i = 0; i < 7; ++i) {                     // chunks 1..7: W1t[i][64]
-            T[64 * (1 + i) + j] = tW1[j * 7 + i];
-            T[64 * (1 + i) + 32 + j] = mW1[j * 10 + i];
+    for (int t = 0; t < 10; ++t)
+        for (int l = 0; l < 64; ++l) {
+            const int j = l & 31;
+            float v;
+            if (t < 4) {
+                const int k = 2 * t + (l >> 5);
+                v = k < 7 ? tW1[j * 7 + k] : (k == 7 ? tb1[j] : 0.0f);
+            } else {
+                const int k = 2 * (t - 4) + (l >> 5);
+                v = k < 10 ? mW1[j * 10 + k] : (k == 10 ? mb1[j] : 0.0f);
+            }
+            T[qr::kOffTabA + 64 * t + l] = v;
         }
-        T[64 * 8 + j] = mW1[j * 10 + 7];                  // chunk 8: W1m[7] | W1m[8]
-        T[64 * 8 + 32 + j] = mW1[j * 10 + 8];
-        T[64 * 9 + j] = mW1[j * 10 + 9];                  // chunk 9: W1m[9] | W2[0]
-        T[64 * 9 + 32 + j] = tW2[j];
-        T[64 * 10 + j] = mW2[0 * 32 + j];                 // chunk 10: W2[1] | W2[2]
-        T[64 * 10 + 32 + j] = mW2[1 * 32 + j];
-        T[64 * 11 + j] = mW2[2 * 32 + j];                 // chunk 11: W2[3] | b2
-    }
-    T[64 * 11 + 32 + 0] = tb2[0];
-    for (int o = 0; o < 3; ++o) T[64 * 11 + 32 + 1 + o] = mb2[o];
+    for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            T[qr::kOffTabW2 + 64 * h + r] = tW2[row];
+            for (int m = 0; m < 3; ++m) T[qr::kOffTabW2 + 64 * h + 16 + 16 * m + r] = mW2[m * 32 + row];
+        }
+    T[qr::kOffB2 + 0] = tb2[0];
+    for (int o = 0; o < 3; ++o) T[qr::kOffB2 + 1 + o] = mb2[o];
     e->P.flags |= qr::kFlagResidual;
     if (e->has_track) return upload_tables(e);
     return QR_OK;

@@ -32,20 +32,15 @@ constexpr int kFlagPauseIfCollision = 4;
 
 // Gate table row (LDS, 48 B): [x y z yaw | cos(yaw) sin(yaw) 0 0 | rel_x rel_y rel_z rel_yaw]
 //
-// MLP table (LDS, read with wave-uniform addresses = hardware broadcast).  Both hidden layers are fused into one
-// 64-wide layer (units 0..31 thrust net, 32..63 moment net) and the table is stored in CONSUMPTION order as
-// twelve 64-float chunks, so the kernel can stream it through a double-buffered register window:
-//   chunk 0      b1[64]
-//   chunk 1..7   W1t[i][64]   i = 0..6: inputs (w1..w4, vbx, vby, vbz) feed both nets
-//   chunk 8      W1m[7][32] | W1m[8][32]      inputs (p, q) feed only the moment net (units 32..63)
-//   chunk 9      W1m[9][32] | W2[0][32]       input r ; thrust output row (units 0..31)
-//   chunk 10     W2[1][32]  | W2[2][32]       moment output rows (units 32..63)
-//   chunk 11     W2[3][32]  | b2[4] | pad
-// Why LDS and a software pipeline (measured on MI355X, N = 65 536 = one wave per SIMD): a wave that waits for each
-// ds_read (or s_load -- the scalar path was tried: 24 exposed scalar-cache round trips) spends 8.3-8.5 k of its
-// 18 k cycles in the MLP; streaming the next chunk while the current one feeds 64 FMAs hides that latency.
-constexpr int kMlpChunks = 12;
-constexpr int kMlpTableFloats = kMlpChunks * 64;  // 768 (740 used)
+// Residual-MLP table (device image, see residual_mlp() below for why layer 1 runs on the f32 matrix core):
+//   tabA [10][64]  layer-1 A operands of v_mfma_f32_32x32x2_f32, one float per lane per K-step:
+//                  t = 0..3  thrust tile,  k = 2t + (lane>>5):      k < 7 ? W1t[lane&31][k] : (k == 7  ? b1t[lane&31] : 0)
+//                  t = 4..9  moment tile,  k = 2(t-4) + (lane>>5):  k < 10 ? W1m[lane&31][k] : (k == 10 ? b1m[lane&31] : 0)
+//   tabW2 [2][64]  layer-2 weights seen by the lanes of wave half h = lane>>5; accumulator register r holds hidden
+//                  row(r,h) = (r&3) + 8*(r>>2) + 4h:   [r] = W2t[0][row]   [16 + 16m + r] = W2m[m][row], m = 0..2
+//   b2 [4]         output biases (thrust, moment x/y/z)
+constexpr int kOffTabA = 0, kOffTabW2 = 640, kOffB2 = 768;
+constexpr int kMlpTableFloats = 784;  // 772 used, padded to a multiple of 16
 
 struct Params {
     // planar state in HBM (structure of float4 arrays, plane stride = n_stride elements)
@@ -192,91 +187,106 @@ __device__ __forceinline__ Rot make_rot(float phi, float theta, float psi) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Residual thrust / moment MLPs: 7->32->1 and 10->32->3, ReLU (R:227-262).  64 independent accumulator
-// chains per lane; weights stream from LDS (broadcast ds_read_b128) one 64-float chunk ahead of their use.
+// Residual thrust / moment MLPs: 7->32->1 and 10->32->3, ReLU (R:227-262).
+//
+// One lane = one env means every lane needs all 740 weights.  Feeding them as wave-uniform operands was
+// measured on MI355X (N = 65 536, one wave per SIMD): broadcast ds_read_b128 from LDS is bandwidth-bound at 16
+// unique bytes per ~4.8 cycles per CU (5.9-8.5 k of the step kernel's 18 k wave cycles, pipelined or not), and
+// scalar loads expose ~24 scalar-cache round trips (8.3 k cycles).  The first layer is a genuine small GEMM per
+// wave -- H^T[64 hidden x 64 envs] = W1[64 x 10(+bias)] * X^T[10(+1) x 64] -- so it runs on the f32 matrix core:
+// v_mfma_f32_32x32x2_f32 is bit-exactly a k-ordered fmaf chain at the f32 vector rate, and the MFMA itself
+// distributes each weight (held ONCE per wave, one float per lane per K-step) to all envs.  20 MFMAs replace
+// 544 broadcast-fed FMAs; the bias is folded in as an extra K element multiplying a constant 1.
+//   A (weights): lane l holds W1[tile row l&31][k = 2s + (l>>5)]            (tabA, loop invariant)
+//   B (inputs):  lane l holds x[k = 2s + (l>>5)] of env (tile*32 + (l&31)) -- built from the lane-per-env inputs
+//                with ONE v_permlane32_swap per input pair (gfx950), which yields both env tiles at once
+//   D: lane l, register r = hidden row (r&3) + 8*(r>>2) + 4*(l>>5) of env tile*32 + (l&31)
+// The 128 output-layer MACs stay on the VALU in that layout (each lane owns 16 hidden rows per tile) and the
+// two wave halves are combined with v_permlane32_swap, which also returns every env's result to its own lane.
 // -------------------------------------------------------------------------------------------------
-struct Chunk {
-    float4 v[16];
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct MlpRegs {   // loop-invariant per-lane registers
+    float a[10];   // tabA[t][lane]
+    float w2[64];  // tabW2[lane>>5][..]
+    float b2[4];
 };
 
-__device__ __forceinline__ void mlp_fetch(const float* __restrict__ W, int c, Chunk& dst) {
-    const float4* w4 = reinterpret_cast<const float4*>(W) + 16 * c;
+__device__ __forceinline__ void mlp_load_regs(const float* __restrict__ tab, int lane, MlpRegs& m) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dst.v[j] = w4[j];
-}
-
-__device__ __forceinline__ void fma4(const float4 w, float x, float* h) {
-    h[0] = fmaf(w.x, x, h[0]);
-    h[1] = fmaf(w.y, x, h[1]);
-    h[2] = fmaf(w.z, x, h[2]);
-    h[3] = fmaf(w.w, x, h[3]);
-}
-
-// One pipeline stage: consume chunk `cur` (64 multiply-accumulates per lane) while fetching chunk `c_next` into
-// `nxt`, interleaved one ds_read_b128 per four FMAs so the LDS pipe and the VALU stay busy together (all four
-// waves of a workgroup run this in lock-step, so a burst of reads followed by a burst of FMAs would idle one
-// unit while the other works).  kind: 0 = 64 units * x0;  1 = units 32..63 * (x0 for the first half, x1 second).
-template <int KIND>
-__device__ __forceinline__ void mlp_stage(const float* __restrict__ W, int c_next, const Chunk& cur, Chunk& nxt,
-                                          float x0, float x1, float* h) {
-    const float4* w4 = reinterpret_cast<const float4*>(W) + 16 * c_next;
+    for (int t = 0; t < 10; ++t) m.a[t] = tab[kOffTabA + 64 * t + lane];
+    const float4* w4 = reinterpret_cast<const float4*>(tab + kOffTabW2 + 64 * (lane >> 5));
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        nxt.v[j] = w4[j];
-        if (KIND == 0) fma4(cur.v[j], x0, h + 4 * j);
-        else fma4(cur.v[j], j < 8 ? x0 : x1, h + 32 + 4 * (j & 7));
-        __builtin_amdgcn_sched_barrier(0);
+        const float4 w = w4[j];
+        m.w2[4 * j + 0] = w.x; m.w2[4 * j + 1] = w.y; m.w2[4 * j + 2] = w.z; m.w2[4 * j + 3] = w.w;
     }
+    const float4 b = *reinterpret_cast<const float4*>(tab + kOffB2);
+    m.b2[0] = b.x; m.b2[1] = b.y; m.b2[2] = b.z; m.b2[3] = b.w;
 }
 
-// dot(W2 row, relu(h)) over 32 hidden units, 4 independent chains
-__device__ __forceinline__ float mlp_dot32(const Chunk& w, int half, const float* h) {
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+// (a, b) lane-per-env  ->  lo = {a[0..31], b[0..31]} (B operand of env tile 0), hi = {a[32..63], b[32..63]} (tile 1)
+__device__ __forceinline__ void pair_to_tiles(float a, float b, float& lo, float& hi) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    lo = __uint_as_float(r.x);
+    hi = __uint_as_float(r.y);
+}
+
+// sum over this lane's 16 hidden rows: dot(w[0..15], relu(acc[0..15])), four independent chains
+__device__ __forceinline__ float relu_dot16(const float* w, const f32x16& acc) {
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float4 ww = w.v[8 * half + j];
-        a0 = fmaf(ww.x, h[4 * j + 0], a0);
-        a1 = fmaf(ww.y, h[4 * j + 1], a1);
-        a2 = fmaf(ww.z, h[4 * j + 2], a2);
-        a3 = fmaf(ww.w, h[4 * j + 3], a3);
+    for (int r = 0; r < 16; r += 4) {
+        s0 = fmaf(w[r + 0], fmaxf(acc[r + 0], 0.0f), s0);
+        s1 = fmaf(w[r + 1], fmaxf(acc[r + 1], 0.0f), s1);
+        s2 = fmaf(w[r + 2], fmaxf(acc[r + 2], 0.0f), s2);
+        s3 = fmaf(w[r + 3], fmaxf(acc[r + 3], 0.0f), s3);
     }
-    return (a0 + a1) + (a2 + a3);
+    return (s0 + s1) + (s2 + s3);
 }
 
-__device__ __forceinline__ void residual_mlp(const float* __restrict__ W, const float x[10], float& thrust,
+__device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const float x[10], float& thrust,
                                              float moment[3]) {
-    Chunk A, B;
-    float h[64];
-    mlp_fetch(W, 0, A);  // biases
-    mlp_fetch(W, 1, B);
+    float b01[2], b23[2], b45[2], b67[2], b89[2], b6one[2];
+    pair_to_tiles(x[0], x[1], b01[0], b01[1]);
+    pair_to_tiles(x[2], x[3], b23[0], b23[1]);
+    pair_to_tiles(x[4], x[5], b45[0], b45[1]);
+    pair_to_tiles(x[6], x[7], b67[0], b67[1]);
+    pair_to_tiles(x[8], x[9], b89[0], b89[1]);
+    pair_to_tiles(x[6], 1.0f, b6one[0], b6one[1]);          // thrust net: k = 6 is vbz, k = 7 carries the bias
+    const float bias_sel = (lane < 32) ? 1.0f : 0.0f;        // moment net: k = 10 carries the bias, k = 11 unused
+    float part[2][4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        h[4 * j + 0] = A.v[j].x; h[4 * j + 1] = A.v[j].y; h[4 * j + 2] = A.v[j].z; h[4 * j + 3] = A.v[j].w;
+    for (int et = 0; et < 2; ++et) {
+        f32x16 hT = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        f32x16 hM = hT;
+        hT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[0], b01[et], hT, 0, 0, 0);
+        hM = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[4], b01[et], hM, 0, 0, 0);
+        hT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[1], b23[et], hT, 0, 0, 0);
+        hM = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[5], b23[et], hM, 0, 0, 0);
+        hT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[2], b45[et], hT, 0, 0, 0);
+        hM = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[6], b45[et], hM, 0, 0, 0);
+        hT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[3], b6one[et], hT, 0, 0, 0);
+        hM = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[7], b67[et], hM, 0, 0, 0);
+        hM = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[8], b89[et], hM, 0, 0, 0);
+        hM = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[9], bias_sel, hM, 0, 0, 0);
+        part[et][0] = relu_dot16(m.w2 + 0, hT);
+        part[et][1] = relu_dot16(m.w2 + 16, hM);
+        part[et][2] = relu_dot16(m.w2 + 32, hM);
+        part[et][3] = relu_dot16(m.w2 + 48, hM);
     }
-    mlp_stage<0>(W, 2, B, A, x[0], 0.0f, h);
-    mlp_stage<0>(W, 3, A, B, x[1], 0.0f, h);
-    mlp_stage<0>(W, 4, B, A, x[2], 0.0f, h);
-    mlp_stage<0>(W, 5, A, B, x[3], 0.0f, h);
-    mlp_stage<0>(W, 6, B, A, x[4], 0.0f, h);
-    mlp_stage<0>(W, 7, A, B, x[5], 0.0f, h);
-    mlp_stage<0>(W, 8, B, A, x[6], 0.0f, h);      // consumes chunk 7 (input vbz), fetches chunk 8
-    mlp_stage<1>(W, 9, A, B, x[7], x[8], h);      // chunk 8: p | q  -> units 32..63
-    // chunk 9 (in B): first half = input r, second half = thrust output row
-    mlp_fetch(W, 10, A);
+    float out[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) fma4(B.v[j], x[9], h + 32 + 4 * j);
-#pragma unroll
-    for (int j = 0; j < 64; ++j) h[j] = fmaxf(h[j], 0.0f);
-    const float out0 = mlp_dot32(B, 1, h);
-    mlp_fetch(W, 11, B);
-    const float out1 = mlp_dot32(A, 0, h + 32);
-    const float out2 = mlp_dot32(A, 1, h + 32);
-    const float out3 = mlp_dot32(B, 0, h + 32);
-    const float4 b2 = B.v[8];
-    thrust = out0 + b2.x;
-    moment[0] = out1 + b2.y;
-    moment[1] = out2 + b2.z;
-    moment[2] = out3 + b2.w;
+    for (int o = 0; o < 4; ++o) {  // lanes 0..31: tile-0 halves; lanes 32..63: tile-1 halves -> env = lane
+        float lo, hi;
+        pair_to_tiles(part[0][o], part[1][o], lo, hi);
+        out[o] = (lo + hi) + m.b2[o];
+    }
+    thrust = out[0];
+    moment[0] = out[1];
+    moment[1] = out[2];
+    moment[2] = out[3];
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -403,10 +413,10 @@ __device__ __forceinline__ void observe(const Params& P, const float* __restrict
 // On auto-reset `episode_next` is bumped and `did_reset` set so the caller persists the new disturbances.
 // -------------------------------------------------------------------------------------------------
 template <int V>
-__device__ __forceinline__ float step_env(const Params& P, const float* __restrict__ gates,
-                                          const float* __restrict__ mlp, Env<V>& e, const float u[4],
-                                          uint32_t gid_lo, uint32_t gid_hi, uint32_t* episode_ptr, bool& done,
-                                          bool& trunc, bool& did_reset) {
+__device__ __forceinline__ float step_env(const Params& P, const float* __restrict__ gates, const MlpRegs& mlp,
+                                          int lane, Env<V>& e, const float u[4],
+                                          uint32_t gid_lo, uint32_t gid_hi, uint32_t* episode_ptr, bool active,
+                                          bool& done, bool& trunc, bool& did_reset) {
     constexpr int S = Env<V>::S;
     const Rot R = make_rot(e.s[6], e.s[7], e.s[8]);
     QR_TICK(P, 3);
@@ -421,7 +431,7 @@ __device__ __forceinline__ float step_env(const Params& P, const float* __restri
         if (P.flags & kFlagResidual) {  // R:502-509: residual evaluated on the PRE-step state
             const float x[10] = {e.s[12], e.s[13], e.s[14], e.s[15], vb[0], vb[1], vb[2], e.s[9], e.s[10], e.s[11]};
             float thrust, moment[3];
-            residual_mlp(mlp, x, thrust, moment);
+            residual_mlp(mlp, lane, x, thrust, moment);
             M[0] += moment[0]; M[1] += moment[1]; M[2] += moment[2];
             F[2] += thrust;
         }
@@ -473,7 +483,7 @@ __device__ __forceinline__ float step_env(const Params& P, const float* __restri
         for (int k = 0; k < S; ++k) e.s[k] = nw[k];
         if (done) {
             const uint32_t ep = *episode_ptr;
-            *episode_ptr = ep + 1u;
+            if (active) *episode_ptr = ep + 1u;  // shadow lanes of a ragged tail must not touch env 0's counter
             reset_env<V>(P, e, gid_lo, gid_hi, ep);
             did_reset = true;
         }

@@ -3,18 +3,19 @@
 // Launch shape: 1 lane = 1 env, 256-thread workgroups (4 wave64).  At N = 65 536 that is 256 workgroups
 // = one per CU; larger N simply adds workgroups (block b lands on XCD b % 8, and consecutive blocks touch
 // consecutive 4 KiB slabs of every plane, so each XCD's L2 sees disjoint, fully-used lines).
-// Per workgroup the gate table (indexed per lane by the env's target gate) and the residual-MLP weight table
-// (wave-uniform addresses = LDS broadcast) are staged once into LDS (<= 4.5 KiB).
+// Per workgroup the gate table (indexed per lane by the env's target gate) is staged once into LDS; each wave
+// also owns an LDS tile for coalesced observation stores.  Residual-MLP weights live in registers (one float per
+// lane per MFMA K-step, see quadrace_device.hpp).
 #include "quadrace_device.hpp"
 
 namespace qr {
 
-// copy floats [begin, end) of the device table image [MLP table (768) | gate rows] to the same LDS offsets
-__device__ __forceinline__ void stage_tables(const Params& P, float* lds, int begin, int end) {
-    // begin/end are multiples of 4; the tables pointer is 16-byte aligned
-    const float4* src = reinterpret_cast<const float4*>(P.tables);
+// copy `count` floats starting at float offset `src_off` of the device table image [MLP table | gate rows] to lds[0..)
+__device__ __forceinline__ void stage_tables(const Params& P, float* lds, int src_off, int count) {
+    // offsets / counts are multiples of 4; the tables pointer is 16-byte aligned
+    const float4* src = reinterpret_cast<const float4*>(P.tables + src_off);
     float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = begin / 4 + threadIdx.x; i < end / 4; i += kBlock) dst[i] = src[i];
+    for (int i = threadIdx.x; i < count / 4; i += kBlock) dst[i] = src[i];
 }
 
 template <int V>
@@ -115,9 +116,11 @@ template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ obs_out,
             float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
-    __shared__ __attribute__((aligned(16))) float lds[kMlpTableFloats + kMaxGates * kGateStride +
-                                                       kBlock * obs_len<V, GA>()];
+    __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
     const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    // Lanes past the end of a ragged batch stay ACTIVE (they shadow env 0) because the residual MLP uses
+    // wave-wide operations (MFMA, permlane swap); only their stores are suppressed.
     const bool active = i < P.n;
     const int ii = active ? i : 0;
     QR_TICK(P, 0);
@@ -126,38 +129,41 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
     Env<V> e;
     load_env<V>(P, ii, e);
     const float4 act = actions[ii];
+    MlpRegs mlp;
+    const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
+    if (use_mlp) mlp_load_regs(P.tables, lane, mlp);
     QR_TICK(P, 1);
 
-    const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
-    const float* mlp = lds;                       // [MLP table (768 floats) | gate rows]
-    const float* gates = lds + kMlpTableFloats;
-    stage_tables(P, lds, use_mlp ? 0 : kMlpTableFloats, kMlpTableFloats + P.num_gates * kGateStride);
+    float* gates = lds;
+    stage_tables(P, lds, kMlpTableFloats, P.num_gates * kGateStride);
     __syncthreads();
     QR_TICK(P, 2);
-    if (!active) return;
 
     const float u[4] = {act.x, act.y, act.z, act.w};
-    const uint32_t gid_lo = P.gid_lo + (uint32_t)i;
+    const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
     bool done, trunc, did_reset;
-    const float reward = step_env<V>(P, gates, mlp, e, u, gid_lo, gid_hi, P.episode + i, done, trunc, did_reset);
-
-    rew_out[i] = reward;
-    done_out[i] = done ? 1 : 0;
-    if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
-    P.ts[i] = make_int2(e.target, e.steps);
+    const float reward = step_env<V>(P, gates, mlp, lane, e, u, gid_lo, gid_hi, P.episode + ii, active, done, trunc,
+                                     did_reset);
+    if (active) {
+        rew_out[i] = reward;
+        done_out[i] = done ? 1 : 0;
+        if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
+        P.ts[i] = make_int2(e.target, e.steps);
+    }
     if (P.flags & kFlagPause) return;  // world state and observation untouched (R:570-572)
     QR_TICK(P, 6);
-    store_world<V>(P, i, e);
-    if (did_reset) store_dist<V>(P, i, e);
+    if (active) {
+        store_world<V>(P, i, e);
+        if (did_reset) store_dist<V>(P, i, e);
+    }
     float o[obs_len<V, GA>()];
     observe<V, GA>(P, gates, e, o);
-    const int lane = threadIdx.x & 63;
     const int wave_first = i - lane;
     if (wave_first + 64 <= P.n) {  // full wave (wave-uniform): coalesced block store through the LDS tile
-        float* tile = lds + kMlpTableFloats + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * obs_len<V, GA>();
+        float* tile = lds + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * obs_len<V, GA>();
         store_obs_coalesced<V, GA>(tile, obs_out, (size_t)wave_first, lane, o);
-    } else {
+    } else if (active) {
         store_obs<V, GA>(obs_out, i, o);
     }
     QR_TICK(P, 7);
@@ -173,47 +179,50 @@ template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
                float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
-    __shared__ __attribute__((aligned(16))) float lds[kMlpTableFloats + kMaxGates * kGateStride +
-                                                       kBlock * obs_len<V, GA>()];
+    __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    const bool active = i < P.n;
+    const int lane = threadIdx.x & 63;
+    const bool active = i < P.n;  // ragged tail lanes stay active (wave-wide MLP ops) and shadow env 0
     const int ii = active ? i : 0;
     Env<V> e;
     load_env<V>(P, ii, e);
     float4 act = actions[ii];
+    MlpRegs mlp;  // weights stay in registers for all K steps
     const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
-    const float* mlp = lds;
-    const float* gates = lds + kMlpTableFloats;
-    stage_tables(P, lds, use_mlp ? 0 : kMlpTableFloats, kMlpTableFloats + P.num_gates * kGateStride);
+    if (use_mlp) mlp_load_regs(P.tables, lane, mlp);
+    float* gates = lds;
+    stage_tables(P, lds, kMlpTableFloats, P.num_gates * kGateStride);
     __syncthreads();
-    if (!active) return;
-    const uint32_t gid_lo = P.gid_lo + (uint32_t)i;
+    const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
     const size_t n = (size_t)P.n;
     constexpr int L = obs_len<V, GA>();
-    const int lane = threadIdx.x & 63;
     const int wave_first = i - lane;
     const bool full_wave = wave_first + 64 <= P.n;
-    float* tile = lds + kMlpTableFloats + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
+    float* tile = lds + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
     bool any_reset = false;
     for (int k = 0; k < K; ++k) {
         const int kn = (k + 1 < K) ? k + 1 : k;
-        const float4 nxt = actions[(size_t)kn * n + i];  // prefetch the next step's action
+        const float4 nxt = actions[(size_t)kn * n + ii];  // prefetch the next step's action
         const float u[4] = {act.x, act.y, act.z, act.w};
         bool done, trunc, did_reset;
-        const float reward = step_env<V>(P, gates, mlp, e, u, gid_lo, gid_hi, P.episode + i, done, trunc, did_reset);
+        const float reward = step_env<V>(P, gates, mlp, lane, e, u, gid_lo, gid_hi, P.episode + ii, active, done,
+                                         trunc, did_reset);
         any_reset |= did_reset;
-        rew_out[(size_t)k * n + i] = reward;
-        done_out[(size_t)k * n + i] = done ? 1 : 0;
-        if (trunc_out) trunc_out[(size_t)k * n + i] = trunc ? 1 : 0;
+        if (active) {
+            rew_out[(size_t)k * n + i] = reward;
+            done_out[(size_t)k * n + i] = done ? 1 : 0;
+            if (trunc_out) trunc_out[(size_t)k * n + i] = trunc ? 1 : 0;
+        }
         if (!(P.flags & kFlagPause)) {
             float o[L];
             observe<V, GA>(P, gates, e, o);
             if (full_wave) store_obs_coalesced<V, GA>(tile, obs_out + (size_t)k * n * L, (size_t)wave_first, lane, o);
-            else store_obs<V, GA>(obs_out + (size_t)k * n * L, i, o);
+            else if (active) store_obs<V, GA>(obs_out + (size_t)k * n * L, i, o);
         }
         act = nxt;
     }
+    if (!active) return;
     P.ts[i] = make_int2(e.target, e.steps);
     if (P.flags & kFlagPause) return;
     store_world<V>(P, i, e);
@@ -224,10 +233,9 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
 template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 reset_kernel(Params P, const uint8_t* __restrict__ mask, float* __restrict__ obs_out) {
-    __shared__ __attribute__((aligned(16))) float lds_all[kMlpTableFloats + kMaxGates * kGateStride];
-    const float* lds = lds_all + kMlpTableFloats;
+    __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride];
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    stage_tables(P, lds_all, kMlpTableFloats, kMlpTableFloats + P.num_gates * kGateStride);
+    stage_tables(P, lds, kMlpTableFloats, P.num_gates * kGateStride);
     __syncthreads();
     if (i >= P.n) return;
     Env<V> e;
@@ -253,10 +261,9 @@ reset_kernel(Params P, const uint8_t* __restrict__ mask, float* __restrict__ obs
 template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 observe_kernel(Params P, float* __restrict__ obs_out) {
-    __shared__ __attribute__((aligned(16))) float lds_all[kMlpTableFloats + kMaxGates * kGateStride];
-    const float* lds = lds_all + kMlpTableFloats;
+    __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride];
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    stage_tables(P, lds_all, kMlpTableFloats, kMlpTableFloats + P.num_gates * kGateStride);
+    stage_tables(P, lds, kMlpTableFloats, P.num_gates * kGateStride);
     __syncthreads();
     if (i >= P.n) return;
     Env<V> e;

@@ -59,8 +59,10 @@ class ShardedRaceEnv:
     def gather_rollout(self, obs, rew, done):
         """All ranks receive the full rollout: obs[K, N_global, L], rew[K, N_global], done[K, N_global]."""
         packed = pack_rollout(obs, rew, done)  # [K, n, L+2]
-        gathered = torch.empty((self.world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-        dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        K = packed.shape[0]
+        flat = torch.empty((self.world * K,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+        dist.all_gather_into_tensor(flat, packed, group=self.group)  # concatenation along dim 0 (rank-major)
+        gathered = flat.view((self.world, K) + tuple(packed.shape[1:]))
         # [world, K, n, L+2] -> [K, world*n, L+2]: rank-major = global env order
         full = gathered.permute(1, 0, 2, 3).reshape(packed.shape[0], self.world * packed.shape[1], packed.shape[2])
         return unpack_rollout(full)
