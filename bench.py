@@ -4,19 +4,27 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--variant e2e|indi] [--envs 65536]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one env.step() of the whole batch: ONE fused HIP kernel over all envs of the rank
-(residual MLPs -> Euler -> reward / gate logic -> auto-reset -> gate-frame observation), launched through
-the C ABI (qr_step, K launches; the fused K-step rollout kernel behind qr_step_many is reported beside it).  Workload at N=1 = BASELINE.json configs[1]: 65 536 envs, Bebop E2E + NNDroneModel
-residual MLPs + training disturbance ranges, gates_ahead = 1, 7-gate zigzag track, random U(-1,1) actions
-pre-generated on the device [K][N][4] (Philox seed 0); outputs go to a full rollout buffer [K][N][...]
-(what PPO's collect phase stores), so every step writes fresh HBM.  Inputs are resident in HBM before the
-timed region.  With --gpus N each rank simulates its own 65 536-env shard (weak scaling, no data-path
-collective); the rollout-boundary RCCL all-gather of [obs|reward|done] is measured separately ("exchange").
+One "step" = one env.step() of the whole batch (residual MLPs -> Euler integration -> reward / gate logic ->
+auto-reset -> gate-frame observation for every env).  Workload at N=1 = BASELINE.json configs[1] as specified in
+SURVEY.md 8(d): 65 536 envs, Bebop E2E + NNDroneModel residual MLPs + training disturbance ranges, gates_ahead = 1,
+7-gate zigzag track, random U(-1,1) actions PRE-GENERATED on the device [K][N][4] (torch Philox, seed = rank);
+every step's obs / reward / done go to a full rollout buffer [K][N][...] (what PPO's collect phase stores), so each
+step writes fresh HBM.  Inputs are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (HBM-bound kernel, algorithmic bytes/launch from
-SURVEY 8(d) / DESIGN.md divided by the mean kernel duration from per-launch hipEvents on the launch stream),
-"cpu_baseline" (the CPU oracle -- a C port of the reference, parity-pinned -- timed on this box's host cores
-on a bounded sample), "parity" (north_star single-trajectory max |d state| vs the reference's recorded step()).
+Two ways to run those K steps through the C ABI are timed, both producing bit-identical outputs:
+  * `value`: qr_step_many -- ONE fused rollout kernel for the K steps (env state stays in registers between steps;
+    the MI355X-native way to replay a recorded action sequence: no per-step launch, state round trip or
+    end-of-kernel write-back);
+  * `per_step_launch`: qr_step_launches -- K step kernels, one per env.step(), the calling pattern of a closed
+    loop whose policy runs between steps (what the reference's SB3 loop does).
+With --gpus N each rank simulates its own 65 536-env shard (weak scaling, no data-path collective); the
+rollout-boundary RCCL all-gather of [obs|reward|done] is measured separately ("exchange").
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel of the timed region: SURVEY 8(d)
+algorithmic bytes per launch / hipEvent launch duration on the launch stream; `traffic` = HBM bytes per launch from
+the rocprofv3 FETCH_SIZE/WRITE_SIZE passes in profiles/pmc_summary.json), "cpu_baseline" (the CPU oracle -- a C port
+of the reference, parity-pinned -- timed on this box's host cores on a bounded sample), "parity" (north_star
+single-trajectory max |d state| vs the reference's recorded step()).
 """
 import argparse
 import json
@@ -102,21 +110,24 @@ def cpu_baseline(variant, n, ga, seconds):
     rng = np.random.default_rng(0)
     acts = rng.uniform(-1, 1, size=(8, n, 4)).astype(np.float32)
     out = {}
-    for threads in (1, cores):
+    cands = sorted({1, 8, 16, 32, 64, cores} & set(range(1, cores + 1)))
+    per = max(0.8, seconds / (len(cands) + 1))
+    for threads in cands:
         env.set_threads(threads)
         env.reset()
         env.step(acts[0])
         t0 = time.perf_counter()
         steps = 0
-        while time.perf_counter() - t0 < seconds / 2 and steps < 2000:
+        while time.perf_counter() - t0 < (2 * per if threads == 1 else per) and steps < 4000:
             env.step(acts[steps % 8])
             steps += 1
         dt = time.perf_counter() - t0
         out[threads] = (n * steps / dt, steps)
     best_threads = max(out, key=lambda k: out[k][0])
     return {"value": out[best_threads][0], "unit": "env-steps/s", "cores": best_threads, "kind": "port",
-            "sample": f"{out[best_threads][1]} steps x {n} envs, same workload ({variant}, random actions), oracle/quadrace_oracle.c"
-                      f" with OpenMP over envs; {out[1][1]} steps single-thread",
+            "sample": f"{out[best_threads][1]} steps x {n} envs of the same workload ({variant}, random actions) on "
+                      f"oracle/quadrace_oracle.c (C port of the reference, OpenMP over envs); thread sweep "
+                      + ", ".join(f"{t}t: {v[0]/1e6:.1f}M/s" for t, v in sorted(out.items())),
             "value_1core": out[1][0], "host_cores": cores}
 
 
@@ -179,25 +190,44 @@ def main():
     fused_kernel_ms = env.last_rollout_ms()  # hipEvents around the single launch, on the launch stream
     # (2) per-step launches: K x qr_step, one kernel per env.step() (closed-loop calling pattern)
     elapsed, times = timed(lambda: env.step_sequence_device(actions[:K], view(K)))
+    step_region_ms = env.last_rollout_ms()  # hipEvents bracketing the K back-to-back step kernels on the launch stream
     dones_frac = float(out[2][:K].float().mean().item())
 
-    # --- roofline of the dominant kernel: per-launch hipEvents on the launch stream -----------------------------
-    Kp = min(K, 500)
-    mean_kernel_ms, region_ms = env.profile_rollout(actions[:Kp], view(Kp))
-    bytes_per_launch = BYTES_PER_ENV_STEP[args.variant](ga) * n
-    achieved = bytes_per_launch / (mean_kernel_ms * 1e-3) / 1e9
-    traffic = None
+    # --- roofline ------------------------------------------------------------------------------------------------
+    # Algorithmic bytes per env-step: 285 B (E2E, G=1) / 209 B (INDI): state read+written
+    # once, action read once, outputs written once.
+    bytes_per_step = BYTES_PER_ENV_STEP[args.variant](ga) * n
+    pmc = {}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc_path):
         try:
-            pmc = json.load(open(pmc_path))
-            traffic = pmc.get(f"{args.variant}_n{n}_ga{ga}", {}).get("hbm_bytes_per_launch")
+            pmc = json.load(open(pmc_path)).get(f"{args.variant}_n{n}_ga{ga}", {})
         except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": f"qr::step_kernel<{args.variant},ga={ga}>", "kernel_us": mean_kernel_ms * 1e3,
-                "bytes_per_launch": bytes_per_launch, "launches_timed": Kp,
-                "region_us_per_step": region_ms * 1e3 / Kp}
+            pmc = {}
+    # (a) fused rollout kernel: ONE launch = K steps; duration from hipEvents around that launch on its stream
+    fused_launch_s = fused_kernel_ms * 1e-3
+    fused_ach = bytes_per_step * K / fused_launch_s / 1e9
+    fused_traffic = pmc.get("fused_hbm_bytes_per_step")
+    roofline = {"bound": "hbm", "achieved": fused_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fused_ach / HBM_PEAK_GBS,
+                "traffic": None if fused_traffic is None else fused_traffic * K,
+                "kernel": f"qr::rollout_kernel<{args.variant},ga={ga}> (one launch = {K} steps)",
+                "launch_us": fused_kernel_ms * 1e3, "us_per_step": fused_kernel_ms * 1e3 / K,
+                "bytes_per_launch": bytes_per_step * K,
+                "note": "algorithmic bytes per SURVEY 8(d); the fused kernel keeps the env state in registers, so its real "
+                        "HBM traffic (PMC) is the action + output bytes only: frac_of_measured_traffic is its true HBM "
+                        "utilisation -- the kernel is VALU/latency bound, not HBM bound",
+                "frac_of_measured_traffic": None if fused_traffic is None else fused_traffic / (fused_launch_s / K) / 1e9 / HBM_PEAK_GBS}
+    # (b) per-step kernel: the K step kernels run back-to-back on one stream (rocprofv3: median gap 0 ns), so the
+    #     hipEvent time over the timed region / K is the average launch duration (per-launch event pairs are also
+    #     reported, but the markers themselves stretch an ~8 us kernel by 2-3 us)
+    mean_kernel_ms = step_region_ms / K
+    Kp = min(K, 200)
+    pair_kernel_ms, _ = env.profile_rollout(actions[:Kp], view(Kp))
+    step_ach = bytes_per_step / (mean_kernel_ms * 1e-3) / 1e9
+    step_roofline = {"bound": "hbm", "achieved": step_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_ach / HBM_PEAK_GBS,
+                     "traffic": pmc.get("hbm_bytes_per_launch"), "kernel": f"qr::step_kernel<{args.variant},ga={ga}>",
+                     "kernel_us": mean_kernel_ms * 1e3, "bytes_per_launch": bytes_per_step, "launches_timed": K,
+                     "kernel_us_event_pair_per_launch": pair_kernel_ms * 1e3}
 
     # --- rollout-boundary exchange (config 4): RCCL all-gather of [obs | reward | done] --------------------------
     exchange = None
@@ -221,24 +251,23 @@ def main():
         result = {
             "metric": "env-steps/sec at N=65536 envs per GPU (Quadcopter3DGates.step, "
                       + ("E2E + residual MLPs" if args.variant == "e2e" else "INDI inner loop") + ")",
-            "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": total_steps / fused_elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": fused_elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n} envs/GPU, " + ("Bebop E2E (motor-cmd actions) + NNDroneModel residual MLPs + "
                                                          "training disturbance ranges, 7-gate zigzag"
                                                          if args.variant == "e2e" else "INDI inner-loop variant, 4-gate square (x2)")
-                       + f", gates_ahead={ga}, U(-1,1) actions pre-generated on device, outputs to a [K][N] rollout buffer",
+                       + f", gates_ahead={ga}, U(-1,1) actions pre-generated on device [K][N][4], outputs to a [K][N] rollout buffer",
                        "envs_per_gpu": n, "variant": args.variant, "gates_ahead": ga, "obs_len": L,
                        "sharding": f"{world} independent shard(s), env_id_base = rank*N"},
-            "repeats": len(times), "all_ms_per_step": [t * 1e3 / K for t in times], "done_fraction": dones_frac,
+            "path": "qr_step_many (fused K-step rollout kernel)",
+            "repeats": len(fused_times), "all_ms_per_step": [t * 1e3 / K for t in fused_times], "done_fraction": dones_frac,
             "roofline": roofline,
-            "fused_rollout": {
-                "what": "qr_step_many: the same K steps as ONE fused rollout kernel (state in registers between steps; "
-                        "bit-identical outputs), for pre-recorded action sequences",
-                "value": total_steps / fused_elapsed, "unit": "env-steps/s", "ms_per_step": fused_elapsed * 1e3 / K,
-                "kernel_us_per_step": fused_kernel_ms * 1e3 / K,
-                "roofline_frac_algorithmic": bytes_per_launch / (fused_kernel_ms * 1e-3 / K) / 1e9 / HBM_PEAK_GBS,
-                "all_ms_per_step": [t * 1e3 / K for t in fused_times]},
+            "per_step_launch": {
+                "what": "qr_step_launches: the same K steps as K step-kernel launches (one per env.step(); bit-identical "
+                        "outputs) -- the closed-loop calling pattern",
+                "value": total_steps / elapsed, "unit": "env-steps/s", "ms_per_step": elapsed * 1e3 / K,
+                "all_ms_per_step": [t * 1e3 / K for t in times], "roofline": step_roofline},
         }
         if exchange:
             result["exchange"] = exchange

@@ -135,8 +135,8 @@ int qr_set_state(qr_env* env, const float* world_dev, const float* dist_dev, con
                  const int32_t* steps_dev, const uint32_t* episode_dev, void* stream);
 
 /* Timing hooks for benchmarks (both block until the work is done).
- * qr_last_step_many_ms: hipEvent time (ms) from the first to after the last launch of the most recent
- *   qr_step_many call, on its launch stream (kernels + inter-launch gaps).
+ * qr_last_step_many_ms: hipEvent time (ms) from before the first to after the last launch of the most recent
+ *   qr_step_many / qr_step_launches call, on its launch stream (back-to-back kernels; rocprofv3 shows no gaps).
  * qr_profile_steps: like qr_step_many, but brackets EVERY step kernel with its own hipEvent pair on the
  *   launch stream and returns the mean single-kernel duration (ms) and the whole-region time (ms). */
 int qr_last_step_many_ms(qr_env* env, float* total_ms);

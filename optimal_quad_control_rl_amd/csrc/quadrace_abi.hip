@@ -339,11 +339,14 @@ int qr_step_launches(qr_env* e, int32_t K, const float* actions_dev, float* obs_
         return fail(QR_E_INVALID, "qr_step_launches: actions/obs/rew/done buffers are required");
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)e->cfg.num_envs;
+    QR_HIP(hipEventRecord(e->ev0, st));
     for (int k = 0; k < K; ++k) {
         QR_HIP(qr::launch_step(e->cfg.variant, e->P, actions_dev + (size_t)k * n * 4, obs_out_dev + (size_t)k * n * e->L,
                                rew_out_dev + (size_t)k * n, done_out_dev + (size_t)k * n,
                                trunc_out_dev ? trunc_out_dev + (size_t)k * n : nullptr, st));
     }
+    QR_HIP(hipEventRecord(e->ev1, st));
+    e->timing_valid = true;
     return QR_OK;
 }
 
@@ -414,6 +417,7 @@ int qr_profile_steps(qr_env* e, int32_t K, const float* actions_dev, float* obs_
 int qr_debug_set_ticks(qr_env* e, unsigned long long* ticks_dev) {
     if (!e) return QR_E_INVALID;
     e->P.ticks = ticks_dev;
+    e->P.tick_on = ticks_dev != nullptr;
     return QR_OK;
 }
 #endif

@@ -60,12 +60,14 @@ struct Params {
     float obs_lo[4], obs_inv[4];  // observation scaling of (Mx,My,Mz,Fz): lo and 1/(hi-lo) after the R:419-441 fix-up
 #ifdef QR_PHASE_TIMING
     unsigned long long* ticks;  // [n_waves][16] shader-clock stamps (profiling build only, tools/phase_timing.py)
+    int tick_on;
 #endif
 };
 
 #ifdef QR_PHASE_TIMING
 #define QR_TICK(P, slot)                                                                      \
     do {                                                                                      \
+        if (!(P).tick_on) break;                                                              \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                           \
         if ((P).ticks && (threadIdx.x & 63) == 0)                                             \
             (P).ticks[((size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * 16 + (slot)] = clock64(); \

@@ -116,7 +116,8 @@ template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ obs_out,
             float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
-    __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
+    constexpr int kTab = (V == kE2E) ? kMlpTableFloats : 0;  // the E2E step kernel also stages the MLP table
+    __shared__ __attribute__((aligned(16))) float lds[kTab + kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     // Lanes past the end of a ragged batch stay ACTIVE (they shadow env 0) because the residual MLP uses
@@ -129,14 +130,17 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
     Env<V> e;
     load_env<V>(P, ii, e);
     const float4 act = actions[ii];
-    MlpRegs mlp;
-    const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
-    if (use_mlp) mlp_load_regs(P.tables, lane, mlp);
     QR_TICK(P, 1);
 
-    float* gates = lds;
-    stage_tables(P, lds, kMlpTableFloats, P.num_gates * kGateStride);
+    // one cooperative pass brings [MLP table | gate rows] (<= 4.6 KiB, L2 resident) into LDS; the per-lane weight
+    // registers are then filled from LDS instead of 26 more global loads on the critical path
+    const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
+    float* gates = lds + kTab;
+    if (use_mlp) stage_tables(P, lds, 0, kMlpTableFloats + P.num_gates * kGateStride);
+    else stage_tables(P, gates, kMlpTableFloats, P.num_gates * kGateStride);
     __syncthreads();
+    MlpRegs mlp;
+    if (use_mlp) mlp_load_regs(lds, lane, mlp);
     QR_TICK(P, 2);
 
     const float u[4] = {act.x, act.y, act.z, act.w};
@@ -161,7 +165,7 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
     observe<V, GA>(P, gates, e, o);
     const int wave_first = i - lane;
     if (wave_first + 64 <= P.n) {  // full wave (wave-uniform): coalesced block store through the LDS tile
-        float* tile = lds + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * obs_len<V, GA>();
+        float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * obs_len<V, GA>();
         store_obs_coalesced<V, GA>(tile, obs_out, (size_t)wave_first, lane, o);
     } else if (active) {
         store_obs<V, GA>(obs_out, i, o);
@@ -202,6 +206,10 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
     float* tile = lds + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
     bool any_reset = false;
     for (int k = 0; k < K; ++k) {
+#ifdef QR_PHASE_TIMING
+        P.tick_on = (k == K / 2);
+#endif
+        QR_TICK(P, 2);
         const int kn = (k + 1 < K) ? k + 1 : k;
         const float4 nxt = actions[(size_t)kn * n + ii];  // prefetch the next step's action
         const float u[4] = {act.x, act.y, act.z, act.w};
@@ -214,12 +222,14 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
             done_out[(size_t)k * n + i] = done ? 1 : 0;
             if (trunc_out) trunc_out[(size_t)k * n + i] = trunc ? 1 : 0;
         }
+        QR_TICK(P, 6);
         if (!(P.flags & kFlagPause)) {
             float o[L];
             observe<V, GA>(P, gates, e, o);
             if (full_wave) store_obs_coalesced<V, GA>(tile, obs_out + (size_t)k * n * L, (size_t)wave_first, lane, o);
             else if (active) store_obs<V, GA>(obs_out + (size_t)k * n * L, i, o);
         }
+        QR_TICK(P, 7);
         act = nxt;
     }
     if (!active) return;

@@ -9,12 +9,14 @@ for path in sys.argv[1:]:
     except Exception as ex:
         print(path, "unreadable:", ex)
         continue
-    r, f = d["roofline"], d.get("fused_rollout")
-    line = (f"{d['config'].get('variant','?'):5s} n_gpus={d['n_gpus']} step-launch: {d['ms_per_step']*1e3:6.2f} us/step "
-            f"{d['value']/1e9:6.2f} G/s | kernel {r['kernel_us']:5.2f} us (events) frac {r['frac']:.3f}")
-    if f:
-        line += (f" | fused: {f['ms_per_step']*1e3:5.2f} us/step {f['value']/1e9:6.2f} G/s kernel {f['kernel_us_per_step']:5.2f} us"
-                 f" frac(alg) {f['roofline_frac_algorithmic']:.3f}")
+    r, ps = d["roofline"], d.get("per_step_launch")
+    line = (f"{d['config'].get('variant','?'):5s} n_gpus={d['n_gpus']} fused: {d['ms_per_step']*1e3:6.2f} us/step "
+            f"{d['value']/1e9:6.2f} G/s | kernel {r['us_per_step']:5.2f} us/step frac(alg) {r['frac']:.3f}"
+            f" frac(traffic) {r.get('frac_of_measured_traffic')}")
+    if ps:
+        pr = ps["roofline"]
+        line += (f" | per-step: {ps['ms_per_step']*1e3:5.2f} us/step {ps['value']/1e9:6.2f} G/s kernel {pr['kernel_us']:5.2f} us"
+                 f" frac {pr['frac']:.3f} traffic {pr['traffic']}")
     if "parity" in d:
         line += f" | parity {d['parity'].get('max_rel_dstate_100_steps')}"
     if "cpu_baseline" in d:
