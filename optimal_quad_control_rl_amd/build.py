@@ -17,8 +17,10 @@ SOURCES = ["quadrace_kernels.hip", "quadrace_abi.hip"]
 HEADERS = ["quadrace_device.hpp", os.path.join("..", "..", "include", "quadrace.h")]
 # -ffp-contract=off: FMAs are written explicitly (fmaf) in the kernels, so the arithmetic is fixed by the source and
 # the per-step kernel and the fused rollout kernel produce bit-identical trajectories.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
-         "-Wno-unused-result"]
+# -amdgpu-mfma-vgpr-form: keep the MFMA accumulators of the residual MLP in VGPRs (gfx950 has a unified register file),
+# so the VALU epilogue reads them directly instead of through 64 v_accvgpr_read per step.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form",
+         "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 
 
 def _hipcc():

@@ -19,6 +19,7 @@ hipError_t launch_rollout(int variant, const Params& P, int K, const float* acti
                           uint8_t* done, uint8_t* trunc, hipStream_t st);
 hipError_t launch_reset(int variant, const Params& P, const uint8_t* mask, float* obs, hipStream_t st);
 hipError_t launch_observe(int variant, const Params& P, float* obs, hipStream_t st);
+hipError_t launch_clear_episode(const Params& P, hipStream_t st);
 hipError_t launch_get_state(int variant, const Params& P, float* world, float* dist, int32_t* target, int32_t* steps,
                             uint32_t* episode, hipStream_t st);
 hipError_t launch_set_state(int variant, const Params& P, const float* world, const float* dist,
@@ -70,21 +71,42 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int upload_tables(qr_env* e) {
     const int gate_floats = e->num_gates * qr::kGateStride;
-    std::vector<float> host(qr::kMlpTableFloats + gate_floats, 0.0f);  // device image: [MLP table | gate rows]
+    // device image: [MLP table | reset table | gate rows]
+    std::vector<float> host(qr::kOffGatesImage + gate_floats, 0.0f);
     std::memcpy(host.data(), e->mlp_table, sizeof(e->mlp_table));
-    for (int g = 0; g < e->num_gates; ++g) {
-        float* row = host.data() + qr::kMlpTableFloats + g * qr::kGateStride;
-        row[0] = e->gate_pos[3 * g + 0];
-        row[1] = e->gate_pos[3 * g + 1];
-        row[2] = e->gate_pos[3 * g + 2];
-        row[3] = e->gate_yaw[g];
-        row[4] = cosf(e->gate_yaw[g]);  // the reference evaluates np.cos/np.sin on the f32 yaw every step (R:372-375,528)
-        row[5] = sinf(e->gate_yaw[g]);
-        row[8] = e->gate_pos_rel[3 * g + 0];
-        row[9] = e->gate_pos_rel[3 * g + 1];
-        row[10] = e->gate_pos_rel[3 * g + 2];
-        row[11] = e->gate_yaw_rel[g];
+    // reset table rows (lo, hi - lo, add, mul): value = ((lo + (hi-lo)*u) + add) * mul   (R:455-489 / I:270-296)
+    float* R = host.data() + qr::kOffResetImage;
+    auto row = [&](int t, float lo, float hi, float add, float mul) {
+        volatile float span = hi - lo;  // float32 subtraction, like the oracle / the reference's ranges
+        R[4 * t + 0] = lo; R[4 * t + 1] = span; R[4 * t + 2] = add; R[4 * t + 3] = mul;
+    };
+    const float pi9 = 0.3490658503988659f, pi = 3.141592653589793f;
+    for (int t = 0; t < 3; ++t) row(t, -0.5f, 0.5f, e->P.start[t], 1.0f);
+    for (int t = 3; t < 6; ++t) row(t, -0.5f, 0.5f, 0.0f, 1.0f);
+    row(6, -pi9, pi9, 0.0f, 1.0f);
+    row(7, -pi9, pi9, 0.0f, 1.0f);
+    row(8, -pi, pi, 0.0f, 1.0f);
+    for (int t = 9; t < 12; ++t) row(t, -0.1f, 0.1f, 0.0f, 1.0f);
+    if (e->cfg.variant == QR_VARIANT_E2E) {
+        for (int t = 12; t < 16; ++t) row(t, -1.0f, 1.0f, 0.0f, 1.0f);
+        for (int k = 0; k < 6; ++k) row(16 + k, e->P.dist_lo[k], e->P.dist_hi[k], 0.0f, e->P.dist_scale);
+    } else {
+        row(12, -0.1f, 0.1f, 0.0f, 1.0f);
     }
+    for (int g = 0; g < e->num_gates; ++g) {
+        float* grow = host.data() + qr::kOffGatesImage + g * qr::kGateStride;
+        grow[0] = e->gate_pos[3 * g + 0];
+        grow[1] = e->gate_pos[3 * g + 1];
+        grow[2] = e->gate_pos[3 * g + 2];
+        grow[3] = e->gate_yaw[g];
+        grow[4] = cosf(e->gate_yaw[g]);  // the reference evaluates np.cos/np.sin on the f32 yaw every step (R:372-375,528)
+        grow[5] = sinf(e->gate_yaw[g]);
+        grow[8] = e->gate_pos_rel[3 * g + 0];
+        grow[9] = e->gate_pos_rel[3 * g + 1];
+        grow[10] = e->gate_pos_rel[3 * g + 2];
+        grow[11] = e->gate_yaw_rel[g];
+    }
+    QR_HIP(hipDeviceSynchronize());  // configuration setters are rare: do not race kernels still reading the table
     QR_HIP(hipMemcpy(e->d_tables, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
     return QR_OK;
 }
@@ -133,13 +155,12 @@ int qr_create(const qr_config* cfg, qr_env** out) {
     const size_t sz_dA = e2e ? align_up(sizeof(float4) * ns, 256) : 0;
     const size_t sz_dB = e2e ? align_up(sizeof(float2) * ns, 256) : 0;
     const size_t sz_ts = align_up(sizeof(int2) * ns, 256);
-    const size_t sz_ep = align_up(sizeof(uint32_t) * ns, 256);
-    const size_t total = sz_ws + sz_tn + sz_dA + sz_dB + sz_ts + sz_ep;
+    const size_t total = sz_ws + sz_tn + sz_dA + sz_dB + sz_ts;
     if (hipMalloc(&e->slab, total) != hipSuccess) {
         delete e;
         return fail(QR_E_HIP, "qr_create: hipMalloc of the state slab failed");
     }
-    if (hipMalloc((void**)&e->d_tables, sizeof(float) * (qr::kMlpTableFloats + qr::kMaxGates * qr::kGateStride)) != hipSuccess) {
+    if (hipMalloc((void**)&e->d_tables, sizeof(float) * (qr::kOffGatesImage + qr::kMaxGates * qr::kGateStride)) != hipSuccess) {
         (void)hipFree(e->slab);
         delete e;
         return fail(QR_E_HIP, "qr_create: hipMalloc of the table buffer failed");
@@ -151,8 +172,7 @@ int qr_create(const qr_config* cfg, qr_env** out) {
     P.tn = e2e ? nullptr : reinterpret_cast<float*>(p); p += sz_tn;
     P.dA = e2e ? reinterpret_cast<float4*>(p) : nullptr; p += sz_dA;
     P.dB = e2e ? reinterpret_cast<float2*>(p) : nullptr; p += sz_dB;
-    P.ts = reinterpret_cast<int2*>(p); p += sz_ts;
-    P.episode = reinterpret_cast<uint32_t*>(p);
+    P.ts = reinterpret_cast<int2*>(p);
     P.tables = e->d_tables;
     P.n = n;
     P.n_stride = (int)ns;
@@ -274,7 +294,8 @@ int qr_set_disturbance(qr_env* e, const float* ranges, float scale) {
     }
     e->P.dist_scale = scale;
     update_obs_scale(e->P);
-    return QR_OK;
+    QR_HIP(hipSetDevice(e->cfg.device));
+    return upload_tables(e);  // the reset table carries the disturbance ranges
 }
 
 int qr_set_limits(qr_env* e, int32_t max_steps, float dt) {
@@ -295,7 +316,8 @@ int qr_seed(qr_env* e, uint64_t seed) {
     QR_HIP(hipSetDevice(e->cfg.device));
     e->P.seed_lo = (uint32_t)seed;
     e->P.seed_hi = (uint32_t)(seed >> 32);
-    QR_HIP(hipMemset(e->P.episode, 0, sizeof(uint32_t) * (size_t)e->P.n_stride));
+    QR_HIP(qr::launch_clear_episode(e->P, nullptr));
+    QR_HIP(hipStreamSynchronize(nullptr));
     return QR_OK;
 }
 

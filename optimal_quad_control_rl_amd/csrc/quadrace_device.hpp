@@ -41,6 +41,17 @@ constexpr int kFlagPauseIfCollision = 4;
 //   b2 [4]         output biases (thrust, moment x/y/z)
 constexpr int kOffTabA = 0, kOffTabW2 = 640, kOffB2 = 768;
 constexpr int kMlpTableFloats = 784;  // 772 used, padded to a multiple of 16
+//
+// Reset table [24][4] (host-built, staged to LDS with the gate rows): row t = (lo, hi - lo, add, mul) of the t-th
+// reset draw, value = ((lo + (hi - lo) * u) + add) * mul with separately rounded operations:
+//   t = 0..2   position: U(-0.5, 0.5) + start_pos[t]        t = 3..5 velocity U(-0.5, 0.5)     (R:455-461)
+//   t = 6,7    phi, theta: U(-pi/9, pi/9)   t = 8 psi: U(-pi, pi)   t = 9..11 rates U(-0.1, 0.1) (R:463-469)
+//   E2E: t = 12..15 motor speeds U(-1, 1); t = 16..21 disturbances scale * U(range)   (R:471-489)
+//   INDI: t = 12 T_norm U(-0.1, 0.1)                                                   (I:285)
+// Device table image: [MLP table (784) | reset table (96) | gate rows (G * 12)]
+constexpr int kResetTableFloats = 96;
+constexpr int kOffResetImage = kMlpTableFloats;
+constexpr int kOffGatesImage = kMlpTableFloats + kResetTableFloats;
 
 struct Params {
     // planar state in HBM (structure of float4 arrays, plane stride = n_stride elements)
@@ -48,8 +59,7 @@ struct Params {
     float* tn;          // INDI: T_norm
     float4* dA;         // E2E: (M_ext_x, M_ext_y, M_ext_z, F_ext_z)
     float2* dB;         // E2E: (F_ext_x, F_ext_y)
-    int2* ts;           // (target_gate, step_count)
-    uint32_t* episode;  // per-env reset counter = RNG stream position
+    int2* ts;           // (target_gate | episode << 8, step_count); episode = per-env reset counter (RNG position)
     const float* tables;  // device copy of [gate table | mlp table]
     int n, n_stride, num_gates, gates_ahead, max_steps, flags;
     float dt;
@@ -120,44 +130,85 @@ struct Env {
     float s[S];   // world state
     float d[6];   // constant external disturbances (E2E only)
     int target, steps;
+    uint32_t episode;  // resets so far (24 bits are persisted next to the target gate)
 };
 
-// reset_ for one env: distributions of R:455-489 / I:270-296
+// value of one reset draw from its table row (lo, span, add, mul): ((lo + span*u) + add) * mul, no FMA contraction
+__device__ __forceinline__ float reset_value(const float4 row, uint32_t bits) {
+    return mul_rn(add_rn(add_rn(row.x, mul_rn(row.y, u01(bits))), row.z), row.w);
+}
+
 template <int V>
-__device__ __forceinline__ void reset_env(const Params& P, Env<V>& e, uint32_t gid_lo, uint32_t gid_hi,
-                                          uint32_t episode) {
-    constexpr int NB = (V == kE2E) ? 6 : 4;
-    float u[4 * NB];
+__device__ __forceinline__ void assign_reset(Env<V>& e, const float* v) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        uint32_t o[4];
-        philox4x32_10(gid_lo, gid_hi, episode, (uint32_t)b, P.seed_lo, P.seed_hi, o);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) u[4 * b + k] = u01(o[k]);
-    }
-    const float pi9 = 0.3490658503988659f, pi = 3.141592653589793f;
-    e.s[0] = add_rn(uni(-0.5f, 0.5f, u[0]), P.start[0]);
-    e.s[1] = add_rn(uni(-0.5f, 0.5f, u[1]), P.start[1]);
-    e.s[2] = add_rn(uni(-0.5f, 0.5f, u[2]), P.start[2]);
-    e.s[3] = uni(-0.5f, 0.5f, u[3]);
-    e.s[4] = uni(-0.5f, 0.5f, u[4]);
-    e.s[5] = uni(-0.5f, 0.5f, u[5]);
-    e.s[6] = uni(-pi9, pi9, u[6]);
-    e.s[7] = uni(-pi9, pi9, u[7]);
-    e.s[8] = uni(-pi, pi, u[8]);
-    e.s[9] = uni(-0.1f, 0.1f, u[9]);
-    e.s[10] = uni(-0.1f, 0.1f, u[10]);
-    e.s[11] = uni(-0.1f, 0.1f, u[11]);
+    for (int k = 0; k < Env<V>::S; ++k) e.s[k] = v[k];
     if constexpr (V == kE2E) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) e.s[12 + k] = uni(-1.0f, 1.0f, u[12 + k]);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) e.d[k] = mul_rn(P.dist_scale, uni(P.dist_lo[k], P.dist_hi[k], u[16 + k]));
-    } else {
-        e.s[12] = uni(-0.1f, 0.1f, u[12]);
+        for (int k = 0; k < 6; ++k) e.d[k] = v[16 + k];
     }
     e.steps = 0;
     e.target = 0;
+    e.episode = (e.episode + 1u) & 0xFFFFFFu;
+}
+
+// reset_ for one env, every lane for itself (reset kernel: whole batches reset at once).
+// Distributions of R:455-489 / I:270-296; `rtab` = reset table in LDS.
+template <int V>
+__device__ __forceinline__ void reset_env(const Params& P, const float* __restrict__ rtab, Env<V>& e, uint32_t gid_lo,
+                                          uint32_t gid_hi) {
+    constexpr int NB = (V == kE2E) ? 6 : 4;
+    const float4* rows = reinterpret_cast<const float4*>(rtab);
+    float v[4 * NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        uint32_t o[4];
+        philox4x32_10(gid_lo, gid_hi, e.episode, (uint32_t)b, P.seed_lo, P.seed_hi, o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[4 * b + k] = reset_value(rows[4 * b + k], o[k]);
+    }
+    assign_reset<V>(e, v);
+}
+
+// Auto-reset inside the step: typically 0-2 of a wave's 64 envs terminate in a step, so instead of every done
+// lane grinding through 4-6 Philox blocks under a divergent branch (the whole wave waits), the WAVE resets one
+// done env at a time: lanes 0..5 each compute one Philox block of that env's (seed, global id, episode) stream and
+// turn it into four reset values with their own table rows; the 24 values reach the env's lane through the wave's
+// LDS tile.  Same stream, same arithmetic as reset_env() -> bit-identical values.
+template <int V>
+__device__ __forceinline__ void reset_done_lanes(const Params& P, const float* __restrict__ rtab,
+                                                 float* __restrict__ tile, int lane, bool done, Env<V>& e,
+                                                 uint32_t gid_lo, uint32_t gid_hi) {
+    constexpr int NB = (V == kE2E) ? 6 : 4;
+    unsigned long long pending = __ballot(done);
+    const int b = lane & 7;
+    const float4* rows = reinterpret_cast<const float4*>(rtab) + 4 * (b < NB ? b : 0);
+    float4* t4 = reinterpret_cast<float4*>(tile);
+    while (pending) {  // wave-uniform
+        const int d = __builtin_ctzll(pending);
+        pending &= pending - 1;
+        const uint32_t g_lo = __builtin_amdgcn_readlane(gid_lo, d);
+        const uint32_t g_hi = __builtin_amdgcn_readlane(gid_hi, d);
+        const uint32_t ep = __builtin_amdgcn_readlane(e.episode, d);
+        uint32_t o[4];
+        philox4x32_10(g_lo, g_hi, ep, (uint32_t)b, P.seed_lo, P.seed_hi, o);
+        if (lane < 8)
+            t4[lane] = make_float4(reset_value(rows[0], o[0]), reset_value(rows[1], o[1]), reset_value(rows[2], o[2]),
+                                   reset_value(rows[3], o[3]));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == d) {
+            float v[4 * NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float4 q = t4[j];
+                v[4 * j + 0] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+            }
+            assign_reset<V>(e, v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -412,13 +463,13 @@ __device__ __forceinline__ void observe(const Params& P, const float* __restrict
 
 // -------------------------------------------------------------------------------------------------
 // One env step (step_wait, R:501-595 / I:303-385).  Returns reward; sets done / trunc flags.
-// On auto-reset `episode_next` is bumped and `did_reset` set so the caller persists the new disturbances.
+// On auto-reset `did_reset` is set so the caller persists the new disturbances.  Must be called by all 64 lanes.
 // -------------------------------------------------------------------------------------------------
 template <int V>
-__device__ __forceinline__ float step_env(const Params& P, const float* __restrict__ gates, const MlpRegs& mlp,
-                                          int lane, Env<V>& e, const float u[4],
-                                          uint32_t gid_lo, uint32_t gid_hi, uint32_t* episode_ptr, bool active,
-                                          bool& done, bool& trunc, bool& did_reset) {
+__device__ __forceinline__ float step_env(const Params& P, const float* __restrict__ gates,
+                                          const float* __restrict__ rtab, float* __restrict__ tile, const MlpRegs& mlp,
+                                          int lane, bool active, Env<V>& e, const float u[4], uint32_t gid_lo,
+                                          uint32_t gid_hi, bool& done, bool& trunc, bool& did_reset) {
     constexpr int S = Env<V>::S;
     const Rot R = make_rot(e.s[6], e.s[7], e.s[8]);
     QR_TICK(P, 3);
@@ -483,12 +534,8 @@ __device__ __forceinline__ float step_env(const Params& P, const float* __restri
     } else {                                                        // R:581-585
 #pragma unroll
         for (int k = 0; k < S; ++k) e.s[k] = nw[k];
-        if (done) {
-            const uint32_t ep = *episode_ptr;
-            if (active) *episode_ptr = ep + 1u;  // shadow lanes of a ragged tail must not touch env 0's counter
-            reset_env<V>(P, e, gid_lo, gid_hi, ep);
-            did_reset = true;
-        }
+        did_reset = done;
+        reset_done_lanes<V>(P, rtab, tile, lane, done && active, e, gid_lo, gid_hi);  // shadow lanes are not reset
     }
     return reward;
 }

@@ -35,8 +35,14 @@ __device__ __forceinline__ void load_env(const Params& P, int i, Env<V>& e) {
         e.s[12] = P.tn[i];
     }
     const int2 ts = P.ts[i];
-    e.target = ts.x;
+    e.target = ts.x & 0xFF;
+    e.episode = (uint32_t)ts.x >> 8;
     e.steps = ts.y;
+}
+
+template <int V>
+__device__ __forceinline__ int2 pack_ts(const Env<V>& e) {
+    return make_int2((int)((uint32_t)e.target | (e.episode << 8)), e.steps);
 }
 
 template <int V>
@@ -117,7 +123,8 @@ __global__ void __launch_bounds__(kBlock)
 step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ obs_out,
             float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
     constexpr int kTab = (V == kE2E) ? kMlpTableFloats : 0;  // the E2E step kernel also stages the MLP table
-    __shared__ __attribute__((aligned(16))) float lds[kTab + kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
+    __shared__ __attribute__((aligned(16))) float lds[kTab + kResetTableFloats + kMaxGates * kGateStride +
+                                                       kBlock * obs_len<V, GA>()];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     // Lanes past the end of a ragged batch stay ACTIVE (they shadow env 0) because the residual MLP uses
@@ -135,25 +142,27 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
     // one cooperative pass brings [MLP table | gate rows] (<= 4.6 KiB, L2 resident) into LDS; the per-lane weight
     // registers are then filled from LDS instead of 26 more global loads on the critical path
     const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
-    float* gates = lds + kTab;
-    if (use_mlp) stage_tables(P, lds, 0, kMlpTableFloats + P.num_gates * kGateStride);
-    else stage_tables(P, gates, kMlpTableFloats, P.num_gates * kGateStride);
+    float* rtab = lds + kTab;                 // [reset table | gate rows | obs tiles]
+    float* gates = rtab + kResetTableFloats;
+    if (use_mlp) stage_tables(P, lds, 0, kOffGatesImage + P.num_gates * kGateStride);
+    else stage_tables(P, rtab, kOffResetImage, kResetTableFloats + P.num_gates * kGateStride);
     __syncthreads();
     MlpRegs mlp;
     if (use_mlp) mlp_load_regs(lds, lane, mlp);
+    float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * obs_len<V, GA>();
     QR_TICK(P, 2);
 
     const float u[4] = {act.x, act.y, act.z, act.w};
     const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
     bool done, trunc, did_reset;
-    const float reward = step_env<V>(P, gates, mlp, lane, e, u, gid_lo, gid_hi, P.episode + ii, active, done, trunc,
+    const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc,
                                      did_reset);
     if (active) {
         rew_out[i] = reward;
         done_out[i] = done ? 1 : 0;
         if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
-        P.ts[i] = make_int2(e.target, e.steps);
+        P.ts[i] = pack_ts<V>(e);
     }
     if (P.flags & kFlagPause) return;  // world state and observation untouched (R:570-572)
     QR_TICK(P, 6);
@@ -165,7 +174,6 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
     observe<V, GA>(P, gates, e, o);
     const int wave_first = i - lane;
     if (wave_first + 64 <= P.n) {  // full wave (wave-uniform): coalesced block store through the LDS tile
-        float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * obs_len<V, GA>();
         store_obs_coalesced<V, GA>(tile, obs_out, (size_t)wave_first, lane, o);
     } else if (active) {
         store_obs<V, GA>(obs_out, i, o);
@@ -183,7 +191,8 @@ template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
                float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
-    __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
+    __shared__ __attribute__((aligned(16))) float lds[kResetTableFloats + kMaxGates * kGateStride +
+                                                       kBlock * obs_len<V, GA>()];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool active = i < P.n;  // ragged tail lanes stay active (wave-wide MLP ops) and shadow env 0
@@ -194,8 +203,9 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
     MlpRegs mlp;  // weights stay in registers for all K steps
     const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
     if (use_mlp) mlp_load_regs(P.tables, lane, mlp);
-    float* gates = lds;
-    stage_tables(P, lds, kMlpTableFloats, P.num_gates * kGateStride);
+    float* rtab = lds;                        // [reset table | gate rows | obs tiles]
+    float* gates = lds + kResetTableFloats;
+    stage_tables(P, lds, kOffResetImage, kResetTableFloats + P.num_gates * kGateStride);
     __syncthreads();
     const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
@@ -203,7 +213,7 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
     constexpr int L = obs_len<V, GA>();
     const int wave_first = i - lane;
     const bool full_wave = wave_first + 64 <= P.n;
-    float* tile = lds + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
+    float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
     bool any_reset = false;
     for (int k = 0; k < K; ++k) {
 #ifdef QR_PHASE_TIMING
@@ -214,8 +224,8 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
         const float4 nxt = actions[(size_t)kn * n + ii];  // prefetch the next step's action
         const float u[4] = {act.x, act.y, act.z, act.w};
         bool done, trunc, did_reset;
-        const float reward = step_env<V>(P, gates, mlp, lane, e, u, gid_lo, gid_hi, P.episode + ii, active, done,
-                                         trunc, did_reset);
+        const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc,
+                                         did_reset);
         any_reset |= did_reset;
         if (active) {
             rew_out[(size_t)k * n + i] = reward;
@@ -233,7 +243,7 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
         act = nxt;
     }
     if (!active) return;
-    P.ts[i] = make_int2(e.target, e.steps);
+    P.ts[i] = pack_ts<V>(e);
     if (P.flags & kFlagPause) return;
     store_world<V>(P, i, e);
     if (any_reset) store_dist<V>(P, i, e);
@@ -243,9 +253,10 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
 template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 reset_kernel(Params P, const uint8_t* __restrict__ mask, float* __restrict__ obs_out) {
-    __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride];
+    __shared__ __attribute__((aligned(16))) float lds_all[kResetTableFloats + kMaxGates * kGateStride];
+    const float* lds = lds_all + kResetTableFloats;
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    stage_tables(P, lds, kMlpTableFloats, P.num_gates * kGateStride);
+    stage_tables(P, lds_all, kOffResetImage, kResetTableFloats + P.num_gates * kGateStride);
     __syncthreads();
     if (i >= P.n) return;
     Env<V> e;
@@ -253,12 +264,10 @@ reset_kernel(Params P, const uint8_t* __restrict__ mask, float* __restrict__ obs
     if (!mask || mask[i]) {
         const uint32_t gid_lo = P.gid_lo + (uint32_t)i;
         const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
-        const uint32_t ep = P.episode[i];
-        P.episode[i] = ep + 1u;
-        reset_env<V>(P, e, gid_lo, gid_hi, ep);
+        reset_env<V>(P, lds_all, e, gid_lo, gid_hi);
         store_world<V>(P, i, e);
         store_dist<V>(P, i, e);
-        P.ts[i] = make_int2(e.target, e.steps);
+        P.ts[i] = pack_ts<V>(e);
     }
     if (obs_out) {
         float o[obs_len<V, GA>()];
@@ -273,7 +282,7 @@ __global__ void __launch_bounds__(kBlock)
 observe_kernel(Params P, float* __restrict__ obs_out) {
     __shared__ __attribute__((aligned(16))) float lds[kMaxGates * kGateStride];
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    stage_tables(P, lds, kMlpTableFloats, P.num_gates * kGateStride);
+    stage_tables(P, lds, kOffGatesImage, P.num_gates * kGateStride);
     __syncthreads();
     if (i >= P.n) return;
     Env<V> e;
@@ -303,7 +312,7 @@ get_state_kernel(Params P, float* __restrict__ world, float* __restrict__ dist, 
     }
     if (target) target[i] = e.target;
     if (steps) steps[i] = e.steps;
-    if (episode) episode[i] = P.episode[i];
+    if (episode) episode[i] = e.episode;
 }
 
 template <int V>
@@ -332,8 +341,17 @@ set_state_kernel(Params P, const float* __restrict__ world, const float* __restr
         e.target = t;
     }
     if (steps) e.steps = steps[i];
-    P.ts[i] = make_int2(e.target, e.steps);
-    if (episode) P.episode[i] = episode[i];
+    if (episode) e.episode = episode[i] & 0xFFFFFFu;
+    P.ts[i] = pack_ts<V>(e);
+}
+
+// qr_seed: restart every env's reset stream (episode counter = 0)
+__global__ void __launch_bounds__(kBlock) clear_episode_kernel(Params P) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P.n) return;
+    int2 ts = P.ts[i];
+    ts.x &= 0xFF;
+    P.ts[i] = ts;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -377,6 +395,11 @@ hipError_t launch_reset(int variant, const Params& P, const uint8_t* mask, float
 hipError_t launch_observe(int variant, const Params& P, float* obs, hipStream_t st) {
     if (variant == kE2E) { QR_DISPATCH_GA(kE2E, observe_kernel, P, obs) }
     else { QR_DISPATCH_GA(kINDI, observe_kernel, P, obs) }
+    return hipGetLastError();
+}
+
+hipError_t launch_clear_episode(const Params& P, hipStream_t st) {
+    hipLaunchKernelGGL(clear_episode_kernel, grid_for(P.n), dim3(kBlock), 0, st, P);
     return hipGetLastError();
 }
 

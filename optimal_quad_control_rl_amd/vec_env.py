@@ -313,6 +313,10 @@ class Quadcopter3DGates(_Base):
 
     update_states_gate = update_states
 
+    def update_states_world(self):
+        """Alternative observation of the reference (R:362-363, unused by default): the raw world state."""
+        return self.world_states
+
     def reset_(self, dones):
         mask = self._to_dev(np.asarray(dones, dtype=np.uint8), torch.uint8)
         _lib.check(self._L.qr_reset(self._h, _ptr(mask), _ptr(self._obs), self._stream()))
@@ -325,17 +329,31 @@ class Quadcopter3DGates(_Base):
     def step_async(self, actions):
         self.actions = actions
 
+    def _host_buffers(self):
+        if getattr(self, "_host", None) is None:
+            n = self.num_envs
+            self._host = (torch.empty((n, self.state_len), dtype=torch.float32).pin_memory(),
+                          torch.empty(n, dtype=torch.float32).pin_memory(),
+                          torch.empty(n, dtype=torch.uint8).pin_memory(),
+                          torch.empty(n, dtype=torch.uint8).pin_memory())
+        return self._host
+
     def step_wait(self):
+        """SB3-facing step: NumPy in, NumPy out (one H->D copy of the actions, one batch of async D->H copies into
+        pinned buffers, one synchronisation).  Use step_device() to stay on the GPU."""
         act = self._to_dev(self.actions, torch.float32)
-        obs, rew, done, trunc = self.step_device(act)
-        done_np = done.cpu().numpy().astype(bool)
+        dev = self.step_device(act)
+        host = self._host_buffers()
+        for h, d in zip(host, dev):
+            h.copy_(d, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        obs_np, rew_np = host[0].numpy().copy(), host[1].numpy().copy()
+        done_np, trunc_np = host[2].numpy().astype(bool), host[3].numpy().astype(bool)
         self.dones = done_np
-        rew_np = rew.cpu().numpy()
-        obs_np = obs.cpu().numpy()
-        infos = self._make_infos(obs_np, done_np, trunc)
+        infos = self._make_infos(obs_np, done_np, trunc_np)
         return obs_np, rew_np, done_np, infos
 
-    def _make_infos(self, obs_np, done_np, trunc):
+    def _make_infos(self, obs_np, done_np, trunc_np):
         if self.infos_mode == "none":
             return []
         if self.infos_mode == "reference":
@@ -344,12 +362,11 @@ class Quadcopter3DGates(_Base):
             shared = {}
             if done_np.any():
                 shared["terminal_observation"] = obs_np[np.nonzero(done_np)[0][-1]]
-            if trunc.any().item():
+            if trunc_np.any():
                 shared["TimeLimit.truncated"] = True
             return [shared] * self.num_envs
         infos = [{} for _ in range(self.num_envs)]
         if done_np.any():
-            trunc_np = trunc.cpu().numpy().astype(bool)
             for i in np.nonzero(done_np)[0]:
                 infos[i]["terminal_observation"] = obs_np[i]
                 if trunc_np[i]:
