@@ -1,0 +1,210 @@
+"""On-device PPO for the MI355X race environment (BASELINE config 5).
+
+The reference trains with stable-baselines3's PPO (`R:783-795`, `I:521-533`): `MlpPolicy` with separate ReLU
+networks pi = vf = [120, 120, 120], `log_std_init = 0`, `gamma = 0.999`, `n_steps = 1000`, `batch_size = 5000`,
+`n_epochs = 10`, SB3 defaults otherwise (lr 3e-4, GAE lambda 0.95, clip 0.2, vf_coef 0.5, ent_coef 0,
+max_grad_norm 0.5, advantage normalisation, orthogonal init, Adam eps 1e-5, actions clipped to the Box).
+
+SB3 is not a dependency here and its NumPy rollout buffer would put a host round trip into every step; this is a
+compact torch implementation of the same algorithm that consumes the env's device tensors directly
+(`step_device`), so observations, actions, rewards and the rollout buffer never leave HBM.  With tens of thousands
+of envs the rollout is short and the minibatches large (`n_steps`, `batch_size`, `n_epochs` are arguments; the
+reference's values suit its 100 envs).  Time-limit truncations are treated like terminations (the reference's own
+bootstrap uses a post-reset observation, see vec_env._make_infos).
+"""
+import math
+import time
+
+import torch
+from torch import nn
+
+
+def _mlp(sizes, out_gain):
+    layers = []
+    for i in range(len(sizes) - 2):
+        lin = nn.Linear(sizes[i], sizes[i + 1])
+        nn.init.orthogonal_(lin.weight, gain=math.sqrt(2.0))
+        nn.init.zeros_(lin.bias)
+        layers += [lin, nn.ReLU()]
+    head = nn.Linear(sizes[-2], sizes[-1])
+    nn.init.orthogonal_(head.weight, gain=out_gain)
+    nn.init.zeros_(head.bias)
+    layers.append(head)
+    return nn.Sequential(*layers)
+
+
+class ActorCritic(nn.Module):
+    """SB3 `MlpPolicy` with `net_arch=dict(pi=[...], vf=[...])`: two separate MLPs and a state-independent log-std."""
+
+    def __init__(self, obs_dim, act_dim, net_arch=(120, 120, 120), log_std_init=0.0):
+        super().__init__()
+        self.pi = _mlp([obs_dim, *net_arch, act_dim], 0.01)
+        self.vf = _mlp([obs_dim, *net_arch, 1], 1.0)
+        self.log_std = nn.Parameter(torch.full((act_dim,), float(log_std_init)))
+
+    def value(self, obs):
+        return self.vf(obs).squeeze(-1)
+
+    def log_prob_entropy(self, obs, actions):
+        mean = self.pi(obs)
+        std = self.log_std.exp()
+        lp = (-0.5 * ((actions - mean) / std) ** 2 - self.log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+        ent = (0.5 + 0.5 * math.log(2 * math.pi) + self.log_std).sum().expand(obs.shape[0])
+        return lp, ent
+
+    @torch.no_grad()
+    def act(self, obs, deterministic=False):
+        mean = self.pi(obs)
+        if deterministic:
+            return mean, None, None
+        std = self.log_std.exp()
+        actions = mean + std * torch.randn_like(mean)
+        lp = (-0.5 * ((actions - mean) / std) ** 2 - self.log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+        return actions, lp, self.vf(obs).squeeze(-1)
+
+
+class PPO:
+    def __init__(self, env, n_steps=32, batch_size=None, n_epochs=5, gamma=0.999, gae_lambda=0.95, clip_range=0.2,
+                 learning_rate=3e-4, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, net_arch=(120, 120, 120),
+                 log_std_init=0.0, seed=0, target_kl=None, lr_final_frac=1.0, total_timesteps_hint=None):
+        self.env = env
+        self.n_envs, self.dev = env.num_envs, env.device
+        self.n_steps, self.n_epochs = n_steps, n_epochs
+        self.batch_size = batch_size or (self.n_envs * n_steps) // 4
+        self.gamma, self.lam, self.clip = gamma, gae_lambda, clip_range
+        self.vf_coef, self.ent_coef, self.max_grad_norm = vf_coef, ent_coef, max_grad_norm
+        self.target_kl, self.lr0, self.lr_final_frac, self.total_hint = target_kl, learning_rate, lr_final_frac, total_timesteps_hint
+        torch.manual_seed(seed)
+        obs_dim = env.state_len
+        self.policy = ActorCritic(obs_dim, 4, net_arch, log_std_init).to(self.dev)
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
+        T, N = n_steps, self.n_envs
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.buf_obs = torch.empty((T, N, obs_dim), **f32)
+        self.buf_act = torch.empty((T, N, 4), **f32)
+        self.buf_lp = torch.empty((T, N), **f32)
+        self.buf_val = torch.empty((T, N), **f32)
+        self.buf_rew = torch.empty((T, N), **f32)
+        self.buf_done = torch.empty((T, N), **f32)
+        self.num_timesteps = 0
+        self.obs = env.reset_device().clone()
+        # on-device episode statistics (what VecMonitor provides in the reference, R:769)
+        self.ep_ret = torch.zeros(N, **f32)
+        self.ep_len = torch.zeros(N, **f32)
+        self.ep_gates = torch.zeros(N, **f32)
+        self.stats = {}
+
+    @torch.no_grad()
+    def collect(self):
+        fin_ret = fin_len = fin_gates = fin_n = 0.0
+        for t in range(self.n_steps):
+            actions, lp, val = self.policy.act(self.obs)
+            self.buf_obs[t].copy_(self.obs)
+            self.buf_act[t].copy_(actions)
+            self.buf_lp[t].copy_(lp)
+            self.buf_val[t].copy_(val)
+            obs, rew, done, _ = self.env.step_device(actions.clamp(-1.0, 1.0).contiguous())  # SB3 clips to the Box
+            d = done.to(torch.float32)
+            self.buf_rew[t].copy_(rew)
+            self.buf_done[t].copy_(d)
+            self.ep_ret += rew
+            self.ep_len += 1.0
+            self.ep_gates += (rew > 5.0).to(torch.float32)  # gate reward 10 - 10*d2g (R:537)
+            fin_ret = fin_ret + (self.ep_ret * d).sum()
+            fin_len = fin_len + (self.ep_len * d).sum()
+            fin_gates = fin_gates + (self.ep_gates * d).sum()
+            fin_n = fin_n + d.sum()
+            keep = 1.0 - d
+            self.ep_ret *= keep
+            self.ep_len *= keep
+            self.ep_gates *= keep
+            self.obs = obs.clone()
+        self.last_val = self.policy.value(self.obs)
+        self.num_timesteps += self.n_steps * self.n_envs
+        n = float(fin_n)
+        if n > 0:
+            self.stats.update(ep_rew_mean=float(fin_ret) / n, ep_len_mean=float(fin_len) / n,
+                              gates_per_episode=float(fin_gates) / n, episodes=n)
+        self.stats["reward_per_step"] = float(self.buf_rew.mean())
+
+    @torch.no_grad()
+    def _gae(self):
+        T = self.n_steps
+        adv = torch.empty_like(self.buf_rew)
+        last = torch.zeros(self.n_envs, dtype=torch.float32, device=self.dev)
+        next_val = self.last_val
+        for t in reversed(range(T)):
+            nonterminal = 1.0 - self.buf_done[t]
+            delta = self.buf_rew[t] + self.gamma * next_val * nonterminal - self.buf_val[t]
+            last = delta + self.gamma * self.lam * nonterminal * last
+            adv[t] = last
+            next_val = self.buf_val[t]
+        return adv, adv + self.buf_val
+
+    def train(self):
+        adv, ret = self._gae()
+        B = self.n_steps * self.n_envs
+        obs = self.buf_obs.view(B, -1)
+        act = self.buf_act.view(B, 4)
+        old_lp, adv, ret = self.buf_lp.view(B), adv.view(B), ret.view(B)
+        losses = []
+        if self.total_hint:  # linear learning-rate decay (SB3: learning_rate may be a schedule)
+            frac = min(1.0, self.num_timesteps / float(self.total_hint))
+            for g in self.opt.param_groups:
+                g["lr"] = self.lr0 * (1.0 - (1.0 - self.lr_final_frac) * frac)
+        stop = False
+        for _ in range(self.n_epochs):
+            if stop:
+                break
+            perm = torch.randperm(B, device=self.dev)
+            for s in range(0, B, self.batch_size):
+                idx = perm[s:s + self.batch_size]
+                a = adv[idx]
+                a = (a - a.mean()) / (a.std() + 1e-8)
+                lp, ent = self.policy.log_prob_entropy(obs[idx], act[idx])
+                log_ratio = lp - old_lp[idx]
+                ratio = log_ratio.exp()
+                if self.target_kl is not None:  # SB3's early stopping on the approximate KL divergence
+                    with torch.no_grad():
+                        approx_kl = float(((ratio - 1.0) - log_ratio).mean())
+                    if approx_kl > 1.5 * self.target_kl:
+                        stop = True
+                        break
+                pg = -torch.min(a * ratio, a * ratio.clamp(1 - self.clip, 1 + self.clip)).mean()
+                v = self.policy.value(obs[idx])
+                vl = torch.nn.functional.mse_loss(v, ret[idx])
+                loss = pg + self.vf_coef * vl - self.ent_coef * ent.mean()
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+                self.opt.step()
+                losses.append(loss.detach())
+        if losses:
+            self.stats["loss"] = float(torch.stack(losses).mean())
+        self.stats["updates"] = self.stats.get("updates", 0) + len(losses)
+        self.stats["std"] = float(self.policy.log_std.detach().exp().mean())
+
+    def learn(self, total_timesteps, log_every=10, callback=None):
+        t0 = time.perf_counter()
+        it = 0
+        while self.num_timesteps < total_timesteps:
+            self.collect()
+            self.train()
+            it += 1
+            if log_every and it % log_every == 0:
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                s = self.stats
+                print(f"it {it:4d}  steps {self.num_timesteps/1e6:8.1f}M  {self.num_timesteps/el/1e6:6.2f} Msteps/s  "
+                      f"ep_rew {s.get('ep_rew_mean', float('nan')):8.2f}  ep_len {s.get('ep_len_mean', float('nan')):7.1f}  "
+                      f"gates/ep {s.get('gates_per_episode', float('nan')):6.2f}  std {s.get('std', 0):.3f}", flush=True)
+            if callback is not None and callback(self) is False:
+                break
+        return self
+
+    @torch.no_grad()
+    def predict(self, obs, deterministic=True):
+        if not isinstance(obs, torch.Tensor):
+            obs = torch.as_tensor(obs, dtype=torch.float32, device=self.dev)
+        a, _, _ = self.policy.act(obs, deterministic=deterministic)
+        return a.clamp(-1.0, 1.0)

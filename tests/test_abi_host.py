@@ -86,3 +86,25 @@ def test_box_stub():
 
     b = Box(-1, 1, shape=(4,))
     assert b.shape == (4,) and b.contains(b.sample())
+
+
+def test_kernel_sincos_algorithm_accuracy():
+    """The kernel's branch-free sincos (qr_sincos), emulated op-for-op in NumPy float32: abs error <= 8e-8 vs float64
+    over the argument range the env can reach -- the same accuracy class as NumPy's float32 sin/cos that the
+    reference evaluates."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from check_sincos import sincos32
+
+    rng = np.random.default_rng(1)
+    for R in (0.4, 3.2, 300.0, 20000.0):
+        x = rng.uniform(-R, R, 200_000).astype(np.float32)
+        s, c = sincos32(x)
+        assert np.abs(s - np.sin(x.astype(np.float64))).max() < 8e-8
+        assert np.abs(c - np.cos(x.astype(np.float64))).max() < 8e-8
+    # constants in the kernel source are the ones that were checked
+    src = open(os.path.join(ROOT, "optimal_quad_control_rl_amd", "csrc", "quadrace_device.hpp")).read()
+    for const in ("0.6366197723675814f", "1.5707963705062866f", "-4.371139000186241e-8f", "-1.7151245100059e-15f",
+                  "2.7183114939898219e-6f", "-0.49999999725103100f"):
+        assert const in src

@@ -301,3 +301,23 @@ def test_sb3_facing_step_wait_and_infos():
         assert env.env_is_wrapped(None) == [False] * n
         assert env.update_states_world().shape == (n, 16)
         env.close()
+
+
+def test_ppo_consumes_device_tensors_and_improves():
+    """BASELINE config 5 smoke: the on-device PPO (reference hyper-parameters' algorithm) runs on the env's device tensors
+    and learns within a few iterations -- the first thing PPO learns here is not to crash (episodes get longer)."""
+    from optimal_quad_control_rl_amd import Quadcopter3DGatesINDI, square_track
+    from optimal_quad_control_rl_amd.ppo import PPO
+
+    env = Quadcopter3DGatesINDI(8192, *square_track(), gates_ahead=1, infos_mode="none", seed=1)
+    model = PPO(env, n_steps=64, n_epochs=8, batch_size=8192 * 64 // 16, learning_rate=1e-3, seed=0)
+    model.collect()
+    first = dict(model.stats)
+    model.train()
+    model.learn(8192 * 64 * 40, log_every=0)
+    last = model.stats
+    assert model.num_timesteps >= 8192 * 64 * 40
+    assert last["ep_len_mean"] > 1.5 * first["ep_len_mean"], (first, last)
+    assert last["reward_per_step"] > first["reward_per_step"]
+    a = model.predict(env.states_tensor)
+    assert a.shape == (8192, 4) and float(a.abs().max()) <= 1.0
