@@ -93,6 +93,26 @@ def parity_probe():
     return {"max_rel_dstate_100_steps": worst, "tolerance": 1e-5, "reference": "tests/golden/f5 (ref step(), 1 env, no residual)"}
 
 
+def host_path_probe(variant, n, ga):
+    """PCIe-inclusive rate of the SB3-facing NumPy path (step_async + step_wait): actions H->D, obs/reward/done D->H
+    every step.  Never the headline `value` (which keeps everything HBM-resident)."""
+    env = make_env(variant, n, ga, env_id_base=0, seed=1)
+    env.infos_mode = "reference"
+    env.reset()
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, size=(n, 4)).astype(np.float32)
+    for _ in range(3):
+        env.step(acts)
+    t0 = time.perf_counter()
+    steps = 20
+    for _ in range(steps):
+        env.step(acts)
+    dt = (time.perf_counter() - t0) / steps
+    env.close()
+    return {"what": "env.step(numpy actions) -> numpy obs/reward/done/infos (SB3 calling convention), PCIe + NumPy inclusive",
+            "ms_per_step": dt * 1e3, "value": n / dt, "unit": "env-steps/s"}
+
+
 def cpu_baseline(variant, n, ga, seconds):
     """The oracle (C port of the reference, parity-pinned against reference fixtures) on this box's host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -278,6 +298,10 @@ def main():
                 except Exception as ex:  # pragma: no cover
                     result["parity"] = {"error": repr(ex)}
             if not args.no_cpu_baseline:
+                try:
+                    result["host_numpy_path"] = host_path_probe(args.variant, n, ga)
+                except Exception as ex:  # pragma: no cover
+                    result["host_numpy_path"] = {"error": repr(ex)}
                 result["cpu_baseline"] = cpu_baseline(args.variant, n, ga, args.cpu_seconds)
         print(json.dumps(result))
     if world > 1:
