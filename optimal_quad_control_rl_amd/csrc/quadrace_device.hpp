@@ -368,6 +368,20 @@ __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const f
     moment[2] = out[3];
 }
 
+// 1/x and sqrt(x) as hardware approximation + one Newton step (error <= 1 ulp; the library forms spend ~10
+// instructions on exact rounding and denormal scaling that this path cannot use: cos(theta) and squared distances
+// are far from the denormal range; at theta = +-pi/2 both forms give inf/NaN exactly like the reference's 1/cos).
+__device__ __forceinline__ float fast_rcp(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float fast_sqrt(float x) {
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float h = 0.5f * __builtin_amdgcn_rcpf(y);
+    const float c = fmaf(fmaf(-y, y, x), h, y);      // y + (x - y*y) / (2y)
+    return x > 0.0f ? c : y;                         // sqrt(0) = 0 (avoid 0 * inf)
+}
+
 // -------------------------------------------------------------------------------------------------
 // Equations of motion: ds = f(s, u, d)
 // -------------------------------------------------------------------------------------------------
@@ -391,7 +405,7 @@ __device__ __forceinline__ void eom_e2e(const float* s, const Rot& R, const floa
     ds[3] = fmaf(R.r00, Fx, fmaf(R.r01, Fy, R.r02 * T));                              // R:138
     ds[4] = fmaf(R.r10, Fx, fmaf(R.r11, Fy, R.r12 * T));
     ds[5] = fmaf(R.r20, Fx, fmaf(R.r21, Fy, fmaf(R.r22, T, 9.81f)));
-    const float inv_cth = 1.0f / R.cth;
+    const float inv_cth = fast_rcp(R.cth);
     const float tth = R.sth * inv_cth;
     const float qr_mix = fmaf(q, R.sph, r * R.cph);
     ds[6] = fmaf(qr_mix, tth, p);                                                     // R:140
@@ -426,7 +440,7 @@ __device__ __forceinline__ void eom_indi(const float* s, const Rot& R, const flo
     ds[3] = fmaf(R.r00, Dx, fmaf(R.r01, Dy, R.r02 * mT));                                 // I:95
     ds[4] = fmaf(R.r10, Dx, fmaf(R.r11, Dy, R.r12 * mT));
     ds[5] = fmaf(R.r20, Dx, fmaf(R.r21, Dy, fmaf(R.r22, mT, 9.81f)));
-    const float inv_cth = 1.0f / R.cth;
+    const float inv_cth = fast_rcp(R.cth);
     const float tth = R.sth * inv_cth;
     const float qr_mix = fmaf(q, R.sph, r * R.cph);
     ds[6] = fmaf(qr_mix, tth, p);                                                         // I:97-99
@@ -528,8 +542,8 @@ __device__ __forceinline__ float step_env(const Params& P, const float* __restri
     const float2 cs = *reinterpret_cast<const float2*>(gates + kGateStride * e.target + 4);
     const float ox = e.s[0] - g0.x, oy = e.s[1] - g0.y, oz = e.s[2] - g0.z;
     const float nx = nw[0] - g0.x, ny = nw[1] - g0.y, nz = nw[2] - g0.z;
-    const float d2g_old = sqrtf(fmaf(ox, ox, fmaf(oy, oy, oz * oz)));  // R:522-525
-    const float d2g_new = sqrtf(fmaf(nx, nx, fmaf(ny, ny, nz * nz)));
+    const float d2g_old = fast_sqrt(fmaf(ox, ox, fmaf(oy, oy, oz * oz)));  // R:522-525
+    const float d2g_new = fast_sqrt(fmaf(nx, nx, fmaf(ny, ny, nz * nz)));
     float reward = d2g_old - d2g_new;
     const float proj_old = fmaf(ox, cs.x, oy * cs.y);               // R:528-532
     const float proj_new = fmaf(nx, cs.x, ny * cs.y);

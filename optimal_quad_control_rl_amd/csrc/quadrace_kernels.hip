@@ -182,65 +182,88 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Fused K-step rollout (qr_step_many): the same step_env() applied K times with the env state held in
-// registers.  Per step a lane only reads its action (prefetched one step ahead) and writes obs / reward /
-// done, so consecutive steps overlap their stores with the next step's arithmetic and there is no launch
-// boundary (and no end-of-kernel L2 write-back) per step.  Bit-identical to K calls of step_kernel.
+// Fused K-step rollout (qr_step_many): the same step_env() applied K times with the env state (and the MLP
+// weights) held in registers.  Per step a lane only needs its action and writes obs / reward / done; there is no
+// launch boundary, state round trip or end-of-kernel L2 write-back per step.  Bit-identical to K x step_kernel.
+//
+// Actions are staged kActChunk steps at a time into a lane-private LDS slot.  On gfx9-family hardware loads and
+// stores share one in-order counter (vmcnt), so ANY global load inside the step loop makes the wave wait for the
+// previous step's stores to be acknowledged (measured: the loop ran at one store round trip, ~1.8 us, per step
+// with ~300 instructions in it).  With the loads hoisted to one burst per chunk, the per-step stores simply
+// stream out behind the arithmetic.
 // ---------------------------------------------------------------------------------------------------
+template <int V, int GA>
+constexpr int act_chunk() {  // steps of actions staged per burst, sized so the static LDS stays <= 64 KiB
+    return (65536 - 4 * (kResetTableFloats + kMaxGates * kGateStride) - 4 * kBlock * obs_len<V, GA>()) / (16 * kBlock) >= 8 ? 8 : 4;
+}
+
 template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
                float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
-    __shared__ __attribute__((aligned(16))) float lds[kResetTableFloats + kMaxGates * kGateStride +
-                                                       kBlock * obs_len<V, GA>()];
+    constexpr int kActChunk = act_chunk<V, GA>();
+    constexpr int L = obs_len<V, GA>();
+    __shared__ __attribute__((aligned(16))) float lds[kResetTableFloats + kMaxGates * kGateStride + kBlock * L +
+                                                       4 * kBlock * kActChunk];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool active = i < P.n;  // ragged tail lanes stay active (wave-wide MLP ops) and shadow env 0
     const int ii = active ? i : 0;
     Env<V> e;
     load_env<V>(P, ii, e);
-    float4 act = actions[ii];
     MlpRegs mlp;  // weights stay in registers for all K steps
     const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
     if (use_mlp) mlp_load_regs(P.tables, lane, mlp);
-    float* rtab = lds;                        // [reset table | gate rows | obs tiles]
+    float* rtab = lds;                        // [reset table | gate rows | obs tiles | action slots]
     float* gates = lds + kResetTableFloats;
     stage_tables(P, lds, kOffResetImage, kResetTableFloats + P.num_gates * kGateStride);
     __syncthreads();
     const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
     const size_t n = (size_t)P.n;
-    constexpr int L = obs_len<V, GA>();
     const int wave_first = i - lane;
     const bool full_wave = wave_first + 64 <= P.n;
     float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
+    // lane-private action slots: element (j, thread) at [j * kBlock + threadIdx.x] (consecutive lanes = consecutive
+    // 16 B, conflict-free); each lane only reads back what it wrote itself
+    float4* act_slot = reinterpret_cast<float4*>(gates + kMaxGates * kGateStride + kBlock * L) + threadIdx.x;
     bool any_reset = false;
-    for (int k = 0; k < K; ++k) {
+    for (int k0 = 0; k0 < K; k0 += kActChunk) {
+        const int c = (K - k0 < kActChunk) ? K - k0 : kActChunk;
+        float4 burst[kActChunk];  // all loads first (clamped step index keeps them unconditional), then the LDS writes
+#pragma unroll
+        for (int j = 0; j < kActChunk; ++j) {
+            const int kk = (k0 + j < K) ? k0 + j : K - 1;
+            burst[j] = actions[(size_t)kk * n + ii];
+        }
+#pragma unroll
+        for (int j = 0; j < kActChunk; ++j) act_slot[j * kBlock] = burst[j];
+        for (int j = 0; j < c; ++j) {
+            const int k = k0 + j;
 #ifdef QR_PHASE_TIMING
-        P.tick_on = (k == K / 2);
+            P.tick_on = (k == K / 2);
 #endif
-        QR_TICK(P, 2);
-        const int kn = (k + 1 < K) ? k + 1 : k;
-        const float4 nxt = actions[(size_t)kn * n + ii];  // prefetch the next step's action
-        const float u[4] = {act.x, act.y, act.z, act.w};
-        bool done, trunc, did_reset;
-        const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc,
-                                         did_reset);
-        any_reset |= did_reset;
-        if (active) {
-            rew_out[(size_t)k * n + i] = reward;
-            done_out[(size_t)k * n + i] = done ? 1 : 0;
-            if (trunc_out) trunc_out[(size_t)k * n + i] = trunc ? 1 : 0;
+            QR_TICK(P, 2);
+            const float4 act = act_slot[j * kBlock];
+            const float u[4] = {act.x, act.y, act.z, act.w};
+            bool done, trunc, did_reset;
+            const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc,
+                                             did_reset);
+            any_reset |= did_reset;
+            if (active) {
+                rew_out[(size_t)k * n + i] = reward;
+                done_out[(size_t)k * n + i] = done ? 1 : 0;
+                if (trunc_out) trunc_out[(size_t)k * n + i] = trunc ? 1 : 0;
+            }
+            QR_TICK(P, 6);
+            if (!(P.flags & kFlagPause)) {
+                float o[L];
+                observe<V, GA>(P, gates, e, o);
+                if (full_wave) store_obs_coalesced<V, GA>(tile, obs_out + (size_t)k * n * L, (size_t)wave_first, lane, o);
+                else if (active) store_obs<V, GA>(obs_out + (size_t)k * n * L, i, o);
+            }
+            QR_TICK(P, 7);
         }
-        QR_TICK(P, 6);
-        if (!(P.flags & kFlagPause)) {
-            float o[L];
-            observe<V, GA>(P, gates, e, o);
-            if (full_wave) store_obs_coalesced<V, GA>(tile, obs_out + (size_t)k * n * L, (size_t)wave_first, lane, o);
-            else if (active) store_obs<V, GA>(obs_out + (size_t)k * n * L, i, o);
-        }
-        QR_TICK(P, 7);
-        act = nxt;
     }
     if (!active) return;
     P.ts[i] = pack_ts<V>(e);
