@@ -36,6 +36,10 @@ struct qr_env {
     bool has_track = false;
     std::vector<float> gate_pos, gate_yaw, gate_pos_rel, gate_yaw_rel;
     float mlp_table[qr::kMlpTableFloats] = {};
+    // host-side configuration that only reaches the device through the tables
+    float start[3] = {0.0f, 0.0f, 0.0f};
+    float dist_lo[6] = {}, dist_hi[6] = {};
+    float dist_scale = 1.0f;  // R:358
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_valid = false;
 };
@@ -43,13 +47,13 @@ struct qr_env {
 namespace {
 
 // observation scaling of the constant disturbances (R:414-448): if min == max the range becomes (min-1, max+1)
-void update_obs_scale(qr::Params& P) {
+void update_obs_scale(qr_env* e) {
     static const int col[4] = {0, 1, 2, 5};
     for (int c = 0; c < 4; ++c) {
-        float lo = P.dist_lo[col[c]], hi = P.dist_hi[col[c]];
+        float lo = e->dist_lo[col[c]], hi = e->dist_hi[col[c]];
         if (lo == hi) { lo -= 1.0f; hi += 1.0f; }
-        P.obs_lo[c] = lo;
-        P.obs_inv[c] = 1.0f / (hi - lo);
+        e->P.obs_lo[c] = lo;
+        e->P.obs_inv[c] = 1.0f / (hi - lo);
     }
 }
 
@@ -81,7 +85,7 @@ int upload_tables(qr_env* e) {
         R[4 * t + 0] = lo; R[4 * t + 1] = span; R[4 * t + 2] = add; R[4 * t + 3] = mul;
     };
     const float pi9 = 0.3490658503988659f, pi = 3.141592653589793f;
-    for (int t = 0; t < 3; ++t) row(t, -0.5f, 0.5f, e->P.start[t], 1.0f);
+    for (int t = 0; t < 3; ++t) row(t, -0.5f, 0.5f, e->start[t], 1.0f);
     for (int t = 3; t < 6; ++t) row(t, -0.5f, 0.5f, 0.0f, 1.0f);
     row(6, -pi9, pi9, 0.0f, 1.0f);
     row(7, -pi9, pi9, 0.0f, 1.0f);
@@ -89,7 +93,7 @@ int upload_tables(qr_env* e) {
     for (int t = 9; t < 12; ++t) row(t, -0.1f, 0.1f, 0.0f, 1.0f);
     if (e->cfg.variant == QR_VARIANT_E2E) {
         for (int t = 12; t < 16; ++t) row(t, -1.0f, 1.0f, 0.0f, 1.0f);
-        for (int k = 0; k < 6; ++k) row(16 + k, e->P.dist_lo[k], e->P.dist_hi[k], 0.0f, e->P.dist_scale);
+        for (int k = 0; k < 6; ++k) row(16 + k, e->dist_lo[k], e->dist_hi[k], 0.0f, e->dist_scale);
     } else {
         row(12, -0.1f, 0.1f, 0.0f, 1.0f);
     }
@@ -184,8 +188,7 @@ int qr_create(const qr_config* cfg, qr_env** out) {
     P.seed_lo = P.seed_hi = 0;
     P.gid_lo = (uint32_t)cfg->env_id_base;
     P.gid_hi = (uint32_t)(cfg->env_id_base >> 32);
-    P.dist_scale = 1.0f;  // R:358
-    update_obs_scale(P);
+    update_obs_scale(e);
     (void)hipEventCreate(&e->ev0);
     (void)hipEventCreate(&e->ev1);
     *out = e;
@@ -229,7 +232,7 @@ int qr_set_track(qr_env* e, const float* gate_pos, const float* gate_yaw, int32_
         e->gate_pos_rel[3 * i + 2] = gate_pos[3 * i + 2] - gate_pos[3 * j + 2];
         e->gate_yaw_rel[i] = gate_yaw[i] - gate_yaw[j];
     }
-    for (int k = 0; k < 3; ++k) e->P.start[k] = start_pos[k];
+    for (int k = 0; k < 3; ++k) e->start[k] = start_pos[k];
     e->P.num_gates = G;
     e->has_track = true;
     return upload_tables(e);
@@ -289,11 +292,11 @@ int qr_set_disturbance(qr_env* e, const float* ranges, float scale) {
     if (!e || !ranges) return fail(QR_E_INVALID, "qr_set_disturbance: null argument");
     if (e->cfg.variant != QR_VARIANT_E2E) return fail(QR_E_INVALID, "qr_set_disturbance: E2E variant only");
     for (int k = 0; k < 6; ++k) {
-        e->P.dist_lo[k] = ranges[2 * k + 0];
-        e->P.dist_hi[k] = ranges[2 * k + 1];
+        e->dist_lo[k] = ranges[2 * k + 0];
+        e->dist_hi[k] = ranges[2 * k + 1];
     }
-    e->P.dist_scale = scale;
-    update_obs_scale(e->P);
+    e->dist_scale = scale;
+    update_obs_scale(e);
     QR_HIP(hipSetDevice(e->cfg.device));
     return upload_tables(e);  // the reset table carries the disturbance ranges
 }

@@ -64,9 +64,6 @@ struct Params {
     int n, n_stride, num_gates, gates_ahead, max_steps, flags;
     float dt;
     uint32_t seed_lo, seed_hi, gid_lo, gid_hi;  // Philox key, global id of env 0
-    float start[3];
-    float dist_lo[6], dist_hi[6];
-    float dist_scale;
     float obs_lo[4], obs_inv[4];  // observation scaling of (Mx,My,Mz,Fz): lo and 1/(hi-lo) after the R:419-441 fix-up
 #ifdef QR_PHASE_TIMING
     unsigned long long* ticks;  // [n_waves][16] shader-clock stamps (profiling build only, tools/phase_timing.py)
@@ -116,14 +113,6 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
 #pragma clang fp contract(off)
     return a * b;
 }
-// lo + (hi-lo)*u
-__device__ __forceinline__ float uni(float lo, float hi, float u) {
-#pragma clang fp contract(off)
-    const float span = hi - lo;
-    const float prod = span * u;
-    return lo + prod;
-}
-
 template <int V>
 struct Env {
     static constexpr int S = (V == kE2E) ? 16 : 13;
