@@ -144,6 +144,22 @@ int qr_profile_steps(qr_env* env, int32_t num_steps, const float* actions_dev, f
                      float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream,
                      float* mean_kernel_ms, float* region_ms);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Policy network on the matrix cores: the MLP the reference trains and deploys,
+ * obs[obs_len] -> 120 -> 120 -> 120 -> 4 with ReLU (SB3 MlpPolicy net_arch pi=[120,120,120], R:783; generated C twin
+ * c_code/neural_network.c:397-430 nn_forward).  f16 operands, f32 accumulation.  Replaces `model.predict(env.states,
+ * deterministic=True)` (R:801) between env steps without leaving the GPU.
+ *   weights: host float32 arrays in torch.nn.Linear layout, w[out][in], b[out].
+ * --------------------------------------------------------------------------------------------------------------- */
+typedef struct qr_policy qr_policy;
+int qr_policy_create(int32_t obs_len, int32_t device, qr_policy** out);
+int qr_policy_destroy(qr_policy* policy);
+const char* qr_policy_last_error(void);
+int qr_policy_set_weights(qr_policy* policy, const float* w1, const float* b1, const float* w2, const float* b2,
+                          const float* w3, const float* b3, const float* w4, const float* b4);
+/* obs_dev [n][obs_len] row-major -> mean_out_dev [n][4] (action means, i.e. the deterministic action before clipping) */
+int qr_policy_forward(qr_policy* policy, int32_t n, const float* obs_dev, float* mean_out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

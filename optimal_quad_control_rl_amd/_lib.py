@@ -46,6 +46,11 @@ SIGNATURES = {
     "qr_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qr_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qr_last_step_many_ms": (C.c_int, [_vp, _f32p]),
+    "qr_policy_create": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "qr_policy_destroy": (C.c_int, [_vp]),
+    "qr_policy_last_error": (C.c_char_p, []),
+    "qr_policy_set_weights": (C.c_int, [_vp] + [_f32p] * 8),
+    "qr_policy_forward": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "qr_profile_steps": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _f32p, _f32p]),
 }
 

@@ -13,8 +13,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libquadrace.so")
-SOURCES = ["quadrace_kernels.hip", "quadrace_abi.hip"]
-HEADERS = ["quadrace_device.hpp", os.path.join("..", "..", "include", "quadrace.h")]
+SOURCES = ["quadrace_kernels.hip", "quadrace_abi.hip", "quadrace_policy.hip"]
+HEADERS = ["quadrace_device.hpp", "quadrace_policy.hpp", os.path.join("..", "..", "include", "quadrace.h")]
 # -ffp-contract=off: FMAs are written explicitly (fmaf) in the kernels, so the arithmetic is fixed by the source and
 # the per-step kernel and the fused rollout kernel produce bit-identical trajectories.
 # -amdgpu-mfma-vgpr-form: keep the MFMA accumulators of the residual MLP in VGPRs (gfx950 has a unified register file),

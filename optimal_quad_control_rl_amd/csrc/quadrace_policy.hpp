@@ -1,0 +1,136 @@
+// quadrace_policy.hpp -- the reference's policy network on the gfx950 matrix cores.
+//
+// The policy the reference trains and deploys is an MLP  obs[L] -> 120 -> 120 -> 120 -> 4  with ReLU
+// (SB3 `MlpPolicy`, net_arch pi=[120,120,120], R:783; generated C twin c_code/neural_network.c:397-430 `nn_forward`).
+// At 65 536 envs it is ~32 k MAC per env-step -- 20x the arithmetic of the env step itself -- and it is a real
+// GEMM chain, so it runs on MFMA: per wave (64 envs)  H^T[128 x 64] = W[128 x K] * X^T[K x 64]  with
+// v_mfma_f32_32x32x16_f16 (f16 operands, f32 accumulate; 160 MFMAs per step).
+//
+// Layout trick that keeps the whole chain in registers (operand layouts verified on MI355X, tools/ubench/mfma_layout.hip):
+//   A (weights, from LDS):  lane l holds  W[row = 32t + (l&31)][k-slot (h = l>>5, j = 0..7)]
+//   B (activations):        lane l holds  act[k-slot (h, j)] of env (32*et + (l&31))
+//   D (result):             lane l, reg r holds row 32t + rho(r, h), rho(r,h) = (r&3) + 8*(r>>2) + 4h, of env 32*et + (l&31)
+// A k-slot is just a name for a hidden unit, so the NEXT layer's K-step (t, s) uses k-slot (h, j) := hidden unit
+// 32t + rho(8s + j, h): its B operand is then exactly registers 8s..8s+7 of accumulator tile t (ReLU + f16 pack, all
+// lane-local), and the host packs the weight columns in the same order.  Biases ride along as one more input: hidden
+// unit 120 of every layer is wired to the constant 1 (weights row 120 = e_bias), and column `bias index` of each
+// weight matrix holds the bias vector.  The first layer's B operand comes from the lane-per-env observation registers
+// via v_permlane32_swap (one swap yields both env tiles); the last layer's 4 outputs return to lane = env the same way.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16p __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2p __attribute__((ext_vector_type(2)));
+
+constexpr int kPolHidden = 120;
+constexpr int kPolHiddenPad = 128;
+constexpr int kPolBiasUnit = 120;  // hidden unit wired to the constant 1
+
+template <int L>
+struct PolicyDims {
+    static constexpr int kIn = L + 1;                          // + constant-1 input
+    static constexpr int kSteps1 = (kIn + 15) / 16;            // K-steps of layer 1
+    static constexpr int kHalf8PerLayer1 = 4 * kSteps1 * 64;   // half8 elements (tiles * ksteps * lanes)
+    static constexpr int kHalf8Hidden = 4 * 8 * 64;
+    static constexpr int kHalf8Out = 1 * 8 * 64;
+    static constexpr int kOff2 = kHalf8PerLayer1;
+    static constexpr int kOff3 = kOff2 + kHalf8Hidden;
+    static constexpr int kOff4 = kOff3 + kHalf8Hidden;
+    static constexpr int kTotalHalf8 = kOff4 + kHalf8Out;      // * 16 bytes
+};
+
+__device__ __forceinline__ void swap32(float a, float b, float& lo, float& hi) {
+    const u32x2p r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    lo = __uint_as_float(r.x);
+    hi = __uint_as_float(r.y);
+}
+
+// relu + f16 pack of accumulator registers 8s..8s+7 -> B operand of the next layer's K-step
+__device__ __forceinline__ half8 relu_pack(const f32x16p& acc, int s) {
+    half8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (_Float16)fmaxf(acc[8 * s + j], 0.0f);
+    return b;
+}
+
+// One hidden layer: in[et][8] (B operands of the 8 K-steps) -> out[et][8].  W = this layer's A operands in LDS.
+__device__ __forceinline__ void policy_hidden_layer(const half8* __restrict__ W, int lane, const half8 (&in)[2][8],
+                                                    half8 (&out)[2][8]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x16p acc0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        f32x16p acc1 = acc0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const half8 a = W[(t * 8 + s) * 64 + lane];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, in[0][s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, in[1][s], acc1, 0, 0, 0);
+        }
+        out[0][2 * t] = relu_pack(acc0, 0);
+        out[0][2 * t + 1] = relu_pack(acc0, 1);
+        out[1][2 * t] = relu_pack(acc1, 0);
+        out[1][2 * t + 1] = relu_pack(acc1, 1);
+    }
+}
+
+// Full policy forward for the wave's 64 envs.  o[L] = this lane's observation (lane = env); mean[4] = action means
+// of this lane's env.  Wlds = packed f16 weights in LDS (PolicyDims<L> layout).  Must be called by all 64 lanes.
+template <int L>
+__device__ __forceinline__ void policy_forward(const half8* __restrict__ Wlds, int lane, const float* o, float mean[4]) {
+    using D = PolicyDims<L>;
+    // ---- layer 1 B operands: input k = 16s + 8h + j; lanes 0..31 supply h = 0, lanes 32..63 h = 1 (of env l-32)
+    half8 in1[2][D::kSteps1];
+#pragma unroll
+    for (int s = 0; s < D::kSteps1; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k0 = 16 * s + j, k1 = 16 * s + 8 + j;
+            const float x0 = (k0 < L) ? o[k0 < L ? k0 : 0] : (k0 == L ? 1.0f : 0.0f);
+            const float x1 = (k1 < L) ? o[k1 < L ? k1 : 0] : (k1 == L ? 1.0f : 0.0f);
+            float lo, hi;
+            swap32(x0, x1, lo, hi);
+            in1[0][s][j] = (_Float16)lo;
+            in1[1][s][j] = (_Float16)hi;
+        }
+    }
+    half8 h1[2][8], h2[2][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x16p acc0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        f32x16p acc1 = acc0;
+#pragma unroll
+        for (int s = 0; s < D::kSteps1; ++s) {
+            const half8 a = Wlds[(t * D::kSteps1 + s) * 64 + lane];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, in1[0][s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, in1[1][s], acc1, 0, 0, 0);
+        }
+        h1[0][2 * t] = relu_pack(acc0, 0);
+        h1[0][2 * t + 1] = relu_pack(acc0, 1);
+        h1[1][2 * t] = relu_pack(acc1, 0);
+        h1[1][2 * t + 1] = relu_pack(acc1, 1);
+    }
+    policy_hidden_layer(Wlds + D::kOff2, lane, h1, h2);
+    policy_hidden_layer(Wlds + D::kOff3, lane, h2, h1);
+    // ---- output layer: one 32-row tile, rows 0..3 = action means
+    f32x16p acc0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    f32x16p acc1 = acc0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const half8 a = Wlds[D::kOff4 + s * 64 + lane];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, h1[0][s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, h1[1][s], acc1, 0, 0, 0);
+    }
+    // rows 0..3 live in registers 0..3 of lanes 0..31 (h = 0) of each env tile: bring tile 1 to lanes 32..63
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float lo, hi;
+        swap32(acc0[r], acc1[r], lo, hi);
+        mean[r] = lo;
+    }
+}
+
+}  // namespace qr

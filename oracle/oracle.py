@@ -78,6 +78,19 @@ def ref_residual_lib():
     return L
 
 
+def ref_policy_lib():
+    """The reference's generated policy C (c_code/neural_network.c: nn_forward + baked weights); None if absent."""
+    build()
+    path = os.path.join(_HERE, "_ref", "libref_policy.so")
+    if not os.path.exists(path):
+        subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    L.nn_forward.argtypes = [_f32p, _f32p]
+    return L
+
+
 def _p(a, t=_f32p):
     return a.ctypes.data_as(t)
 

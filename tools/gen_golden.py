@@ -462,6 +462,34 @@ def gen_reset_stats(ns_e2e, ns_indi):
     save("reset_stats", **out)
 
 
+def gen_f10_policy(rng):
+    """F10: the reference's deployed policy network (c_code/neural_network.c, compiled from where it lies by
+    oracle/Makefile): its baked weights (data) + 512 observation rows -> nn_forward outputs."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+
+    L = O.ref_policy_lib()
+    assert L is not None, "oracle/_ref/libref_policy.so not built"
+    f32p = C.POINTER(C.c_float)
+
+    def arr(name, n):
+        a = (C.c_float * n).in_dll(L, name)
+        return np.ctypeslib.as_array(a).copy()
+
+    w = dict(w1=arr("weights_fc1", 120 * 24).reshape(120, 24), b1=arr("biases_fc1", 120),
+             w2=arr("weights_fc2", 120 * 120).reshape(120, 120), b2=arr("biases_fc2", 120),
+             w3=arr("weights_fc3", 120 * 120).reshape(120, 120), b3=arr("biases_fc3", 120),
+             w4=arr("weights_fc4", 4 * 120).reshape(4, 120), b4=arr("biases_fc4", 4))
+    n = 512
+    scale = np.array([3, 3, 1, 5, 5, 3, 0.6, 0.6, 3.1, 3, 3, 2, 1, 1, 1, 1, 3, 3, 0.5, 2, 1, 1, 1, 1])
+    x = (rng.uniform(-1, 1, size=(n, 24)) * scale).astype(np.float32)
+    y = np.zeros((n, 4), np.float32)
+    for i in range(n):
+        L.nn_forward(x[i].ctypes.data_as(f32p), y[i].ctypes.data_as(f32p))
+    save("f10_policy", obs=x, mean=y, **w)
+
+
 def main():
     assert ref_import.reference_available(), "reference not mounted"
     os.makedirs(OUT, exist_ok=True)
@@ -480,6 +508,7 @@ def main():
     gen_f8_indi_traj(ns_indi, rng)
     gen_f9_modes(ns_e2e, ns_indi, rng)
     gen_reset_stats(ns_e2e, ns_indi)
+    gen_f10_policy(rng)
     print("done")
 
 
