@@ -160,6 +160,18 @@ int qr_policy_set_weights(qr_policy* policy, const float* w1, const float* b1, c
 /* obs_dev [n][obs_len] row-major -> mean_out_dev [n][4] (action means, i.e. the deterministic action before clipping) */
 int qr_policy_forward(qr_policy* policy, int32_t n, const float* obs_dev, float* mean_out_dev, void* stream);
 
+/* Closed-loop rollout: K steps of  obs -> policy -> a ~ N(mean, exp(log_std)^2) -> env.step(clip(a, -1, 1))  in ONE
+ * kernel (PPO's collect phase, R:820 -> SB3 collect_rollouts, without leaving the chip).  Row t of the outputs is
+ * (obs_t the action was computed from, unclipped action_t, log-prob_t of that action, reward_t, done_t[, trunc_t]);
+ * last_obs_dev [N][obs_len] (may be NULL) receives the observation after the last step (value bootstrap).
+ * log_std: host float[4].  Action noise is Philox4x32-10 + Box-Muller keyed by (noise_seed, global env id,
+ * first_step + t): pass the number of steps already taken as first_step.  deterministic != 0: action = mean.
+ * qr_last_step_many_ms() reports this launch too. */
+int qr_rollout_policy(qr_env* env, qr_policy* policy, int32_t num_steps, const float* log_std, uint64_t noise_seed,
+                      uint64_t first_step, int32_t deterministic, float* obs_out_dev, float* act_out_dev,
+                      float* logp_out_dev, float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev,
+                      float* last_obs_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,12 +11,19 @@
 
 #include "../../include/quadrace.h"
 #include "quadrace_device.hpp"
+#include "quadrace_policy.hpp"
 
 namespace qr {
 hipError_t launch_step(int variant, const Params& P, const float* actions, float* obs, float* rew, uint8_t* done,
                        uint8_t* trunc, hipStream_t st);
 hipError_t launch_rollout(int variant, const Params& P, int K, const float* actions, float* obs, float* rew,
                           uint8_t* done, uint8_t* trunc, hipStream_t st);
+hipError_t launch_rollout_policy(int variant, const Params& P, const PolicyArgs& A, int K, float* obs, float* act,
+                                 float* logp, float* rew, uint8_t* done, uint8_t* trunc, float* last_obs,
+                                 hipStream_t st);
+const half8* policy_weights(const qr_policy* p);
+int policy_obs_len(const qr_policy* p);
+int policy_device(const qr_policy* p);
 hipError_t launch_reset(int variant, const Params& P, const uint8_t* mask, float* obs, hipStream_t st);
 hipError_t launch_observe(int variant, const Params& P, float* obs, hipStream_t st);
 hipError_t launch_clear_episode(const Params& P, hipStream_t st);
@@ -370,6 +377,42 @@ int qr_step_launches(qr_env* e, int32_t K, const float* actions_dev, float* obs_
                                rew_out_dev + (size_t)k * n, done_out_dev + (size_t)k * n,
                                trunc_out_dev ? trunc_out_dev + (size_t)k * n : nullptr, st));
     }
+    QR_HIP(hipEventRecord(e->ev1, st));
+    e->timing_valid = true;
+    return QR_OK;
+}
+
+int qr_rollout_policy(qr_env* e, qr_policy* policy, int32_t K, const float* log_std, uint64_t noise_seed,
+                      uint64_t first_step, int32_t deterministic, float* obs_out_dev, float* act_out_dev,
+                      float* logp_out_dev, float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev,
+                      float* last_obs_dev, void* stream) {
+    if (int rc = check_ready(e)) return rc;
+    if (K < 1 || !policy || !log_std) return fail(QR_E_INVALID, "qr_rollout_policy: bad argument");
+    if (!obs_out_dev || !act_out_dev || !logp_out_dev || !rew_out_dev || !done_out_dev)
+        return fail(QR_E_INVALID, "qr_rollout_policy: obs/act/logp/rew/done buffers are required");
+    if (e->P.flags & (qr::kFlagPause | qr::kFlagPauseIfCollision))
+        return fail(QR_E_STATE, "qr_rollout_policy: pause / pause_if_collision envs are evaluation modes; use qr_step");
+    const qr::half8* w = qr::policy_weights(policy);
+    if (!w) return fail(QR_E_STATE, "qr_rollout_policy: the policy has no weights");
+    if (qr::policy_obs_len(policy) != e->L) return fail(QR_E_INVALID, "qr_rollout_policy: policy obs_len != env obs_len");
+    if (qr::policy_device(policy) != e->cfg.device) return fail(QR_E_INVALID, "qr_rollout_policy: policy on another GPU");
+    qr::PolicyArgs A{};
+    A.weights = w;
+    float sum_log_std = 0.0f;
+    for (int c = 0; c < 4; ++c) {
+        A.std[c] = expf(log_std[c]);
+        sum_log_std += log_std[c];
+    }
+    A.logp_const = -sum_log_std - 2.0f * 1.8378770664093453f;  // 4 * 0.5 * log(2*pi)
+    A.seed_lo = (uint32_t)noise_seed;
+    A.seed_hi = (uint32_t)(noise_seed >> 32);
+    A.step_lo = (uint32_t)first_step;
+    A.step_hi = (uint32_t)(first_step >> 32);
+    A.deterministic = deterministic ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    QR_HIP(hipEventRecord(e->ev0, st));
+    QR_HIP(qr::launch_rollout_policy(e->cfg.variant, e->P, A, K, obs_out_dev, act_out_dev, logp_out_dev, rew_out_dev,
+                                     done_out_dev, trunc_out_dev, last_obs_dev, st));
     QR_HIP(hipEventRecord(e->ev1, st));
     e->timing_valid = true;
     return QR_OK;

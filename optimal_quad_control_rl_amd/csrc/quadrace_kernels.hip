@@ -7,6 +7,7 @@
 // also owns an LDS tile for coalesced observation stores.  Residual-MLP weights live in registers (one float per
 // lane per MFMA K-step, see quadrace_device.hpp).
 #include "quadrace_device.hpp"
+#include "quadrace_policy.hpp"
 
 namespace qr {
 
@@ -272,6 +273,103 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
     if (any_reset) store_dist<V>(P, i, e);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Closed-loop rollout (qr_rollout_policy): policy network + Gaussian action sampling + env step, K times in one
+// kernel.  Per step: obs (registers) -> MFMA policy -> mean; action = mean + std * N(0,1) (Philox + Box-Muller keyed
+// by (noise seed, global env id, global step)); the buffer gets (obs_t, action_t, log-prob_t), the env gets the action
+// clipped to the Box [-1, 1] (what SB3 does, R:785); reward_t / done_t follow; the post-step observation feeds the
+// next step.  This is PPO's collect phase (R:820 -> SB3 collect_rollouts) without leaving the chip.
+// ---------------------------------------------------------------------------------------------------
+template <int V, int GA>
+__global__ void __launch_bounds__(kBlock, 1)
+rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out, float4* __restrict__ act_out,
+                      float* __restrict__ logp_out, float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
+                      uint8_t* __restrict__ trunc_out, float* __restrict__ last_obs_out) {
+    constexpr int L = obs_len<V, GA>();
+    using D = PolicyDims<L>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8* W = reinterpret_cast<half8*>(smem);                                   // policy weights (f16)
+    float* rtab = reinterpret_cast<float*>(smem + (size_t)D::kTotalHalf8 * 16);  // reset table | gate rows | obs tiles
+    float* gates = rtab + kResetTableFloats;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool active = i < P.n;
+    const int ii = active ? i : 0;
+    Env<V> e;
+    load_env<V>(P, ii, e);
+    MlpRegs mlp;
+    const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
+    if (use_mlp) mlp_load_regs(P.tables, lane, mlp);
+    {
+        const float4* s4 = reinterpret_cast<const float4*>(A.weights);
+        float4* d4 = reinterpret_cast<float4*>(W);
+        for (int j = threadIdx.x; j < D::kTotalHalf8; j += kBlock) d4[j] = s4[j];
+    }
+    stage_tables(P, rtab, kOffResetImage, kResetTableFloats + P.num_gates * kGateStride);
+    __syncthreads();
+    const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
+    const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
+    const size_t n = (size_t)P.n;
+    const int wave_first = i - lane;
+    const bool full_wave = wave_first + 64 <= P.n;
+    float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
+    bool any_reset = false;
+    float o[L];
+    observe<V, GA>(P, gates, e, o);
+    for (int k = 0; k < K; ++k) {
+        float mean[4];
+        policy_forward<L>(W, lane, o, mean);
+        float a[4] = {mean[0], mean[1], mean[2], mean[3]};
+        float logp = A.logp_const;
+        if (!A.deterministic) {
+            const uint32_t s_lo = A.step_lo + (uint32_t)k;
+            const uint32_t s_hi = A.step_hi + (s_lo < A.step_lo ? 1u : 0u);
+            uint32_t r[4];
+            philox4x32_10(gid_lo, gid_hi, s_lo, s_hi, A.seed_lo, A.seed_hi, r);
+            // Box-Muller: two pairs of normals from four uniforms (u1 in (0,1], u2 in [0,1))
+            const float u1a = (float)((r[0] >> 8) + 1u) * 5.9604644775390625e-8f, u2a = u01(r[1]);
+            const float u1b = (float)((r[2] >> 8) + 1u) * 5.9604644775390625e-8f, u2b = u01(r[3]);
+            const float ra = fast_sqrt(-2.0f * __logf(u1a)), rb = fast_sqrt(-2.0f * __logf(u1b));
+            float sa, ca, sb, cb;
+            qr_sincos(6.283185307179586f * u2a, sa, ca);
+            qr_sincos(6.283185307179586f * u2b, sb, cb);
+            const float eps[4] = {ra * ca, ra * sa, rb * cb, rb * sb};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                a[c] = fmaf(A.std[c], eps[c], mean[c]);
+                logp = fmaf(-0.5f * eps[c], eps[c], logp);
+            }
+        }
+        // rollout buffer row t: the observation the action was computed from, the unclipped action, its log-prob
+        if (full_wave) store_obs_coalesced<V, GA>(tile, obs_out + (size_t)k * n * L, (size_t)wave_first, lane, o);
+        else if (active) store_obs<V, GA>(obs_out + (size_t)k * n * L, i, o);
+        if (active) {
+            act_out[(size_t)k * n + i] = make_float4(a[0], a[1], a[2], a[3]);
+            logp_out[(size_t)k * n + i] = logp;
+        }
+        const float u[4] = {fminf(fmaxf(a[0], -1.0f), 1.0f), fminf(fmaxf(a[1], -1.0f), 1.0f),
+                            fminf(fmaxf(a[2], -1.0f), 1.0f), fminf(fmaxf(a[3], -1.0f), 1.0f)};
+        bool done, trunc, did_reset;
+        const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc,
+                                         did_reset);
+        any_reset |= did_reset;
+        if (active) {
+            rew_out[(size_t)k * n + i] = reward;
+            done_out[(size_t)k * n + i] = done ? 1 : 0;
+            if (trunc_out) trunc_out[(size_t)k * n + i] = trunc ? 1 : 0;
+        }
+        observe<V, GA>(P, gates, e, o);
+    }
+    if (last_obs_out) {
+        if (full_wave) store_obs_coalesced<V, GA>(tile, last_obs_out, (size_t)wave_first, lane, o);
+        else if (active) store_obs<V, GA>(last_obs_out, i, o);
+    }
+    if (!active) return;
+    P.ts[i] = pack_ts<V>(e);
+    store_world<V>(P, i, e);
+    if (any_reset) store_dist<V>(P, i, e);
+}
+
 // reset_(mask) + update_states for ALL envs (R:452-496)
 template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
@@ -407,6 +505,39 @@ hipError_t launch_rollout(int variant, const Params& P, int K, const float* acti
     if (variant == kE2E) { QR_DISPATCH_GA(kE2E, rollout_kernel, P, K, a4, obs, rew, done, trunc) }
     else { QR_DISPATCH_GA(kINDI, rollout_kernel, P, K, a4, obs, rew, done, trunc) }
     return hipGetLastError();
+}
+
+template <int V, int GA>
+hipError_t launch_rollout_policy_vg(const Params& P, const PolicyArgs& A, int K, float* obs, float* act, float* logp,
+                                    float* rew, uint8_t* done, uint8_t* trunc, float* last_obs, hipStream_t st) {
+    constexpr int L = obs_len<V, GA>();
+    const size_t lds = (size_t)PolicyDims<L>::kTotalHalf8 * 16 +
+                       sizeof(float) * (kResetTableFloats + kMaxGates * kGateStride + kBlock * L);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_policy_kernel<V, GA>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((rollout_policy_kernel<V, GA>), grid_for(P.n), dim3(kBlock), lds, st, P, A, K, obs,
+                       reinterpret_cast<float4*>(act), logp, rew, done, trunc, last_obs);
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout_policy(int variant, const Params& P, const PolicyArgs& A, int K, float* obs, float* act,
+                                 float* logp, float* rew, uint8_t* done, uint8_t* trunc, float* last_obs,
+                                 hipStream_t st) {
+#define QR_RP(V, GA) return launch_rollout_policy_vg<V, GA>(P, A, K, obs, act, logp, rew, done, trunc, last_obs, st)
+    if (variant == kE2E) {
+        switch (P.gates_ahead) { case 0: QR_RP(kE2E, 0); case 1: QR_RP(kE2E, 1); case 2: QR_RP(kE2E, 2);
+                                 case 3: QR_RP(kE2E, 3); case 4: QR_RP(kE2E, 4); }
+    } else {
+        switch (P.gates_ahead) { case 0: QR_RP(kINDI, 0); case 1: QR_RP(kINDI, 1); case 2: QR_RP(kINDI, 2);
+                                 case 3: QR_RP(kINDI, 3); case 4: QR_RP(kINDI, 4); }
+    }
+#undef QR_RP
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_reset(int variant, const Params& P, const uint8_t* mask, float* obs, hipStream_t st) {

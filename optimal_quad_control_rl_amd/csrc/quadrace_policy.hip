@@ -95,6 +95,12 @@ int pfail(int code, const std::string& m) { g_perr = m; return code; }
 inline int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 }  // namespace
 
+namespace qr {  // accessors for the closed-loop rollout entry point in quadrace_abi.hip
+const half8* policy_weights(const qr_policy* p) { return (p && p->has_weights) ? p->d_weights : nullptr; }
+int policy_obs_len(const qr_policy* p) { return p ? p->L : -1; }
+int policy_device(const qr_policy* p) { return p ? p->device : -1; }
+}  // namespace qr
+
 extern "C" {
 
 const char* qr_policy_last_error(void) { return g_perr.c_str(); }

@@ -133,4 +133,14 @@ __device__ __forceinline__ void policy_forward(const half8* __restrict__ Wlds, i
     }
 }
 
+// Arguments of the closed-loop rollout (policy + sampling inside the env rollout kernel)
+struct PolicyArgs {
+    const half8* weights;   // packed f16 image (PolicyDims<L> layout)
+    float std[4];           // exp(log_std)
+    float logp_const;       // -sum(log_std) - 2*log(2*pi)
+    uint32_t seed_lo, seed_hi;  // Philox key of the action noise
+    uint32_t step_lo, step_hi;  // global step counter of this call's first step (noise stream position)
+    int deterministic;          // 1: action = mean (no noise)
+};
+
 }  // namespace qr

@@ -441,6 +441,26 @@ class Quadcopter3DGates(_Base):
             self._obs.copy_(obs[K - 1])
         return out
 
+    def rollout_policy_device(self, policy, num_steps, log_std, noise_seed=0, first_step=0, deterministic=False, out=None):
+        """Closed-loop rollout in ONE kernel (qr_rollout_policy): K x [obs -> MFMA policy -> sample -> env.step].
+        `policy` is an optimal_quad_control_rl_amd.policy.MfmaPolicy.  Returns device tensors
+        (obs[K,N,L], actions[K,N,4] unclipped, logp[K,N], reward[K,N], done[K,N] u8, trunc[K,N] u8, last_obs[N,L])."""
+        K, n, dev = int(num_steps), self.num_envs, self.device
+        if out is None:
+            out = (torch.empty((K, n, self.state_len), dtype=torch.float32, device=dev),
+                   torch.empty((K, n, 4), dtype=torch.float32, device=dev),
+                   torch.empty((K, n), dtype=torch.float32, device=dev),
+                   torch.empty((K, n), dtype=torch.float32, device=dev),
+                   torch.empty((K, n), dtype=torch.uint8, device=dev),
+                   torch.empty((K, n), dtype=torch.uint8, device=dev))
+        obs, act, logp, rew, done, trunc = out
+        ls = np.ascontiguousarray(log_std.detach().cpu().numpy() if isinstance(log_std, torch.Tensor) else log_std,
+                                  dtype=np.float32).reshape(4)
+        _lib.check(self._L.qr_rollout_policy(self._h, policy._h, K, _f32p(ls), int(noise_seed), int(first_step),
+                                             int(bool(deterministic)), _ptr(obs), _ptr(act), _ptr(logp), _ptr(rew),
+                                             _ptr(done), _ptr(trunc), _ptr(self._obs), self._stream()))
+        return obs, act, logp, rew, done, trunc, self._obs
+
     def profile_rollout(self, actions, out):
         """Like rollout_device but every step kernel is bracketed by its own hipEvent pair on the launch stream.
         Returns (mean single-kernel duration in ms, whole-region ms).  Blocks."""

@@ -62,3 +62,75 @@ def test_policy_errors():
     assert L.qr_policy_create(24, 0, C.byref(h)) == 0
     assert L.qr_policy_forward(h, 4, C.c_void_p(8), C.c_void_p(8), None) == _lib.QR_E_STATE  # no weights yet
     assert L.qr_policy_destroy(h) == 0
+
+
+def _make(variant, n, seed=5):
+    from optimal_quad_control_rl_amd import (Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES,
+                                             square_track, zigzag_track)
+
+    if variant == "e2e":
+        env = Quadcopter3DGates(n, *zigzag_track(), gates_ahead=1, seed=seed, infos_mode="none")
+        env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+    else:
+        env = Quadcopter3DGatesINDI(n, *square_track(), gates_ahead=1, seed=seed, infos_mode="none")
+    env.max_steps = 30  # auto-resets inside the window
+    env.reset_device()
+    return env
+
+
+def _policy_for(env, gain=20.0):
+    from optimal_quad_control_rl_amd.policy import MfmaPolicy
+    from optimal_quad_control_rl_amd.ppo import ActorCritic
+
+    torch.manual_seed(3)
+    net = ActorCritic(env.state_len, 4).cuda()
+    with torch.no_grad():
+        net.pi[-1].weight.mul_(gain)  # a policy that actually moves the drone
+    return net, MfmaPolicy(env.state_len).load_torch(net.pi)
+
+
+@pytest.mark.parametrize("variant", ["e2e", "indi"])
+@pytest.mark.parametrize("n", [65536, 1000])
+def test_closed_loop_rollout_equals_policy_plus_step_launches(variant, n):
+    """deterministic closed-loop rollout kernel == K x [policy kernel, clip, step kernel], bit for bit."""
+    K = 48
+    net, pol = _policy_for(_make(variant, 8))
+    a, b = _make(variant, n), _make(variant, n)
+    obs, act, logp, rew, done, trunc, last = a.rollout_policy_device(pol, K, torch.zeros(4), deterministic=True)
+    o = b.states_tensor.clone()
+    for k in range(K):
+        assert torch.equal(obs[k], o), k
+        mean = pol.forward(o)
+        assert torch.equal(act[k], mean), k
+        o2, r2, d2, t2 = b.step_device(mean.clamp(-1, 1).contiguous())
+        assert torch.equal(rew[k], r2) and torch.equal(done[k], d2) and torch.equal(trunc[k], t2), k
+        o = o2.clone()
+    assert torch.equal(last, o)
+    for sa, sb in zip(a.get_state_tensors(), b.get_state_tensors()):
+        assert sa is None or torch.equal(sa, sb)
+    assert done.sum() >= n  # max_steps = 30 inside K = 48
+
+
+def test_closed_loop_rollout_sampling_statistics():
+    n, K = 65536, 8
+    env = _make("indi", n)
+    net, pol = _policy_for(env, gain=1.0)
+    log_std = torch.tensor([0.0, -0.5, 0.3, -1.0])
+    obs, act, logp, rew, done, trunc, last = env.rollout_policy_device(pol, K, log_std, noise_seed=11, first_step=1000)
+    std = log_std.exp().cuda()
+    mean = torch.stack([pol.forward(obs[k].contiguous()) for k in range(K)])
+    eps = (act - mean) / std
+    assert abs(eps.mean().item()) < 5e-3 and abs(eps.var().item() - 1.0) < 1e-2
+    assert abs((eps ** 4).mean().item() - 3.0) < 0.1            # Gaussian kurtosis
+    c = torch.corrcoef(eps.reshape(-1, 4).T)
+    assert (c - torch.eye(4, device="cuda")).abs().max() < 1e-2  # independent components
+    assert abs(torch.corrcoef(torch.stack([eps[0, :, 0], eps[1, :, 0]]))[0, 1].item()) < 2e-2  # and steps
+    lp = (-0.5 * eps ** 2).sum(-1) - log_std.sum().item() - 2 * np.log(2 * np.pi)
+    assert (lp - logp).abs().max().item() < 2e-3
+    # same seed / step offset -> same noise; different offset -> different noise
+    env2 = _make("indi", n)
+    _, act2, *_ = env2.rollout_policy_device(pol, K, log_std, noise_seed=11, first_step=1000)
+    assert torch.equal(act, act2)
+    env3 = _make("indi", n)
+    _, act3, *_ = env3.rollout_policy_device(pol, K, log_std, noise_seed=11, first_step=2000)
+    assert not torch.equal(act[0], act3[0])
