@@ -66,7 +66,8 @@ class ActorCritic(nn.Module):
 class PPO:
     def __init__(self, env, n_steps=32, batch_size=None, n_epochs=5, gamma=0.999, gae_lambda=0.95, clip_range=0.2,
                  learning_rate=3e-4, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, net_arch=(120, 120, 120),
-                 log_std_init=0.0, seed=0, target_kl=None, lr_final_frac=1.0, total_timesteps_hint=None):
+                 log_std_init=0.0, seed=0, target_kl=None, lr_final_frac=1.0, total_timesteps_hint=None,
+                 fused_collect=False):
         self.env = env
         self.n_envs, self.dev = env.num_envs, env.device
         self.n_steps, self.n_epochs = n_steps, n_epochs
@@ -86,6 +87,8 @@ class PPO:
         self.buf_val = torch.empty((T, N), **f32)
         self.buf_rew = torch.empty((T, N), **f32)
         self.buf_done = torch.empty((T, N), **f32)
+        self._done_u8 = torch.empty((T, N), dtype=torch.uint8, device=self.dev)
+        self._trunc_u8 = torch.empty((T, N), dtype=torch.uint8, device=self.dev)
         self.num_timesteps = 0
         self.obs = env.reset_device().clone()
         # on-device episode statistics (what VecMonitor provides in the reference, R:769)
@@ -93,9 +96,53 @@ class PPO:
         self.ep_len = torch.zeros(N, **f32)
         self.ep_gates = torch.zeros(N, **f32)
         self.stats = {}
+        # fused_collect: the whole collect phase is ONE kernel (qr_rollout_policy): MFMA policy (f16 operands) +
+        # Gaussian sampling + env step; values (and nothing else) are evaluated by torch afterwards in one batch.
+        self.fused_collect = fused_collect
+        self.noise_seed = seed
+        self._mfma = None
+        if fused_collect:
+            from .policy import MfmaPolicy
+
+            self._mfma = MfmaPolicy(obs_dim, self.dev.index)
+            self._last_obs = None
+
+    @torch.no_grad()
+    def _episode_stats(self, rew, done):
+        fin = torch.zeros(4, dtype=torch.float32, device=self.dev)
+        for t in range(rew.shape[0]):
+            d = done[t]
+            self.ep_ret += rew[t]
+            self.ep_len += 1.0
+            self.ep_gates += (rew[t] > 5.0).to(torch.float32)  # gate reward 10 - 10*d2g (R:537)
+            fin += torch.stack([(self.ep_ret * d).sum(), (self.ep_len * d).sum(), (self.ep_gates * d).sum(), d.sum()])
+            keep = 1.0 - d
+            self.ep_ret *= keep
+            self.ep_len *= keep
+            self.ep_gates *= keep
+        f = fin.tolist()
+        if f[3] > 0:
+            self.stats.update(ep_rew_mean=f[0] / f[3], ep_len_mean=f[1] / f[3], gates_per_episode=f[2] / f[3], episodes=f[3])
+        self.stats["reward_per_step"] = float(rew.mean())
+
+    @torch.no_grad()
+    def collect_fused(self):
+        self._mfma.load_torch(self.policy.pi)
+        first_step = self.num_timesteps // self.n_envs
+        obs, act, logp, rew, done, trunc, last_obs = self.env.rollout_policy_device(
+            self._mfma, self.n_steps, self.policy.log_std, noise_seed=self.noise_seed, first_step=first_step,
+            out=(self.buf_obs, self.buf_act, self.buf_lp, self.buf_rew, self._done_u8, self._trunc_u8))
+        self.buf_done.copy_(done)
+        T, N = self.n_steps, self.n_envs
+        self.buf_val.copy_(self.policy.value(self.buf_obs.view(T * N, -1)).view(T, N))
+        self.last_val = self.policy.value(last_obs)
+        self.num_timesteps += T * N
+        self._episode_stats(self.buf_rew, self.buf_done)
 
     @torch.no_grad()
     def collect(self):
+        if self.fused_collect:
+            return self.collect_fused()
         fin_ret = fin_len = fin_gates = fin_n = 0.0
         for t in range(self.n_steps):
             actions, lp, val = self.policy.act(self.obs)
