@@ -249,6 +249,34 @@ def main():
                      "kernel_us": mean_kernel_ms * 1e3, "bytes_per_launch": bytes_per_step, "launches_timed": K,
                      "kernel_us_event_pair_per_launch": pair_kernel_ms * 1e3}
 
+    # --- closed loop (config 5 collect phase): policy MLP + sampling + env step in one kernel --------------------------
+    closed_loop = None
+    try:
+        from optimal_quad_control_rl_amd.policy import MfmaPolicy
+        from optimal_quad_control_rl_amd.ppo import ActorCritic
+
+        torch.manual_seed(0)
+        net = ActorCritic(L, 4).to(dev)  # random-init weights of the reference's policy architecture (R:783)
+        pol = MfmaPolicy(L, dev.index).load_torch(net.pi)
+        Kc = min(K, 256)
+        cl_out = None
+        cl_t = []
+        for r in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            cl_res = env.rollout_policy_device(pol, Kc, torch.zeros(4), noise_seed=rank, first_step=r * Kc, out=cl_out)
+            barrier()
+            cl_t.append(time.perf_counter() - t0)
+            cl_out = cl_res[:6]
+        cl_el = float(np.median(cl_t[1:]))
+        closed_loop = {"what": "qr_rollout_policy: K x [obs -> policy MLP (L->120->120->120->4, f16 MFMA) -> Gaussian sample -> "
+                               "env.step] in ONE kernel (PPO collect phase); random-init policy weights",
+                       "steps": Kc, "ms_per_step": cl_el * 1e3 / Kc, "value": n * world * Kc / cl_el, "unit": "env-steps/s",
+                       "kernel_us_per_step": env.last_rollout_ms() * 1e3 / Kc}
+        del cl_out, cl_res
+    except Exception as ex:  # pragma: no cover
+        closed_loop = {"error": repr(ex)}
+
     # --- rollout-boundary exchange (config 4): RCCL all-gather of [obs | reward | done] --------------------------
     exchange = None
     if world > 1 and not args.no_exchange:
@@ -289,6 +317,8 @@ def main():
                 "value": total_steps / elapsed, "unit": "env-steps/s", "ms_per_step": elapsed * 1e3 / K,
                 "all_ms_per_step": [t * 1e3 / K for t in times], "roofline": step_roofline},
         }
+        if closed_loop:
+            result["closed_loop"] = closed_loop
         if exchange:
             result["exchange"] = exchange
         if world == 1:

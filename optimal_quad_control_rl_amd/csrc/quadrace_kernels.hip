@@ -317,8 +317,13 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
     float o[L];
     observe<V, GA>(P, gates, e, o);
     for (int k = 0; k < K; ++k) {
+#ifdef QR_PHASE_TIMING
+        P.tick_on = (k == K / 2);
+#endif
+        QR_TICK(P, 8);
         float mean[4];
         policy_forward<L>(W, lane, o, mean);
+        QR_TICK(P, 9);
         float a[4] = {mean[0], mean[1], mean[2], mean[3]};
         float logp = A.logp_const;
         if (!A.deterministic) {
@@ -340,6 +345,7 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
                 logp = fmaf(-0.5f * eps[c], eps[c], logp);
             }
         }
+        QR_TICK(P, 10);
         // rollout buffer row t: the observation the action was computed from, the unclipped action, its log-prob
         if (full_wave) store_obs_coalesced<V, GA>(tile, obs_out + (size_t)k * n * L, (size_t)wave_first, lane, o);
         else if (active) store_obs<V, GA>(obs_out + (size_t)k * n * L, i, o);
@@ -347,6 +353,7 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
             act_out[(size_t)k * n + i] = make_float4(a[0], a[1], a[2], a[3]);
             logp_out[(size_t)k * n + i] = logp;
         }
+        QR_TICK(P, 11);
         const float u[4] = {fminf(fmaxf(a[0], -1.0f), 1.0f), fminf(fmaxf(a[1], -1.0f), 1.0f),
                             fminf(fmaxf(a[2], -1.0f), 1.0f), fminf(fmaxf(a[3], -1.0f), 1.0f)};
         bool done, trunc, did_reset;
@@ -358,7 +365,9 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
             done_out[(size_t)k * n + i] = done ? 1 : 0;
             if (trunc_out) trunc_out[(size_t)k * n + i] = trunc ? 1 : 0;
         }
+        QR_TICK(P, 12);
         observe<V, GA>(P, gates, e, o);
+        QR_TICK(P, 13);
     }
     if (last_obs_out) {
         if (full_wave) store_obs_coalesced<V, GA>(tile, last_obs_out, (size_t)wave_first, lane, o);

@@ -50,30 +50,58 @@ __device__ __forceinline__ void swap32(float a, float b, float& lo, float& hi) {
 }
 
 // relu + f16 pack of accumulator registers 8s..8s+7 -> B operand of the next layer's K-step
+// (convert first, then one packed f16 max per two values: v_cvt_pk_f16_f32 + v_pk_max_f16 = 1 instruction per
+// element instead of 2.5 for an f32 fmaxf, which also canonicalises its input)
 __device__ __forceinline__ half8 relu_pack(const f32x16p& acc, int s) {
     half8 b;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) b[j] = (_Float16)fmaxf(acc[8 * s + j], 0.0f);
-    return b;
+    for (int j = 0; j < 8; ++j) b[j] = (_Float16)acc[8 * s + j];
+    const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_elementwise_max(b, zero);
 }
 
-// One hidden layer: in[et][8] (B operands of the 8 K-steps) -> out[et][8].  W = this layer's A operands in LDS.
-__device__ __forceinline__ void policy_hidden_layer(const half8* __restrict__ W, int lane, const half8 (&in)[2][8],
-                                                    half8 (&out)[2][8]) {
+// One layer with KS K-steps per 32-row output tile: in[et][KS] -> out[et][8].  W = this layer's A operands in LDS.
+// Software-pipelined by output tile: the 2*KS MFMAs of tile t are issued interleaved with the ReLU/f16 pack of tile
+// t-1 (the wave issues in order, so VALU work only overlaps the matrix pipe when it sits BETWEEN the MFMAs in program
+// order; sched_group_barrier pins that interleave: 2 MFMA, then up to 8 VALU, repeat).
+template <int KS>
+__device__ __forceinline__ void policy_layer(const half8* __restrict__ W, int lane, const half8 (&in)[2][KS],
+                                             half8 (&out)[2][8]) {
+    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    f32x16p acc[2][2];  // [tile parity][env tile]
+    half8 a[2][KS];     // [tile parity][K-step]: A operands, fetched one tile ahead of their MFMAs
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        f32x16p acc0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        f32x16p acc1 = acc0;
+    for (int s = 0; s < KS; ++s) a[0][s] = W[s * 64 + lane];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const half8 a = W[(t * 8 + s) * 64 + lane];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, in[0][s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, in[1][s], acc1, 0, 0, 0);
+    for (int t = 0; t <= 4; ++t) {
+        if (t < 3) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a[(t + 1) & 1][s] = W[((t + 1) * KS + s) * 64 + lane];
         }
-        out[0][2 * t] = relu_pack(acc0, 0);
-        out[0][2 * t + 1] = relu_pack(acc0, 1);
-        out[1][2 * t] = relu_pack(acc1, 0);
-        out[1][2 * t + 1] = relu_pack(acc1, 1);
+        if (t < 4) {
+            acc[t & 1][0] = zero;
+            acc[t & 1][1] = zero;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc[t & 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t & 1][s], in[0][s], acc[t & 1][0], 0, 0, 0);
+                acc[t & 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t & 1][s], in[1][s], acc[t & 1][1], 0, 0, 0);
+            }
+        }
+        if (t > 0) {
+            const int p = (t - 1) & 1;
+            out[0][2 * (t - 1)] = relu_pack(acc[p][0], 0);
+            out[0][2 * (t - 1) + 1] = relu_pack(acc[p][0], 1);
+            out[1][2 * (t - 1)] = relu_pack(acc[p][1], 0);
+            out[1][2 * (t - 1) + 1] = relu_pack(acc[p][1], 1);
+        }
+        if (t < 4) {
+#pragma unroll
+            for (int g = 0; g < KS; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                    // 2 MFMA
+                if (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // 1 LDS read of the next tile's A
+                if (t > 0) __builtin_amdgcn_sched_group_barrier(0x002, 64 / KS, 0);   // a share of the previous tile's pack
+            }
+        }
     }
 }
 
@@ -98,23 +126,9 @@ __device__ __forceinline__ void policy_forward(const half8* __restrict__ Wlds, i
         }
     }
     half8 h1[2][8], h2[2][8];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        f32x16p acc0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        f32x16p acc1 = acc0;
-#pragma unroll
-        for (int s = 0; s < D::kSteps1; ++s) {
-            const half8 a = Wlds[(t * D::kSteps1 + s) * 64 + lane];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, in1[0][s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, in1[1][s], acc1, 0, 0, 0);
-        }
-        h1[0][2 * t] = relu_pack(acc0, 0);
-        h1[0][2 * t + 1] = relu_pack(acc0, 1);
-        h1[1][2 * t] = relu_pack(acc1, 0);
-        h1[1][2 * t + 1] = relu_pack(acc1, 1);
-    }
-    policy_hidden_layer(Wlds + D::kOff2, lane, h1, h2);
-    policy_hidden_layer(Wlds + D::kOff3, lane, h2, h1);
+    policy_layer<D::kSteps1>(Wlds, lane, in1, h1);
+    policy_layer<8>(Wlds + D::kOff2, lane, h1, h2);
+    policy_layer<8>(Wlds + D::kOff3, lane, h2, h1);
     // ---- output layer: one 32-row tile, rows 0..3 = action means
     f32x16p acc0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     f32x16p acc1 = acc0;

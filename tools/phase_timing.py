@@ -64,3 +64,21 @@ for s in range(3, 8):
     d = np.median(t[:, :, s] - t[:, :, s - 1])
     print(f"  {s} {names[s]:24s} delta {d:8.0f} cycles")
 print(f"  per-step in-wave total {np.median(t[:, :, 7] - t[:, :, 2]):8.0f} cycles (instrumented: queues drained at every stamp)")
+
+# closed-loop rollout kernel: one instrumented iteration, slots 8..13
+from optimal_quad_control_rl_amd.policy import MfmaPolicy
+from optimal_quad_control_rl_amd.ppo import ActorCritic
+net = ActorCritic(env.state_len, 4).cuda()
+pol = MfmaPolicy(env.state_len).load_torch(net.pi)
+ticks.zero_()
+reps = []
+for r in range(8):
+    env.rollout_policy_device(pol, 32, torch.zeros(4), noise_seed=1, first_step=32 * r)
+    torch.cuda.synchronize()
+    reps.append(ticks.cpu().numpy().copy())
+t = np.stack(reps)[2:]
+cl = ["", "policy forward", "sampling", "obs/act/logp stores", "env step (+small stores)", "observe"]
+print("closed-loop rollout kernel, one step:")
+for s_ in range(9, 14):
+    print(f"  {cl[s_ - 8]:26s} delta {np.median(t[:, :, s_] - t[:, :, s_ - 1]):8.0f} cycles")
+print(f"  per-step in-wave total {np.median(t[:, :, 13] - t[:, :, 8]):8.0f} cycles")

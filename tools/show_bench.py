@@ -17,6 +17,9 @@ for path in sys.argv[1:]:
         pr = ps["roofline"]
         line += (f" | per-step: {ps['ms_per_step']*1e3:5.2f} us/step {ps['value']/1e9:6.2f} G/s kernel {pr['kernel_us']:5.2f} us"
                  f" frac {pr['frac']:.3f} traffic {pr['traffic']}")
+    if "closed_loop" in d and "value" in d["closed_loop"]:
+        c = d["closed_loop"]
+        line += f" | closed-loop: {c['ms_per_step']*1e3:5.2f} us/step {c['value']/1e9:5.2f} G/s"
     if "parity" in d:
         line += f" | parity {d['parity'].get('max_rel_dstate_100_steps')}"
     if "cpu_baseline" in d:
