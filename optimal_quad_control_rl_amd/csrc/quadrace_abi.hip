@@ -70,6 +70,14 @@ int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+}  // namespace
+
+namespace qr {
+// shared with quadrace_policy.hip: one thread-local error string behind qr_last_error()
+int set_last_error(int code, const std::string& msg) { return fail(code, msg); }
+}  // namespace qr
+
+namespace {
 
 #define QR_HIP(expr)                                                                              \
     do {                                                                                          \

@@ -89,9 +89,11 @@ struct qr_policy {
     bool has_weights = false;
 };
 
+namespace qr {
+int set_last_error(int code, const std::string& msg);  // quadrace_abi.hip
+}
 namespace {
-thread_local std::string g_perr;
-int pfail(int code, const std::string& m) { g_perr = m; return code; }
+int pfail(int code, const std::string& m) { return qr::set_last_error(code, m); }
 inline int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 }  // namespace
 
@@ -103,7 +105,7 @@ int policy_device(const qr_policy* p) { return p ? p->device : -1; }
 
 extern "C" {
 
-const char* qr_policy_last_error(void) { return g_perr.c_str(); }
+const char* qr_policy_last_error(void) { return qr_last_error(); }  // same thread-local message as the env calls
 
 int qr_policy_create(int32_t obs_len, int32_t device, qr_policy** out) {
     if (!out) return pfail(QR_E_INVALID, "qr_policy_create: null output");
