@@ -57,7 +57,20 @@ __device__ __forceinline__ half8 relu_pack(const f32x16p& acc, int s) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) b[j] = (_Float16)acc[8 * s + j];
     const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    return __builtin_elementwise_max(b, zero);
+    const _Float16 m = (_Float16)65504.0f;  // saturate instead of overflowing to inf (inf * 0 = NaN downstream)
+    const half8 top = {m, m, m, m, m, m, m, m};
+    return __builtin_elementwise_min(__builtin_elementwise_max(b, zero), top);
+}
+
+// f32 -> f16 with saturation to the finite range; NaN becomes 0 (maxnum/minnum drop the NaN operand)
+__device__ __forceinline__ half8 sat_pack(const float* v) {
+    half8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (_Float16)v[j];
+    const _Float16 m = (_Float16)65504.0f;
+    const half8 top = {m, m, m, m, m, m, m, m};
+    const half8 bot = {-m, -m, -m, -m, -m, -m, -m, -m};
+    return __builtin_elementwise_min(__builtin_elementwise_max(b, bot), top);
 }
 
 // One layer with KS K-steps per 32-row output tile: in[et][KS] -> out[et][8].  W = this layer's A operands in LDS.
@@ -114,16 +127,16 @@ __device__ __forceinline__ void policy_forward(const half8* __restrict__ Wlds, i
     half8 in1[2][D::kSteps1];
 #pragma unroll
     for (int s = 0; s < D::kSteps1; ++s) {
+        float t0[8], t1[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k0 = 16 * s + j, k1 = 16 * s + 8 + j;
             const float x0 = (k0 < L) ? o[k0 < L ? k0 : 0] : (k0 == L ? 1.0f : 0.0f);
             const float x1 = (k1 < L) ? o[k1 < L ? k1 : 0] : (k1 == L ? 1.0f : 0.0f);
-            float lo, hi;
-            swap32(x0, x1, lo, hi);
-            in1[0][s][j] = (_Float16)lo;
-            in1[1][s][j] = (_Float16)hi;
+            swap32(x0, x1, t0[j], t1[j]);
         }
+        in1[0][s] = sat_pack(t0);  // observations can be large (rates up to 1000 rad/s) or NaN: keep f16 finite
+        in1[1][s] = sat_pack(t1);
     }
     half8 h1[2][8], h2[2][8];
     policy_layer<D::kSteps1>(Wlds, lane, in1, h1);

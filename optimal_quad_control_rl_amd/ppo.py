@@ -254,8 +254,28 @@ class PPO:
         self.stats["loss"] = float(losses) / max(1, n_mb * self.n_epochs)
         self.stats["updates"] = self.stats.get("updates", 0) + n_mb * self.n_epochs
 
+    @torch.no_grad()
+    def _sanitise_buffers(self):
+        """An env whose state went NaN lives until max_steps (reference behaviour); its rows must not
+        poison a minibatch: zero them (their advantage is zeroed in train())."""
+        bad = ~(torch.isfinite(self.buf_obs).all(-1) & torch.isfinite(self.buf_act).all(-1) &
+                torch.isfinite(self.buf_lp) & torch.isfinite(self.buf_rew) & torch.isfinite(self.buf_val))
+        self._bad = bad
+        self.stats["non_finite_rows"] = int(bad.sum())
+        if self.stats["non_finite_rows"]:
+            self.buf_obs[bad] = 0.0
+            self.buf_act[bad] = 0.0
+            self.buf_lp[bad] = 0.0
+            self.buf_rew[bad] = 0.0
+            self.buf_val[bad] = 0.0
+            self.last_val = torch.nan_to_num(self.last_val)
+
     def train(self):
+        self._sanitise_buffers()
         adv, ret = self._gae()
+        if self.stats["non_finite_rows"]:
+            adv = adv.masked_fill(self._bad, 0.0)
+            ret = torch.where(self._bad, self.buf_val, ret)
         B = self.n_steps * self.n_envs
         obs = self.buf_obs.view(B, -1)
         act = self.buf_act.view(B, 4)

@@ -321,3 +321,51 @@ def test_ppo_consumes_device_tensors_and_improves():
     assert last["reward_per_step"] > first["reward_per_step"]
     a = model.predict(env.states_tensor)
     assert a.shape == (8192, 4) and float(a.abs().max()) <= 1.0
+
+
+@pytest.mark.parametrize("variant", [E2E, INDI])
+def test_limits_setters_vs_oracle(PA, OA, variant, residual_blob):
+    """env.dt / env.max_steps writes (I:648) reach the kernels: compare against the oracle with the same limits."""
+    n = 512
+    g, o = _pair(PA, OA, variant, n, "square", 1, residual_blob, seed=21)
+    g.env.dt = 0.004
+    g.env.max_steps = 5
+    o.env.set_limits(5, 0.004)
+    g.reset(); o.reset()
+    rng = np.random.default_rng(3)
+    total_done = 0
+    for k in range(6):
+        a = rng.uniform(-1, 1, size=(n, 4)).astype(np.float32)
+        og, rg, dng, trg = g.step(a)
+        oo, ro, dno, tro = o.step(a)
+        np.testing.assert_array_equal(dng, dno)
+        np.testing.assert_array_equal(trg, tro)
+        assert P.obs_err(og, oo).max() < 4 * P.TOL_STEP_OBS
+        total_done += int(dno.sum())
+    assert total_done == n and float(g.env.dt) == np.float32(0.004) and g.env.max_steps == 5
+
+
+def test_non_finite_actions_do_not_crash_and_stay_contained():
+    """A NaN action poisons only its own env (no cross-lane effects through the wave-wide MLP / reset paths), and the
+    reference's behaviour is kept: NaN comparisons are False, so the env lives until max_steps."""
+    from optimal_quad_control_rl_amd import Quadcopter3DGates, zigzag_track
+
+    n = 256
+    env = Quadcopter3DGates(n, *zigzag_track(), gates_ahead=1, seed=2, infos_mode="none")
+    ref = Quadcopter3DGates(n, *zigzag_track(), gates_ahead=1, seed=2, infos_mode="none")
+    env.max_steps = 12
+    ref.max_steps = 12
+    env.reset_device(); ref.reset_device()
+    a = torch.full((n, 4), 0.1, device="cuda")
+    bad = a.clone()
+    bad[37] = float("nan")
+    for k in range(12):
+        o1, r1, d1, t1 = env.step_device(bad)
+        o2, r2, d2, t2 = ref.step_device(a)
+        keep = torch.ones(n, dtype=torch.bool, device="cuda")
+        keep[37] = False
+        assert torch.equal(o1[keep], o2[keep]) and torch.equal(r1[keep], r2[keep]) and torch.equal(d1[keep], d2[keep])
+        if k < 11:
+            assert not bool(d1[37]) and torch.isnan(o1[37]).any()
+    assert bool(d1[37]) and bool(t1[37])  # ended by the time limit, then reset to a finite state
+    assert torch.isfinite(o1[37]).all()
