@@ -67,7 +67,7 @@ class PPO:
     def __init__(self, env, n_steps=32, batch_size=None, n_epochs=5, gamma=0.999, gae_lambda=0.95, clip_range=0.2,
                  learning_rate=3e-4, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, net_arch=(120, 120, 120),
                  log_std_init=0.0, seed=0, target_kl=None, lr_final_frac=1.0, total_timesteps_hint=None,
-                 fused_collect=False, graph_update=False):
+                 fused_collect=False):
         self.env = env
         self.n_envs, self.dev = env.num_envs, env.device
         self.n_steps, self.n_epochs = n_steps, n_epochs
@@ -78,15 +78,7 @@ class PPO:
         torch.manual_seed(seed)
         obs_dim = env.state_len
         self.policy = ActorCritic(obs_dim, 4, net_arch, log_std_init).to(self.dev)
-        # graph_update: the whole minibatch update (gathers, losses, backward, grad clipping, Adam) is captured once
-        # into a HIP graph and replayed -- with thousands of envs the update is launch-bound, not FLOP-bound.
-        self.graph_update = graph_update
-        self._graph = None
-        if graph_update:
-            self.opt = torch.optim.Adam(self.policy.parameters(), lr=torch.tensor(learning_rate, device=self.dev),
-                                        eps=1e-5, capturable=True)
-        else:
-            self.opt = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
         T, N = n_steps, self.n_envs
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.buf_obs = torch.empty((T, N, obs_dim), **f32)
@@ -196,64 +188,6 @@ class PPO:
             next_val = self.buf_val[t]
         return adv, adv + self.buf_val
 
-    def _minibatch_loss(self, obs, act, old_lp, a, ret):
-        a = (a - a.mean()) / (a.std() + 1e-8)
-        lp, ent = self.policy.log_prob_entropy(obs, act)
-        ratio = (lp - old_lp).exp()
-        pg = -torch.min(a * ratio, a * ratio.clamp(1 - self.clip, 1 + self.clip)).mean()
-        vl = torch.nn.functional.mse_loss(self.policy.value(obs), ret)
-        return pg + self.vf_coef * vl - self.ent_coef * ent.mean()
-
-    def _graph_step(self):
-        g = self._g
-        loss = self._minibatch_loss(g["src_obs"].index_select(0, g["idx"]), g["src_act"].index_select(0, g["idx"]),
-                                    g["src_lp"].index_select(0, g["idx"]), g["src_adv"].index_select(0, g["idx"]),
-                                    g["src_ret"].index_select(0, g["idx"]))
-        loss.backward()
-        nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
-        self.opt.step()
-        g["loss"].copy_(loss.detach())
-
-    def _build_graph(self, obs, act, old_lp):
-        B = obs.shape[0]
-        f32 = dict(dtype=torch.float32, device=self.dev)
-        self._g = dict(idx=torch.zeros(self.batch_size, dtype=torch.int64, device=self.dev), src_obs=obs, src_act=act,
-                       src_lp=old_lp, src_adv=torch.zeros(B, **f32), src_ret=torch.zeros(B, **f32),
-                       loss=torch.zeros((), **f32))
-        state = {k: v.clone() for k, v in self.policy.state_dict().items()}
-        opt_state = self.opt.state_dict()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # warm-up iterations outside capture (allocations, lazy init)
-            for _ in range(3):
-                self.opt.zero_grad(set_to_none=True)
-                self._graph_step()
-        torch.cuda.current_stream().wait_stream(side)
-        self.policy.load_state_dict(state)  # undo the warm-up updates
-        self.opt.load_state_dict(opt_state)
-        self.opt.zero_grad(set_to_none=True)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._graph_step()
-
-    def _train_graph(self, obs, act, old_lp, adv, ret):
-        B = obs.shape[0]
-        if self._graph is None:
-            self._build_graph(obs, act, old_lp)
-        g = self._g
-        g["src_adv"].copy_(adv)
-        g["src_ret"].copy_(ret)
-        n_mb = B // self.batch_size
-        losses = torch.zeros((), dtype=torch.float32, device=self.dev)
-        for _ in range(self.n_epochs):
-            perm = torch.randperm(B, device=self.dev)
-            for m in range(n_mb):
-                g["idx"].copy_(perm[m * self.batch_size:(m + 1) * self.batch_size])
-                self._graph.replay()
-                losses += g["loss"]
-        self.stats["loss"] = float(losses) / max(1, n_mb * self.n_epochs)
-        self.stats["updates"] = self.stats.get("updates", 0) + n_mb * self.n_epochs
-
     @torch.no_grad()
     def _sanitise_buffers(self):
         """An env whose state went NaN lives until max_steps (reference behaviour); its rows must not
@@ -284,15 +218,7 @@ class PPO:
         if self.total_hint:  # linear learning-rate decay (SB3: learning_rate may be a schedule)
             frac = min(1.0, self.num_timesteps / float(self.total_hint))
             for g in self.opt.param_groups:
-                lr = self.lr0 * (1.0 - (1.0 - self.lr_final_frac) * frac)
-                if isinstance(g["lr"], torch.Tensor):
-                    g["lr"].fill_(lr)
-                else:
-                    g["lr"] = lr
-        if self.graph_update:
-            self._train_graph(obs, act, old_lp, adv, ret)
-            self.stats["std"] = float(self.policy.log_std.detach().exp().mean())
-            return
+                g["lr"] = self.lr0 * (1.0 - (1.0 - self.lr_final_frac) * frac)
         stop = False
         for _ in range(self.n_epochs):
             if stop:
