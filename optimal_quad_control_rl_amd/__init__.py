@@ -7,7 +7,7 @@ for gfx950 behind a C ABI (include/quadrace.h -> libquadrace.so); this package i
 from .tracks import TRAIN_DISTURBANCE_RANGES, square_track, zigzag_track  # noqa: F401
 
 __all__ = ["Quadcopter3DGates", "Quadcopter3DGatesINDI", "zigzag_track", "square_track", "TRAIN_DISTURBANCE_RANGES",
-           "default_residual_blob", "ShardedRaceEnv"]
+           "default_residual_blob", "ShardedRaceEnv", "Quadcopter3DVec", "Quadcopter3DVecGates"]
 
 
 def __getattr__(name):  # lazy: importing the package must not require torch / a GPU
@@ -15,6 +15,10 @@ def __getattr__(name):  # lazy: importing the package must not require torch / a
         from . import vec_env
 
         return getattr(vec_env, name)
+    if name in ("Quadcopter3DVec", "Quadcopter3DVecGates"):  # predecessor envs of "3D quad.ipynb"
+        from . import quad3d
+
+        return getattr(quad3d, name)
     if name == "ShardedRaceEnv":
         from . import sharded
 

@@ -22,7 +22,7 @@ class QrConfig(C.Structure):
                 ("pause_if_collision", C.c_int32), ("reserved0", C.c_int32), ("env_id_base", C.c_uint64)]
 
 
-# name -> (restype, argtypes); must list every symbol of include/quadrace.h
+# name -> (restype, argtypes); must list every symbol of include/quadrace.h and include/quad3d.h
 SIGNATURES = {
     "qr_abi_version": (C.c_int, []),
     "qr_last_error": (C.c_char_p, []),
@@ -54,6 +54,20 @@ SIGNATURES = {
     "qr_rollout_policy": (C.c_int, [_vp, _vp, C.c_int32, _f32p, C.c_uint64, C.c_uint64, C.c_int32, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp]),
     "qr_profile_steps": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _f32p, _f32p]),
+    # include/quad3d.h (predecessor environments of "3D quad.ipynb")
+    "q3_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
+    "q3_destroy": (C.c_int, [_vp]),
+    "q3_num_envs": (C.c_int, [_vp]),
+    "q3_elem_size": (C.c_int, [_vp]),
+    "q3_set_track": (C.c_int, [_vp, _f32p, _f32p, C.c_int32, _f32p]),
+    "q3_set_limits": (C.c_int, [_vp, C.c_int32, C.c_double]),
+    "q3_set_thresholds": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "q3_seed": (C.c_int, [_vp, C.c_uint64]),
+    "q3_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "q3_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "q3_step_many": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
+    "q3_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "q3_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
 }
 
 

@@ -13,8 +13,9 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libquadrace.so")
-SOURCES = ["quadrace_kernels.hip", "quadrace_abi.hip", "quadrace_policy.hip"]
-HEADERS = ["quadrace_device.hpp", "quadrace_policy.hpp", os.path.join("..", "..", "include", "quadrace.h")]
+SOURCES = ["quadrace_kernels.hip", "quadrace_abi.hip", "quadrace_policy.hip", "quad3d.hip"]
+HEADERS = ["quadrace_device.hpp", "quadrace_policy.hpp", os.path.join("..", "..", "include", "quadrace.h"),
+           os.path.join("..", "..", "include", "quad3d.h")]
 # -ffp-contract=off: FMAs are written explicitly (fmaf) in the kernels, so the arithmetic is fixed by the source and
 # the per-step kernel and the fused rollout kernel produce bit-identical trajectories.
 # -amdgpu-mfma-vgpr-form: keep the MFMA accumulators of the residual MLP in VGPRs (gfx950 has a unified register file),
@@ -30,18 +31,43 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libquadrace.so cannot be built")
 
 
+OBJ_DIR = os.path.join(PKG, "_obj")   # per-source objects (git- and gpurun-ignored): only stale sources are recompiled
+
+
+def _deps(src):
+    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+
+
+def _obj(src, extra_flags=()):
+    tag = ("_" + "_".join(f.lstrip("-") for f in extra_flags)) if extra_flags else ""
+    return os.path.join(OBJ_DIR, os.path.splitext(src)[0] + tag.replace("=", "-").replace("/", "-") + ".o")
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for s in SOURCES for d in _deps(s))
 
 
 def build_native(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), *FLAGS, *extra_flags, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    compile_flags = [f for f in FLAGS if f != "-shared"]
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = _obj(src, extra_flags)
+        objs.append(obj)
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src)):
+            cmd = [_hipcc(), *compile_flags, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))   # sources compile concurrently
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

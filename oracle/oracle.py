@@ -23,8 +23,8 @@ _u8p = C.POINTER(C.c_uint8)
 
 def build(force=False):
     """Compile the oracle (and oracle/_ref when /root/reference is mounted)."""
-    src = os.path.join(_HERE, "quadrace_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("quadrace_oracle.c", "quad3d_oracle.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libquadrace_oracle.so"], stdout=subprocess.DEVNULL)
     if force or not os.path.exists(_REF_LIB_PATH):
         subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)

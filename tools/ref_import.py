@@ -119,3 +119,24 @@ def load_indi():
     finally:
         os.chdir(cwd)
     return ns
+
+
+Q3_NB = "3D quad.ipynb"
+
+
+def load_q3():
+    """Namespace with the predecessor notebook's f_func, Quadcopter3DVec (hover) and Quadcopter3DVecGates."""
+    import torch
+
+    _install_stubs()
+    ns = {"np": np, "torch": torch, "__name__": "ref_q3"}
+    cwd = os.getcwd()
+    os.chdir(REF_ROOT)
+    try:
+        import contextlib, io
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            _exec_cells(Q3_NB, (2, 6, 14), ns)
+    finally:
+        os.chdir(cwd)
+    return ns
