@@ -333,6 +333,13 @@ def main():
                 except Exception as ex:  # pragma: no cover
                     result["host_numpy_path"] = {"error": repr(ex)}
                 result["cpu_baseline"] = cpu_baseline(args.variant, n, ga, args.cpu_seconds)
+                try:  # the predecessor envs of "3D quad.ipynb" (include/quad3d.h), short measurement
+                    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                    from bench_quad3d import measure as q3_measure
+
+                    result["predecessor_envs"] = {k: q3_measure(k, n, 200, repeats=3, cpu_seconds=2.0) for k in ("hover", "gates")}
+                except Exception as ex:  # pragma: no cover
+                    result["predecessor_envs"] = {"error": repr(ex)}
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

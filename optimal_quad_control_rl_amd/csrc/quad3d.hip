@@ -170,7 +170,7 @@ __device__ __forceinline__ void q3_normal_pair(uint32_t a, uint32_t b, float& z0
     cp = cp * z + -1.388731625493765e-3f;
     cp = cp * z + 4.166664568298827e-2f;
     const float cs = 1.0f - 0.5f * z + z * z * cp;
-    const float rad = __fsqrt_rn(-2.0f * q3_log(u1));
+    const float rad = sqrtf(-2.0f * q3_log(u1));
     const float c = quad == 0 ? cs : (quad == 1 ? -sn : (quad == 2 ? -cs : sn));
     const float s = quad == 0 ? sn : (quad == 1 ? cs : (quad == 2 ? -sn : -cs));
     z0 = rad * c;
@@ -276,9 +276,9 @@ __device__ __forceinline__ float q3_step_env(const Q3Params& P, int i, Q3Env<flo
     const float gx = P.gate[g][0], gy = P.gate[g][1], gz = P.gate[g][2];
     const float ox = s[0] - gx, oy = s[1] - gy, oz = s[2] - gz;
     const float nx = ns[0] - gx, ny = ns[1] - gy, nz = ns[2] - gz;
-    const float d2g_old = __fsqrt_rn(ox * ox + oy * oy + oz * oz);
-    const float d2g_new = __fsqrt_rn(nx * nx + ny * ny + nz * nz);
-    const float rat_penalty = 0.0001f * __fsqrt_rn(ns[9] * ns[9] + ns[10] * ns[10] + ns[11] * ns[11]);
+    const float d2g_old = sqrtf(ox * ox + oy * oy + oz * oz);
+    const float d2g_new = sqrtf(nx * nx + ny * ny + nz * nz);
+    const float rat_penalty = 0.0001f * sqrtf(ns[9] * ns[9] + ns[10] * ns[10] + ns[11] * ns[11]);
     float reward = d2g_old - d2g_new - rat_penalty;
     const float n0 = P.gate_normal[g][0], n1 = P.gate_normal[g][1];
     const float proj_old = ox * n0 + oy * n1, proj_new = nx * n0 + ny * n1;

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Throughput of the predecessor environments (include/quad3d.h: Quadcopter3DVec hover f64, Quadcopter3DVecGates f32)
+on one MI355X: per-step launches and the fused K-step kernel, against the HBM roofline, with the CPU oracle timed
+beside them.  `python tools/bench_quad3d.py [--envs N] [--steps K]` prints one JSON line; bench.py embeds the same
+measurement (with fewer steps) as `predecessor_envs`.
+
+Algorithmic bytes per env-step (state read once / written once, action read once, outputs written once):
+  hover (float64): read 16*8 + steps 4 + action 16 = 148; write 16*8 + steps 4 + states_out 128 + reward 8 + done 1 = 269 -> 417 B
+  gates (float32): read 16*4 + target 4 + steps 4 + action 16 = 88; write 64 + 4 + 4 + states_out 64 + reward 4 + done 1 = 141 -> 229 B
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+BYTES = {"hover": 417, "gates": 229}
+Q3_TRACK = (np.array([[-1.5, -2, -1.5], [1.5, 2, -1.5], [1.5, -2, -1.5], [-1.5, 2, -1.5]] * 2, dtype=np.float64),
+            np.array([0, 0, np.pi, np.pi] * 2), np.array([-4, -2, -1.5]))     # Q3 cell 16
+
+
+def _time_region(fn, repeats):
+    ts = []
+    for _ in range(repeats):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e-3)
+    return float(np.median(ts))
+
+
+def measure(kind, n=65536, K=200, repeats=3, cpu_seconds=3.0):
+    from optimal_quad_control_rl_amd.quad3d import Quadcopter3DVec, Quadcopter3DVecGates
+
+    env = Quadcopter3DVec(n) if kind == "hover" else Quadcopter3DVecGates(n, *Q3_TRACK)
+    dev = env.device
+    gen = torch.Generator(device=dev).manual_seed(0)
+    acts = torch.rand((K, n, 4), device=dev, generator=gen) * 2 - 1
+    env.reset_device()
+    for k in range(min(K, 20)):
+        env.step_device(acts[k])
+
+    def per_step():
+        for k in range(K):
+            env.step_device(acts[k])
+
+    t_step = _time_region(per_step, repeats)
+    env.rollout_device(acts)
+    t_fused = _time_region(lambda: env.rollout_device(acts), repeats)
+    rew, done, _ = env.rollout_device(acts)
+    out = {"env": "Quadcopter3DVec (hover, f64)" if kind == "hover" else "Quadcopter3DVecGates (f32, 8-gate track of Q3 cell 16)",
+           "envs": n, "steps": K, "actions": "U(-1,1) pre-generated on device", "bytes_per_env_step": BYTES[kind],
+           "done_fraction": float(done.float().mean())}
+    for name, t in (("per_step_launch", t_step), ("fused_rollout", t_fused)):
+        gbs = BYTES[kind] * n * K / t / 1e9
+        out[name] = {"us_per_step": t / K * 1e6, "env_steps_per_s": n * K / t,
+                     "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": gbs / HBM_PEAK_GBS}}
+    if cpu_seconds > 0:
+        from oracle import quad3d as q3
+
+        m = 4096
+        o = q3.Quad3DOracle(q3.HOVER, m) if kind == "hover" else q3.Quad3DOracle(q3.GATES, m, *Q3_TRACK)
+        o.reset()
+        a = np.random.default_rng(0).uniform(-1, 1, (m, 4)).astype(np.float32)
+        cores = min(16, os.cpu_count() or 1)
+        res = {}
+        for threads in (1, cores):
+            o.set_threads(threads)
+            o.step(a)
+            t0, it = time.perf_counter(), 0
+            while time.perf_counter() - t0 < cpu_seconds / 2:
+                o.step(a)
+                it += 1
+            res[threads] = m * it / (time.perf_counter() - t0)
+        out["cpu_baseline"] = {"kind": "port", "what": "oracle/quad3d_oracle.c (OpenMP over envs)", "sample": f"{m} envs",
+                               "value": res[cores], "cores": cores, "single_thread": res[1], "unit": "env-steps/s"}
+    env.close()
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=65536)
+    ap.add_argument("--steps", type=int, default=1000)
+    args = ap.parse_args()
+    print(json.dumps({k: measure(k, args.envs, args.steps, repeats=5, cpu_seconds=6.0) for k in ("hover", "gates")}))
