@@ -172,6 +172,35 @@ int qr_rollout_policy(qr_env* env, qr_policy* policy, int32_t num_steps, const f
                       float* logp_out_dev, float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev,
                       float* last_obs_dev, void* stream);
 
+/* ---- PPO minibatch update on the matrix cores (replaces SB3's PPO.train inner loop, R:783-795 / R:820) -------------
+ * Networks: policy obs -> 120 -> 120 -> 120 -> 4 and value obs -> 120 -> 120 -> 120 -> 1 (ReLU), log_std[4].
+ * Parameters live in ONE flat float32 device vector owned by the caller (torch Linear layouts, w[out][in]):
+ *   [ pi: w1 b1 w2 b2 w3 b3 w4 b4 | vf: w1 b1 w2 b2 w3 b3 w4 b4 | log_std[4] ]        (qr_ppo_num_params floats)
+ * Loss (SB3): -mean(min(A r, A clip(r, 1-eps, 1+eps))) + vf_coef * mse(v, ret) - ent_coef * mean(entropy), with the
+ * advantages of the minibatch normalised to zero mean / unit (unbiased) std; gradients are clipped to max_grad_norm
+ * (global L2) and applied with Adam (torch.optim.Adam semantics).  Forward / backward GEMMs use f16 operands with f32
+ * accumulation; parameters, gradient accumulation and Adam are f32.
+ * Rollout rows (obs [rows][obs_len], act [rows][4], old_logp / adv / ret [rows]) are device arrays; idx_dev[B] selects
+ * the rows of this minibatch (B a multiple of 64, <= max_minibatch). */
+typedef struct qr_ppo qr_ppo;
+int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo** out);
+int qr_ppo_destroy(qr_ppo* ppo);
+int qr_ppo_num_params(const qr_ppo* ppo);
+/* builds the f16 operand images from the parameters: call once before the first qr_ppo_minibatch and after any
+ * change of theta made outside this library */
+int qr_ppo_pack(qr_ppo* ppo, const float* theta_dev, void* stream);
+/* gradient only (no clipping, no optimiser step): grad_out_dev [num_params]; stats_dev (may be NULL) float[4] is
+ * ACCUMULATED into: sum of per-sample surrogate losses, sum of squared value errors, sum of approx-KL terms, number
+ * of clipped samples */
+int qr_ppo_grad(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const float* act_dev,
+                const float* old_logp_dev, const float* adv_dev, const float* ret_dev, const int32_t* idx_dev, int32_t B,
+                float clip, float vf_coef, float ent_coef, float* grad_out_dev, float* stats_dev, void* stream);
+/* one complete minibatch update of theta (and the Adam moments); adam_step = 1, 2, ... counts updates */
+int qr_ppo_minibatch(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* adam_v_dev, const float* obs_dev,
+                     const float* act_dev, const float* old_logp_dev, const float* adv_dev, const float* ret_dev,
+                     const int32_t* idx_dev, int32_t B, float clip, float vf_coef, float ent_coef, float max_grad_norm,
+                     float lr, float beta1, float beta2, float eps, int32_t adam_step, float* stats_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,12 @@ SIGNATURES = {
     "qr_rollout_policy": (C.c_int, [_vp, _vp, C.c_int32, _f32p, C.c_uint64, C.c_uint64, C.c_int32, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp]),
     "qr_profile_steps": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _f32p, _f32p]),
+    "qr_ppo_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "qr_ppo_destroy": (C.c_int, [_vp]),
+    "qr_ppo_num_params": (C.c_int, [_vp]),
+    "qr_ppo_pack": (C.c_int, [_vp, _vp, _vp]),
+    "qr_ppo_grad": (C.c_int, [_vp] * 8 + [C.c_int32, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp]),
+    "qr_ppo_minibatch": (C.c_int, [_vp] * 10 + [C.c_int32] + [C.c_float] * 8 + [C.c_int32, _vp, _vp]),
     # include/quad3d.h (predecessor environments of "3D quad.ipynb")
     "q3_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
     "q3_destroy": (C.c_int, [_vp]),

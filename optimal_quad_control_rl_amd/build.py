@@ -13,7 +13,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libquadrace.so")
-SOURCES = ["quadrace_kernels.hip", "quadrace_abi.hip", "quadrace_policy.hip", "quad3d.hip"]
+SOURCES = ["quadrace_kernels.hip", "quadrace_abi.hip", "quadrace_policy.hip", "quadrace_ppo.hip", "quad3d.hip"]
 HEADERS = ["quadrace_device.hpp", "quadrace_policy.hpp", os.path.join("..", "..", "include", "quadrace.h"),
            os.path.join("..", "..", "include", "quad3d.h")]
 # -ffp-contract=off: FMAs are written explicitly (fmaf) in the kernels, so the arithmetic is fixed by the source and
@@ -31,6 +31,9 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libquadrace.so cannot be built")
 
 
+# quadrace_ppo.hip keeps far more matrix-core accumulators live than the env kernels: let the compiler use the AGPR half of
+# the register file for them (with the VGPR form it spills 3x as much)
+NO_VGPR_FORM = {"quadrace_ppo.hip"}
 OBJ_DIR = os.path.join(PKG, "_obj")   # per-source objects (git- and gpurun-ignored): only stale sources are recompiled
 
 
@@ -60,7 +63,8 @@ def build_native(force=False, verbose=False, extra_flags=()):
         obj = _obj(src, extra_flags)
         objs.append(obj)
         if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src)):
-            cmd = [_hipcc(), *compile_flags, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+            flags = [f for f in compile_flags if not (src in NO_VGPR_FORM and f in ("-mllvm", "-amdgpu-mfma-vgpr-form"))]
+            cmd = [_hipcc(), *flags, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((cmd, subprocess.Popen(cmd)))   # sources compile concurrently

@@ -63,11 +63,93 @@ class ActorCritic(nn.Module):
         return actions, lp, self.vf(obs).squeeze(-1)
 
 
+class MfmaPpoUpdater:
+    """PPO minibatch updates on the matrix cores (`qr_ppo_*`, csrc/quadrace_ppo.hip) for an `ActorCritic` with
+    net_arch (120, 120, 120).  The module's parameters are re-pointed at views of ONE flat float32 vector (the layout
+    the C ABI defines), so torch code that evaluates the networks keeps seeing the current weights."""
+
+    def __init__(self, policy, obs_len, device, max_minibatch, betas=(0.9, 0.999), eps=1e-5):
+        import ctypes as C
+
+        from . import _lib
+
+        self._C, self._lib = C, _lib
+        self._L = _lib.load()
+        self._h = None
+        self.device = device
+        h = C.c_void_p()
+        _lib.check(self._L.qr_ppo_create(int(obs_len), int(device.index or 0), int(max_minibatch), C.byref(h)))
+        self._h = h
+        n = self._L.qr_ppo_num_params(self._h)
+        self.theta = torch.zeros(n, dtype=torch.float32, device=device)
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        self.stats = torch.zeros(4, dtype=torch.float32, device=device)
+        self.betas, self.eps, self.step = betas, eps, 0
+        off = 0
+        params = []
+        for net in (policy.pi, policy.vf):
+            for lin in [m for m in net if isinstance(m, nn.Linear)]:
+                params += [lin.weight, lin.bias]
+        params.append(policy.log_std)
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.theta[off:off + k].copy_(p.data.reshape(-1))
+                p.data = self.theta[off:off + k].view(p.shape)
+                off += k
+        assert off == n, (off, n)
+        self.pack()
+
+    def close(self):
+        if self._h is not None:
+            self._L.qr_ppo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _p(self, t):
+        return self._C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def _stream(self):
+        return self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def pack(self):
+        """Rebuild the f16 operand images (after theta was changed by anything but `minibatch`)."""
+        self._lib.check(self._L.qr_ppo_pack(self._h, self._p(self.theta), self._stream()))
+
+    @staticmethod
+    def _check(obs, act, old_lp, adv, ret, idx):
+        for t in (obs, act, old_lp, adv, ret):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        assert idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()
+
+    def grad(self, obs, act, old_lp, adv, ret, idx, clip=0.2, vf_coef=0.5, ent_coef=0.0, stats=False):
+        """Flat gradient of the PPO loss on the rows `idx` (no clipping, no optimiser step)."""
+        self._check(obs, act, old_lp, adv, ret, idx)
+        g = torch.empty_like(self.theta)
+        self._lib.check(self._L.qr_ppo_grad(self._h, self._p(self.theta), self._p(obs), self._p(act), self._p(old_lp), self._p(adv),
+                                            self._p(ret), self._p(idx), int(idx.numel()), clip, vf_coef, ent_coef, self._p(g),
+                                            self._p(self.stats) if stats else None, self._stream()))
+        return g
+
+    def minibatch(self, obs, act, old_lp, adv, ret, idx, lr, clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5):
+        self.step += 1
+        self._lib.check(self._L.qr_ppo_minibatch(self._h, self._p(self.theta), self._p(self.m), self._p(self.v), self._p(obs),
+                                                 self._p(act), self._p(old_lp), self._p(adv), self._p(ret), self._p(idx),
+                                                 int(idx.numel()), clip, vf_coef, ent_coef, max_grad_norm, lr, self.betas[0],
+                                                 self.betas[1], self.eps, self.step, self._p(self.stats), self._stream()))
+
+
 class PPO:
     def __init__(self, env, n_steps=32, batch_size=None, n_epochs=5, gamma=0.999, gae_lambda=0.95, clip_range=0.2,
                  learning_rate=3e-4, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, net_arch=(120, 120, 120),
                  log_std_init=0.0, seed=0, target_kl=None, lr_final_frac=1.0, total_timesteps_hint=None,
-                 fused_collect=False):
+                 fused_collect=False, native_update=False):
         self.env = env
         self.n_envs, self.dev = env.num_envs, env.device
         self.n_steps, self.n_epochs = n_steps, n_epochs
@@ -98,6 +180,14 @@ class PPO:
         self.stats = {}
         # fused_collect: the whole collect phase is ONE kernel (qr_rollout_policy): MFMA policy (f16 operands) +
         # Gaussian sampling + env step; values (and nothing else) are evaluated by torch afterwards in one batch.
+        # native_update: every minibatch update (forward, loss, backward, grad-norm clip, Adam) runs in the hand-written
+        # matrix-core kernels of csrc/quadrace_ppo.hip instead of torch autograd + torch.optim.Adam
+        self.native_update = native_update
+        self._updater = None
+        if native_update:
+            assert tuple(net_arch) == (120, 120, 120), "the matrix-core update is built for the reference's 3 x 120 networks"
+            assert self.batch_size % 64 == 0 and (T * N) % self.batch_size == 0
+            self._updater = MfmaPpoUpdater(self.policy, obs_dim, self.dev, self.batch_size)
         self.fused_collect = fused_collect
         self.noise_seed = seed
         self._mfma = None
@@ -219,6 +309,8 @@ class PPO:
             frac = min(1.0, self.num_timesteps / float(self.total_hint))
             for g in self.opt.param_groups:
                 g["lr"] = self.lr0 * (1.0 - (1.0 - self.lr_final_frac) * frac)
+        if self.native_update:
+            return self._train_native(obs, act, old_lp.contiguous(), adv.contiguous(), ret.contiguous(), B)
         stop = False
         for _ in range(self.n_epochs):
             if stop:
@@ -249,6 +341,30 @@ class PPO:
         if losses:
             self.stats["loss"] = float(torch.stack(losses).mean())
         self.stats["updates"] = self.stats.get("updates", 0) + len(losses)
+        self.stats["std"] = float(self.policy.log_std.detach().exp().mean())
+
+    def _train_native(self, obs, act, old_lp, adv, ret, B):
+        up = self._updater
+        lr = self.opt.param_groups[0]["lr"]
+        n_updates = 0
+        up.stats.zero_()
+        for _ in range(self.n_epochs):
+            perm = torch.randperm(B, device=self.dev).to(torch.int32)
+            if self.target_kl is not None and self.target_kl < 1e8:
+                up.stats.zero_()
+            for s in range(0, B, self.batch_size):
+                up.minibatch(obs, act, old_lp, adv, ret, perm[s:s + self.batch_size], lr, self.clip, self.vf_coef, self.ent_coef,
+                             self.max_grad_norm)
+                n_updates += 1
+            if self.target_kl is not None and self.target_kl < 1e8:   # SB3 checks every minibatch; here once per epoch
+                if float(up.stats[2]) / B > 1.5 * self.target_kl:
+                    break
+        st = up.stats.tolist()
+        seen = max(1, n_updates * self.batch_size) if not (self.target_kl is not None and self.target_kl < 1e8) else B
+        self.stats["loss"] = (st[0] + self.vf_coef * st[1]) / seen
+        self.stats["approx_kl"] = st[2] / seen
+        self.stats["clip_fraction"] = st[3] / seen
+        self.stats["updates"] = self.stats.get("updates", 0) + n_updates
         self.stats["std"] = float(self.policy.log_std.detach().exp().mean())
 
     def learn(self, total_timesteps, log_every=10, callback=None):

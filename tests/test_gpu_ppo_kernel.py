@@ -1,0 +1,157 @@
+"""GPU: the matrix-core PPO update (qr_ppo_*, csrc/quadrace_ppo.hip) against torch autograd / torch.optim.Adam on the
+same minibatch.  Forward and backward GEMMs use f16 operands (f32 accumulation), so gradients agree to the f16 operand
+level (a few 1e-3 relative per tensor); the optimiser arithmetic is f32 and is compared tightly."""
+import copy
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(L, rows, seed=0, scale_w=1.0):
+    from optimal_quad_control_rl_amd.ppo import ActorCritic, MfmaPpoUpdater
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(seed)
+    pol = ActorCritic(L, 4).to(dev)
+    with torch.no_grad():   # non-trivial biases / output layer / log_std so every gradient path is exercised
+        for p in pol.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+        pol.pi[-1].weight.mul_(30.0)
+        pol.log_std.copy_(torch.tensor([-0.3, 0.1, -0.5, 0.2], device=dev))
+    ref = copy.deepcopy(pol)
+    up = MfmaPpoUpdater(pol, L, dev, max_minibatch=4096)
+    g = torch.Generator(device=dev).manual_seed(seed + 1)
+    obs = torch.randn((rows, L), device=dev, generator=g) * 1.5
+    with torch.no_grad():
+        mean = ref.pi(obs)
+        act = mean + ref.log_std.exp() * torch.randn((rows, 4), device=dev, generator=g)
+        lp_now, _ = ref.log_prob_entropy(obs, act)
+        old_lp = lp_now + 0.15 * torch.randn(rows, device=dev, generator=g)     # ratios around 1, some clipped
+        adv = torch.randn(rows, device=dev, generator=g) * 2.0 + 0.3
+        ret = ref.value(obs) + torch.randn(rows, device=dev, generator=g) * 3.0
+    return pol, ref, up, obs.contiguous(), act.contiguous(), old_lp.contiguous(), adv.contiguous(), ret.contiguous()
+
+
+def _f16_operands(net, x):
+    """The network with every GEMM operand (activations, weights, biases) rounded to f16 and f32 accumulation -- what the
+    matrix-core kernels compute.  `.half().float()` is a straight-through rounding for autograd."""
+    q = lambda t: t + (t.half().float() - t).detach()
+    for m in net:
+        x = torch.nn.functional.linear(q(x), q(m.weight), q(m.bias)) if isinstance(m, torch.nn.Linear) else m(x)
+    return x
+
+
+def _torch_loss(ref, obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef, f16_operands=False):
+    i = idx.long()
+    a = adv[i]
+    a = (a - a.mean()) / (a.std() + 1e-8)
+    if f16_operands:
+        mean, v = _f16_operands(ref.pi, obs[i]), _f16_operands(ref.vf, obs[i]).squeeze(-1)
+        lp = (-0.5 * ((act[i] - mean) / ref.log_std.exp()) ** 2 - ref.log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+        ent = (0.5 + 0.5 * math.log(2 * math.pi) + ref.log_std).sum().expand(i.shape[0])
+    else:
+        lp, ent = ref.log_prob_entropy(obs[i], act[i])
+        v = ref.value(obs[i])
+    ratio = (lp - old_lp[i]).exp()
+    pg = -torch.min(a * ratio, a * ratio.clamp(1 - clip, 1 + clip)).mean()
+    vl = torch.nn.functional.mse_loss(v, ret[i])
+    return pg + vf_coef * vl - ent_coef * ent.mean(), pg, vl, ratio
+
+
+def _flat_ref_grads(ref):
+    out = []
+    for net in (ref.pi, ref.vf):
+        for lin in [m for m in net if isinstance(m, torch.nn.Linear)]:
+            out += [lin.weight.grad.reshape(-1), lin.bias.grad.reshape(-1)]
+    out.append(ref.log_std.grad.reshape(-1))
+    return out
+
+
+@pytest.mark.parametrize("L,B,clip", [(17, 1024, 0.2), (17, 1024, 50.0), (24, 512, 0.2), (36, 256, 50.0), (13, 64, 0.2)])
+def test_gradient_matches_autograd(L, B, clip):
+    """Two references: (1) autograd through the same networks with f16-rounded GEMM operands -- what the kernels compute,
+    so the comparison is tight; (2) plain f32 autograd -- there the f16 forward flips the ReLU state of units whose
+    pre-activation is ~0 and (with clip = 0.2) the branch of ratios on the clip edge, a few-percent unbiased difference.
+    clip = 50 switches the clipping off."""
+    rows = 3000
+    pol, ref, up, obs, act, old_lp, adv, ret = _setup(L, rows, seed=L)
+    idx = torch.randperm(rows, device=obs.device)[:B].to(torch.int32).contiguous()
+    vf_coef, ent_coef = 0.5, 0.01
+    up.stats.zero_()
+    g = up.grad(obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef, stats=True)
+    loss, pg, vl, ratio = _torch_loss(ref, obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef, f16_operands=True)
+    loss.backward()
+    refs16 = _flat_ref_grads(ref)
+    for p in ref.parameters():
+        p.grad = None
+    loss, pg, vl, ratio = _torch_loss(ref, obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef)
+    loss.backward()
+    refs = _flat_ref_grads(ref)
+    names = [f"{n}.{l}.{k}" for n in ("pi", "vf") for l in (1, 2, 3, 4) for k in ("w", "b")] + ["log_std"]
+    off = 0
+    report = []
+    for name, r, r16 in zip(names, refs, refs16):
+        mine = g[off:off + r.numel()]
+        off += r.numel()
+        err = float((mine - r).norm() / (r.norm() + 1e-12))
+        err16 = float((mine - r16).norm() / (r16.norm() + 1e-12))
+        cos = float(torch.dot(mine, r) / (mine.norm() * r.norm() + 1e-20))
+        report.append((name, round(err16, 5), round(err, 5), round(cos, 6)))
+    print(report)
+    for name, err16, err, cos in report:
+        if clip > 1 or name.startswith("vf"):
+            # same operands: only the f16 rounding of the deltas remains (a 64-sample sum of +-deltas can cancel)
+            assert err16 < (6e-3 if B >= 256 else 3e-2), (name, err16, report)
+        assert err < 1e-1 and cos > 0.995, (name, err, cos, report)
+    assert off == g.numel()
+    st = up.stats.cpu().numpy()
+    assert abs(st[0] / B - float(pg)) < 5e-3 * max(1.0, abs(float(pg)))
+    assert abs(st[1] / B - float(vl)) < 5e-3 * max(1.0, abs(float(vl)))
+    clipped = float(((ratio - 1).abs() > clip).float().sum())
+    assert abs(st[3] - clipped) <= max(3.0, 0.02 * B)      # f16 forward moves a few ratios across the clip edge
+    if clip < 1:
+        assert clipped > 0.05 * B                            # the clipped branch is exercised
+
+
+def test_minibatch_update_matches_torch_adam():
+    L, rows, B = 17, 4096, 1024
+    pol, ref, up, obs, act, old_lp, adv, ret = _setup(L, rows, seed=5)
+    opt = torch.optim.Adam(ref.parameters(), lr=3e-4, eps=1e-5)
+    theta0 = up.theta.clone()
+    perm = torch.randperm(rows, device=obs.device).to(torch.int32)
+    for k in range(4):
+        idx = perm[k * B:(k + 1) * B].contiguous()
+        up.minibatch(obs, act, old_lp, adv, ret, idx, lr=3e-4)
+        loss, *_ = _torch_loss(ref, obs, act, old_lp, adv, ret, idx, 0.2, 0.5, 0.0)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        opt.step()
+    flat_ref = torch.cat([p.detach().reshape(-1) for net in (ref.pi, ref.vf) for lin in net if isinstance(lin, torch.nn.Linear)
+                          for p in (lin.weight, lin.bias)] + [ref.log_std.detach().reshape(-1)])
+    d_mine, d_ref = up.theta - theta0, flat_ref - theta0
+    assert float(d_ref.abs().max()) > 5e-4                       # four Adam steps of 3e-4 moved the parameters
+    # Adam's first steps are ~ lr * sign(g): elements whose gradient is near zero may differ, the bulk must agree
+    close = ((d_mine - d_ref).abs() < 0.15 * 3e-4 * 4).float().mean()
+    assert float(close) > 0.97, float(close)
+    assert float(torch.dot(d_mine, d_ref) / (d_mine.norm() * d_ref.norm())) > 0.98
+    # the module the updater re-pointed sees the new weights (aliases of theta)
+    assert torch.equal(pol.pi[0].weight.reshape(-1), up.theta[:120 * L])
+    assert pol.log_std.data_ptr() == up.theta[-4:].data_ptr()
+
+
+def test_argument_validation():
+    from optimal_quad_control_rl_amd import _lib
+
+    pol, ref, up, obs, act, old_lp, adv, ret = _setup(17, 256, seed=2)
+    idx = torch.arange(100, device=obs.device, dtype=torch.int32)
+    with pytest.raises(_lib.QuadraceError):
+        up.grad(obs, act, old_lp, adv, ret, idx)                # not a multiple of 64
+    idx = torch.arange(8192, device=obs.device, dtype=torch.int32) % 256
+    with pytest.raises(_lib.QuadraceError):
+        up.grad(obs, act, old_lp, adv, ret, idx.contiguous())   # larger than max_minibatch

@@ -24,6 +24,7 @@ ap.add_argument("--lr", type=float, default=3e-4)
 ap.add_argument("--target-kl", type=float, default=0.02)
 ap.add_argument("--lr-final", type=float, default=0.1)
 ap.add_argument("--fused", action="store_true", help="collect with the closed-loop rollout kernel (qr_rollout_policy)")
+ap.add_argument("--native-update", action="store_true", help="minibatch updates in the matrix-core kernels (qr_ppo_minibatch)")
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 
@@ -33,7 +34,8 @@ env = cls(a.envs, *trk, gates_ahead=1, infos_mode="none", seed=1)
 if a.variant == "e2e":
     env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
 model = PPO(env, n_steps=a.n_steps, n_epochs=a.epochs, batch_size=a.envs * a.n_steps // a.minibatches, learning_rate=a.lr,
-            target_kl=a.target_kl, lr_final_frac=a.lr_final, total_timesteps_hint=int(a.steps), fused_collect=a.fused)
+            target_kl=a.target_kl, lr_final_frac=a.lr_final, total_timesteps_hint=int(a.steps), fused_collect=a.fused,
+            native_update=a.native_update)
 best = {"gates": -1.0, "state": None}
 def keep_best(m):
     g = m.stats.get("gates_per_episode", 0.0)
@@ -58,7 +60,7 @@ for k in range(1200):
     obs, rew, done, trunc = ev.step_device(model.predict(obs).contiguous())
     gates += (rew > 5).float(); crashes += (done.float() - trunc.float()).clamp(min=0)
 dt = 0.01
-res = dict(fused_collect=a.fused, variant=a.variant, track=a.track, envs=a.envs, train_steps=model.num_timesteps, train_seconds=train_s,
+res = dict(fused_collect=a.fused, native_update=a.native_update, variant=a.variant, track=a.track, envs=a.envs, train_steps=model.num_timesteps, train_seconds=train_s,
            train_Msteps_per_s=model.num_timesteps / train_s / 1e6,
            eval_gates_per_12s=float(gates.mean()), eval_crashes_per_12s=float(crashes.mean()),
            eval_seconds_per_gate=float(1200 * dt / gates.mean().clamp(min=1e-9)),
