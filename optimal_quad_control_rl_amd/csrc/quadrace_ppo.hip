@@ -63,7 +63,8 @@ struct PpoDims {
     static constexpr int kSlotX0 = 0, kSlotH1 = kIT, kSlotH2 = kIT + 4, kSlotH3 = kIT + 8;
     static constexpr int kSlotD1 = kIT + 12, kSlotD2 = kIT + 16, kSlotD3 = kIT + 20, kSlotD4 = kIT + 24;
     static constexpr int kSlots = kIT + 25;
-    static constexpr int kJobsPerNet = 4 * kIT + 36;  // 32x32 weight tiles: layer1 4*kIT, layers 2,3 16 each, layer4 4
+    static constexpr int kIT2 = (kIT + 1) / 2;
+    static constexpr int kBlocksPerNet = 2 * kIT2 + 10;  // 2x2 blocks of 32x32 weight tiles: layer1 2*kIT2, layers 2,3 4 each, layer4 2
 };
 
 // ---- pack: f32 parameters -> f16 operand images -----------------------------------------------------------------------
@@ -115,32 +116,24 @@ __global__ void __launch_bounds__(256) ppo_pack_kernel(const float* __restrict__
     images[(size_t)net * D::kImage + e] = v;
 }
 
-// ---- adv_stats: mean and 1 / (unbiased std + 1e-8) of adv[idx[0..B)] ---------------------------------------------------
-__global__ void __launch_bounds__(1024) ppo_adv_stats_kernel(const float* __restrict__ adv, const int* __restrict__ idx, int B,
-                                                             float* __restrict__ out) {
-    __shared__ double s1[1024], s2[1024];
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < B; i += 1024) {
-        const double x = adv[idx[i]];
-        a += x;
-        b += x * x;
-    }
-    s1[threadIdx.x] = a;
-    s2[threadIdx.x] = b;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) {
-            s1[threadIdx.x] += s1[threadIdx.x + w];
-            s2[threadIdx.x] += s2[threadIdx.x + w];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const double mean = s1[0] / B;
-        double var = (s2[0] - B * mean * mean) / (B > 1 ? B - 1 : 1);
-        if (var < 0.0) var = 0.0;
-        out[0] = (float)mean;
-        out[1] = (float)(1.0 / (sqrt(var) + 1e-8));
+// ---- adv_stats: sum and sum of squares of adv[idx[0..B)] into acc[0], acc[1] (phase A turns them into mean / rstd) -------
+// acc (double[4]) = {sum adv, sum adv^2, sum grad^2, -}: each accumulator is cleared by the kernel that runs before its
+// next use (adv_stats clears acc[2]; the norm kernel clears acc[0..1]), so a minibatch needs no memset.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) ppo_adv_stats_kernel(const float* __restrict__ adv, const int* __restrict__ idx, int B,
+                                                            double* __restrict__ acc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) acc[2] = 0.0;
+    const double x = i < B ? (double)adv[idx[i]] : 0.0;
+    const double s1 = wave_sum_f64(x), s2 = wave_sum_f64(x * x);
+    if ((threadIdx.x & 63) == 0) {
+        unsafeAtomicAdd(acc + 0, s1);
+        unsafeAtomicAdd(acc + 1, s2);
     }
 }
 
@@ -154,13 +147,27 @@ struct PpoBatch {
     const int* idx;         // [B] rows of this minibatch
     int B, G;               // G = B / 64 groups
     float clip, vf_coef, ent_coef;
-    const float* adv_stats;  // [mean, rstd]
+    const double* acc;       // [sum adv, sum adv^2] of this minibatch (ppo_adv_stats_kernel)
     const float* theta;      // flat parameters (log_std is read from here)
     const half8* images;     // [2][kImage]
     half8* tbuf;             // [2][kSlots][G][4][64]
     float* grad;             // flat gradient (atomics)
     float* stats;            // [0] sum pg loss, [1] sum value loss, [2] sum approx kl, [3] clipped count (atomics)
+#ifdef QR_PHASE_TIMING
+    unsigned long long* ticks;  // [waves][16] shader-clock stamps (profiling build only, tools/ppo_phase_timing.py)
+#endif
 };
+
+#ifdef QR_PHASE_TIMING
+#define PPO_TICK(a, slot)                                                                                       \
+    do {                                                                                                        \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                             \
+        if ((a).ticks && (threadIdx.x & 63) == 0)                                                               \
+            (a).ticks[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + (slot)] = clock64(); \
+    } while (0)
+#else
+#define PPO_TICK(a, slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ half8 plain_pack(const f32x16p& acc, int s) {
     half8 b;
@@ -211,6 +218,7 @@ __device__ __forceinline__ void mlp_layer(const half8* __restrict__ W, int lane,
             out[1][2 * t] = relu_pack(acc1, 0);
             out[1][2 * t + 1] = relu_pack(acc1, 1);
         }
+        __builtin_amdgcn_sched_barrier(0);  // do not hoist all four tiles' A operands (128 registers) above the first MFMA
     }
 }
 
@@ -233,6 +241,7 @@ __device__ __forceinline__ void tstore_hidden(const half8 (&X)[2][8], half8* __r
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[st][2 * ut + 1], id[1], acc, 0, 0, 0);
             dst[ut * slot_stride + (2 * st) * 64] = plain_pack(acc, 0);
             dst[ut * slot_stride + (2 * st + 1) * 64] = plain_pack(acc, 1);
+            if (st == 1) __builtin_amdgcn_sched_barrier(0);  // keep the unrolled tiles from piling up live accumulators
         }
 }
 
@@ -250,16 +259,53 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half8* W = reinterpret_cast<half8*>(smem);
     const int net = blockIdx.y;
-    {
+    PPO_TICK(a, 0);
+    {   // operand images -> LDS, 8 independent 16-byte loads in flight per thread (one load per round trip took 22 k cycles)
         const float4* src = reinterpret_cast<const float4*>(a.images + (size_t)net * D::kImage);
         float4* dst = reinterpret_cast<float4*>(W);
-        for (int i = threadIdx.x; i < D::kImage; i += kPpoBlock) dst[i] = src[i];
+        constexpr int kBatch = 8;
+        for (int base = 0; base < D::kImage; base += kBatch * kPpoBlock) {
+            float4 v[kBatch];
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) {
+                const int i = base + q * kPpoBlock + threadIdx.x;
+                v[q] = src[i < D::kImage ? i : 0];
+            }
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) {
+                const int i = base + q * kPpoBlock + threadIdx.x;
+                if (i < D::kImage) dst[i] = v[q];
+            }
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int g = blockIdx.x * (kPpoBlock / 64) + (threadIdx.x >> 6);
     if (g >= a.G) return;  // whole wave
+    PPO_TICK(a, 1);
     const int b = a.idx[g * 64 + lane];
+    // every global LOAD of this wave is issued here: loads and stores share one in-order counter, so a load issued after the
+    // transposed-operand stores would wait for all of them to drain
+    // (they are parked in the LDS left over beside the operand images until the loss needs them: LDS traffic is counted
+    // separately, and 7 fewer live registers through the forward pass)
+    float* stash = reinterpret_cast<float*>(W + D::kImage) + threadIdx.x;
+    {
+        const float4 act_v = net == 0 ? reinterpret_cast<const float4*>(a.act)[b] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        stash[0 * kPpoBlock] = act_v.x;
+        stash[1 * kPpoBlock] = act_v.y;
+        stash[2 * kPpoBlock] = act_v.z;
+        stash[3 * kPpoBlock] = act_v.w;
+        stash[4 * kPpoBlock] = a.old_logp[b];
+        stash[5 * kPpoBlock] = a.adv[b];
+        stash[6 * kPpoBlock] = a.ret[b];
+    }
+    const double acc_s1 = a.acc[0], acc_s2 = a.acc[1];
+    float log_std_v[4];
+    {
+        const float* log_std = a.theta + net_off(L, 4).total + net_off(L, 1).total;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) log_std_v[k] = log_std[k];
+    }
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const size_t slot_stride = (size_t)a.G * 256;
     half8* tb = a.tbuf + ((size_t)net * D::kSlots * a.G + g) * 256 + lane;  // slot 0, this group, kk = 0
@@ -303,14 +349,21 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
         }
 
     // ---- forward
+    PPO_TICK(a, 2);
     uint32_t m1[2][2], m2[2][2], m3[2][2];
     half8 x[2][8], y[2][8];
     mlp_layer<KS1, false>(W, lane, in1, x, m1);
+    PPO_TICK(a, 3);
     tstore_hidden(x, tb + D::kSlotH1 * slot_stride, slot_stride, lane);
+    PPO_TICK(a, 4);
     mlp_layer<8, false>(W + P::kOff2, lane, x, y, m2);
+    PPO_TICK(a, 5);
     tstore_hidden(y, tb + D::kSlotH2 * slot_stride, slot_stride, lane);
+    PPO_TICK(a, 6);
     mlp_layer<8, false>(W + P::kOff3, lane, y, x, m3);  // x = h3
+    PPO_TICK(a, 7);
     tstore_hidden(x, tb + D::kSlotH3 * slot_stride, slot_stride, lane);
+    PPO_TICK(a, 8);
     float out4[4];
     {
         f32x16p acc0 = zero, acc1 = zero;
@@ -331,20 +384,22 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
     // ---- per-sample loss gradients (x B; the 1/B of the batch means is applied in phase B)
     float dout[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (net == 0) {
-        const float* log_std = a.theta + net_off(L, 4).total + net_off(L, 1).total;
-        const float4 av = reinterpret_cast<const float4*>(a.act)[b];
-        const float act[4] = {av.x, av.y, av.z, av.w};
+        const float act[4] = {stash[0 * kPpoBlock], stash[1 * kPpoBlock], stash[2 * kPpoBlock], stash[3 * kPpoBlock]};
+        const float old_logp_v = stash[4 * kPpoBlock], adv_v = stash[5 * kPpoBlock];
         float z[4], inv_std[4], logp = 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float ls = log_std[k];
+            const float ls = log_std_v[k];
             inv_std[k] = __expf(-ls);
             z[k] = (act[k] - out4[k]) * inv_std[k];
             logp += -0.5f * z[k] * z[k] - ls - 0.9189385332046727f;
         }
-        const float log_ratio = logp - a.old_logp[b];
+        const float log_ratio = logp - old_logp_v;
         const float ratio = __expf(log_ratio);
-        const float A = (a.adv[b] - a.adv_stats[0]) * a.adv_stats[1];
+        // SB3: advantages = (adv - mean) / (std + 1e-8), unbiased std over the minibatch
+        const double amean = acc_s1 / a.B;
+        const double avar = fmax((acc_s2 - a.B * amean * amean) / (a.B > 1 ? a.B - 1 : 1), 0.0);
+        const float A = (adv_v - (float)amean) * (float)(1.0 / (sqrt(avar) + 1e-8));
         const bool flows = A >= 0.0f ? (ratio <= 1.0f + a.clip) : (ratio >= 1.0f - a.clip);
         const float gl = flows ? -A * ratio : 0.0f;  // d loss / d logp
         float dls[4];
@@ -372,7 +427,7 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
             }
         }
     } else {
-        const float err = out4[0] - a.ret[b];
+        const float err = out4[0] - stash[6 * kPpoBlock];
         dout[0] = a.vf_coef * 2.0f * err;  // vf_coef * d mse / d v  (x B)
         if (a.stats) {
             const float vl = wave_sum(err * err);
@@ -380,6 +435,7 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
         }
     }
 
+    PPO_TICK(a, 9);
     // ---- output deltas as a B operand (k-slot (h, j) = output unit 8 h + j) and in transposed form
     half8 d4[2];
     {
@@ -409,97 +465,111 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
         x[1][2 * t] = mask_pack(acc1, m3[1][t >> 1], t, 0);
         x[1][2 * t + 1] = mask_pack(acc1, m3[1][t >> 1], t, 1);
     }
+    PPO_TICK(a, 10);
     tstore_hidden(x, tb + D::kSlotD3 * slot_stride, slot_stride, lane);
+    PPO_TICK(a, 11);
     mlp_layer<8, true>(W + D::kOffT3, lane, x, y, m2);
+    PPO_TICK(a, 12);
     tstore_hidden(y, tb + D::kSlotD2 * slot_stride, slot_stride, lane);
+    PPO_TICK(a, 13);
     mlp_layer<8, true>(W + D::kOffT2, lane, y, x, m1);
+    PPO_TICK(a, 14);
     tstore_hidden(x, tb + D::kSlotD1 * slot_stride, slot_stride, lane);
+    PPO_TICK(a, 15);
 }
 
 // ---- phase B: weight gradients -------------------------------------------------------------------------------------------
+// One wave = a 2x2 block of 32x32 weight tiles of one layer (operands shared: 4 loads feed 4 MFMAs) over a chunk of the
+// minibatch's sample groups.  Results go, NOT atomically, to partial[chunk][param]; the norm kernel sums the chunks.
+// (Measured: f32 atomics from ~3000 waves cost 17 us per minibatch, as much as the loads and MFMAs themselves.)
 template <int L>
-__global__ void __launch_bounds__(64) ppo_phase_b_kernel(const half8* __restrict__ tbuf, float* __restrict__ grad, int G,
-                                                         int groups_per_chunk, float scale) {
+__global__ void __launch_bounds__(64) ppo_phase_b_kernel(const half8* __restrict__ tbuf, float* __restrict__ partial, int num_params,
+                                                         int G, int groups_per_chunk, float scale) {
     using D = PpoDims<L>;
     const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
-    const int net = blockIdx.x / D::kJobsPerNet;
-    int j = blockIdx.x % D::kJobsPerNet;
-    int layer, to, ti;
-    if (j < 4 * D::kIT) { layer = 1; to = j / D::kIT; ti = j % D::kIT; }
-    else if (j < 4 * D::kIT + 16) { j -= 4 * D::kIT; layer = 2; to = j >> 2; ti = j & 3; }
-    else if (j < 4 * D::kIT + 32) { j -= 4 * D::kIT + 16; layer = 3; to = j >> 2; ti = j & 3; }
-    else { layer = 4; to = 0; ti = j - (4 * D::kIT + 32); }
-    const int slot_a = layer == 1 ? D::kSlotD1 + to : (layer == 2 ? D::kSlotD2 + to : (layer == 3 ? D::kSlotD3 + to : D::kSlotD4));
-    const int slot_b = layer == 1 ? D::kSlotX0 + ti : (layer == 2 ? D::kSlotH1 + ti : (layer == 3 ? D::kSlotH2 + ti : D::kSlotH3 + ti));
-    const half8* A = tbuf + ((size_t)net * D::kSlots + slot_a) * G * 256 + lane;
-    const half8* Bm = tbuf + ((size_t)net * D::kSlots + slot_b) * G * 256 + lane;
+    const int net = blockIdx.x / D::kBlocksPerNet;
+    int j = blockIdx.x % D::kBlocksPerNet;
+    int layer, to0, nto, ti0, nti;
+    if (j < 2 * D::kIT2) { layer = 1; to0 = 2 * (j / D::kIT2); nto = 2; ti0 = 2 * (j % D::kIT2); nti = min(2, D::kIT - ti0); }
+    else if (j < 2 * D::kIT2 + 4) { j -= 2 * D::kIT2; layer = 2; to0 = 2 * (j >> 1); nto = 2; ti0 = 2 * (j & 1); nti = 2; }
+    else if (j < 2 * D::kIT2 + 8) { j -= 2 * D::kIT2 + 4; layer = 3; to0 = 2 * (j >> 1); nto = 2; ti0 = 2 * (j & 1); nti = 2; }
+    else { layer = 4; to0 = 0; nto = 1; ti0 = 2 * (j - (2 * D::kIT2 + 8)); nti = 2; }
+    const int slot_a = (layer == 1 ? D::kSlotD1 : (layer == 2 ? D::kSlotD2 : (layer == 3 ? D::kSlotD3 : D::kSlotD4))) + to0;
+    const int slot_b = (layer == 1 ? D::kSlotX0 : (layer == 2 ? D::kSlotH1 : (layer == 3 ? D::kSlotH2 : D::kSlotH3))) + ti0;
+    const size_t slot_stride = (size_t)G * 256;
+    const half8* A0 = tbuf + ((size_t)net * D::kSlots + slot_a) * slot_stride + lane;
+    const half8* B0 = tbuf + ((size_t)net * D::kSlots + slot_b) * slot_stride + lane;
+    const half8* A1 = A0 + (nto > 1 ? slot_stride : 0);  // a block without a second row / column re-reads the first
+    const half8* B1 = B0 + (nti > 1 ? slot_stride : 0);
     const int g0 = blockIdx.y * groups_per_chunk;
     const int g1 = min(G, g0 + groups_per_chunk);
-    f32x16p acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    f32x16p acc[2][2] = {{zero, zero}, {zero, zero}};
     for (int g = g0; g < g1; ++g) {
-        half8 av[4], bv[4];
+        half8 a0[4], a1[4], b0[4], b1[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            av[kk] = A[((size_t)g * 4 + kk) * 64];
-            bv[kk] = Bm[((size_t)g * 4 + kk) * 64];
+            const size_t e = ((size_t)g * 4 + kk) * 64;
+            a0[kk] = A0[e]; a1[kk] = A1[e]; b0[kk] = B0[e]; b1[kk] = B1[e];
         }
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[kk], bv[kk], acc, 0, 0, 0);
+        for (int kk = 0; kk < 4; ++kk) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kk], b0[kk], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kk], b1[kk], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kk], b0[kk], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kk], b1[kk], acc[1][1], 0, 0, 0);
+        }
     }
     // D: register r of lane (c, h) = dW[row = 32 to + rho(r, h)][col = 32 ti + c]
     const int O = net == 0 ? 4 : 1;
     const NetOff o = net_off(L, O);
-    float* gn = grad + (net == 0 ? 0 : net_off(L, 4).total);
-    const int col = 32 * ti + c;
+    float* gn = partial + (size_t)blockIdx.y * num_params + (net == 0 ? 0 : net_off(L, 4).total);
+    const int in_dim = layer == 1 ? L : kH, out_dim = layer == 4 ? O : kH;   // column `in_dim` is the constant-1 unit = bias
+    const int ow = layer == 1 ? o.w1 : (layer == 2 ? o.w2 : (layer == 3 ? o.w3 : o.w4));
+    const int ob = layer == 1 ? o.b1 : (layer == 2 ? o.b2 : (layer == 3 ? o.b3 : o.b4));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = 32 * to + rho_(r, h);
-        const float v = acc[r] * scale;
-        if (layer == 1) {
-            if (row < kH) {
-                if (col < L) unsafeAtomicAdd(gn + o.w1 + row * L + col, v);
-                else if (col == L) unsafeAtomicAdd(gn + o.b1 + row, v);
-            }
-        } else if (layer == 4) {
-            if (row < O) {
-                if (col < kH) unsafeAtomicAdd(gn + o.w4 + row * kH + col, v);
-                else if (col == kPolBiasUnit) unsafeAtomicAdd(gn + o.b4 + row, v);
-            }
-        } else {
-            const int ow = layer == 2 ? o.w2 : o.w3, ob = layer == 2 ? o.b2 : o.b3;
-            if (row < kH) {
-                if (col < kH) unsafeAtomicAdd(gn + ow + row * kH + col, v);
-                else if (col == kPolBiasUnit) unsafeAtomicAdd(gn + ob + row, v);
+    for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+            if (bt >= nto || bi >= nti) continue;
+            const int col = 32 * (ti0 + bi) + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * (to0 + bt) + rho_(r, h);
+                const float v = acc[bt][bi][r] * scale;
+                if (row < out_dim) {
+                    if (col < in_dim) gn[ow + row * in_dim + col] = v;
+                    else if (col == in_dim) gn[ob + row] = v;
+                }
             }
         }
-    }
 }
 
 // ---- global gradient norm -> clip scale; Adam ----------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) ppo_norm_kernel(const float* __restrict__ grad, int n, float max_norm,
-                                                        float* __restrict__ out /* [norm, scale] */) {
-    __shared__ double s[1024];
-    double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += 1024) a += (double)grad[i] * grad[i];
-    s[threadIdx.x] = a;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
-        __syncthreads();
+__global__ void __launch_bounds__(256) ppo_norm_kernel(float* __restrict__ grad, const float* __restrict__ partial, int chunks, int n,
+                                                       double* __restrict__ acc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) acc[0] = acc[1] = 0.0;  // the advantage sums of this minibatch have been consumed by phase A
+    float g = 0.0f;
+    if (i < n) {
+        g = grad[i];                     // log_std (accumulated atomically by phase A); zero elsewhere
+        if (i < n - 4)
+            for (int cix = 0; cix < chunks; ++cix) g += partial[(size_t)cix * n + i];
+        grad[i] = g;
     }
-    if (threadIdx.x == 0) {
-        const float norm = (float)sqrt(s[0]);
-        out[0] = norm;
-        out[1] = fminf(1.0f, max_norm / (norm + 1e-6f));  // torch.nn.utils.clip_grad_norm_
-    }
+    const double s = wave_sum_f64((double)g * g);
+    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(acc + 2, s);
 }
 
 __global__ void __launch_bounds__(256) ppo_adam_kernel(float* __restrict__ theta, float* __restrict__ m, float* __restrict__ v,
-                                                       float* __restrict__ grad, int n, const float* __restrict__ clip,
-                                                       float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+                                                       float* __restrict__ grad, int n, const double* __restrict__ acc,
+                                                       float max_norm, float lr, float beta1, float beta2, float eps, float bc1,
+                                                       float bc2_sqrt) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float g = grad[i] * clip[1];
+    const float norm = (float)sqrt(acc[2]);
+    const float clip = fminf(1.0f, max_norm / (norm + 1e-6f));  // torch.nn.utils.clip_grad_norm_
+    float g = grad[i] * clip;
     if (!(fabsf(g) <= 3.0e38f)) g = 0.0f;  // a non-finite gradient never reaches the parameters
     const float mi = beta1 * m[i] + (1.0f - beta1) * g;
     const float vi = beta2 * v[i] + (1.0f - beta2) * g * g;
@@ -514,11 +584,15 @@ __global__ void __launch_bounds__(256) ppo_adam_kernel(float* __restrict__ theta
 // ------------------------------------------------------------------------------------------------------------------------
 struct qr_ppo {
     int L = 0, device = 0, max_B = 0, num_params = 0;
-    int image_half8 = 0, slots = 0, jobs_per_net = 0;
+    int image_half8 = 0, slots = 0, max_chunks = 32;  // chunks = split of the minibatch's sample groups in phase B
     qr::half8* d_images = nullptr;
     qr::half8* d_tbuf = nullptr;
     float* d_grad = nullptr;
-    float* d_scalars = nullptr;  // [0..1] adv mean / rstd, [2..3] grad norm / clip scale
+    float* d_partial = nullptr;  // [max_chunks][num_params] phase-B outputs
+#ifdef QR_PHASE_TIMING
+    unsigned long long* ticks = nullptr;
+#endif
+    double* d_acc = nullptr;     // {sum adv, sum adv^2, sum grad^2, -}, see ppo_adv_stats_kernel
 };
 
 namespace qr {
@@ -545,23 +619,26 @@ struct PpoOps {
         return QR_OK;
     }
     static int grad(qr_ppo* p, qr::PpoBatch b, hipStream_t st) {
-        const size_t lds = (size_t)D::kImage * 16;
+        const size_t lds = (size_t)D::kImage * 16 + 7 * qr::kPpoBlock * sizeof(float);  // operand images + per-sample stash
         static bool configured = false;
         if (!configured) {
             PPO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
         }
-        hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3(1), dim3(1024), 0, st, b.adv, b.idx, b.B, p->d_scalars);
+        hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((b.B + 255) / 256), dim3(256), 0, st, b.adv, b.idx, b.B, p->d_acc);
         hipLaunchKernelGGL(qr::ppo_phase_a_kernel<L>, dim3((b.G + 3) / 4, 2), dim3(qr::kPpoBlock), lds, st, b);
-        // split-K over the minibatch: enough waves to fill the chip (2 * kJobsPerNet tiles x chunks)
-        int chunks = 2048 / (2 * D::kJobsPerNet);
+        // split the minibatch's sample groups into chunks: 2 * kBlocksPerNet x chunks waves
+        int chunks = p->max_chunks;
         if (chunks > b.G) chunks = b.G;
         if (chunks < 1) chunks = 1;
         const int per = (b.G + chunks - 1) / chunks;
         chunks = (b.G + per - 1) / per;
-        hipLaunchKernelGGL(qr::ppo_phase_b_kernel<L>, dim3(2 * D::kJobsPerNet, chunks), dim3(64), 0, st, p->d_tbuf, p->d_grad, b.G,
-                           per, 1.0f / (float)b.B);
+        hipLaunchKernelGGL(qr::ppo_phase_b_kernel<L>, dim3(2 * D::kBlocksPerNet, chunks), dim3(64), 0, st, p->d_tbuf, p->d_partial,
+                           p->num_params, b.G, per, 1.0f / (float)b.B);
+        // chunk reduction + gradient norm (also leaves the complete gradient in d_grad)
+        hipLaunchKernelGGL(qr::ppo_norm_kernel, dim3((p->num_params + 255) / 256), dim3(256), 0, st, p->d_grad, p->d_partial, chunks,
+                           p->num_params, p->d_acc);
         PPO_HIP(hipGetLastError());
         return QR_OK;
     }
@@ -592,12 +669,15 @@ int fill_batch(qr_ppo* p, qr::PpoBatch& b, const float* theta, const float* obs,
     b.obs = obs; b.act = act; b.old_logp = old_logp; b.adv = adv; b.ret = ret; b.idx = idx;
     b.B = B; b.G = B / 64;
     b.clip = clip; b.vf_coef = vf_coef; b.ent_coef = ent_coef;
-    b.adv_stats = p->d_scalars;
+    b.acc = p->d_acc;
     b.theta = theta;
     b.images = p->d_images;
     b.tbuf = p->d_tbuf;
     b.grad = p->d_grad;
     b.stats = stats;
+#ifdef QR_PHASE_TIMING
+    b.ticks = p->ticks;
+#endif
     return QR_OK;
 }
 
@@ -621,7 +701,6 @@ int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo
         using D = qr::PpoDims<decltype(Lc)::value>;
         p->image_half8 = D::kImage;
         p->slots = D::kSlots;
-        p->jobs_per_net = D::kJobsPerNet;
         return (int)QR_OK;
     });
     if (rc != QR_OK) { delete p; return rc; }
@@ -631,9 +710,10 @@ int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo
     hipError_t e = hipMalloc((void**)&p->d_images, (size_t)2 * p->image_half8 * 16);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_tbuf, tbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_grad, (size_t)p->num_params * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_scalars, 16 * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_partial, (size_t)p->max_chunks * p->num_params * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_acc, 4 * sizeof(double));
     if (e == hipSuccess) e = hipMemset(p->d_grad, 0, (size_t)p->num_params * 4);
-    if (e == hipSuccess) e = hipMemset(p->d_scalars, 0, 16 * 4);
+    if (e == hipSuccess) e = hipMemset(p->d_acc, 0, 4 * sizeof(double));
     if (e != hipSuccess) {
         qr_ppo_destroy(p);
         return ppofail(QR_E_HIP, std::string("qr_ppo_create: ") + hipGetErrorString(e));
@@ -649,10 +729,15 @@ int qr_ppo_destroy(qr_ppo* p) {
     (void)hipFree(p->d_images);
     (void)hipFree(p->d_tbuf);
     (void)hipFree(p->d_grad);
-    (void)hipFree(p->d_scalars);
+    (void)hipFree(p->d_partial);
+    (void)hipFree(p->d_acc);
     delete p;
     return QR_OK;
 }
+
+#ifdef QR_PHASE_TIMING
+int qr_ppo_debug_set_ticks(qr_ppo* p, unsigned long long* ticks_dev) { p->ticks = ticks_dev; return QR_OK; }
+#endif
 
 int qr_ppo_num_params(const qr_ppo* p) { return p ? p->num_params : ppofail(QR_E_INVALID, "qr_ppo_num_params: null handle"); }
 
@@ -672,6 +757,7 @@ int qr_ppo_grad(qr_ppo* p, const float* theta_dev, const float* obs_dev, const f
     PPO_HIP(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
     PPO_HIP(hipMemsetAsync(p->d_grad, 0, (size_t)p->num_params * 4, st));
+    PPO_HIP(hipMemsetAsync(p->d_acc, 0, 4 * sizeof(double), st));
     if (int rc = dispatch_L(p->L, [&](auto Lc) {
             constexpr int L = decltype(Lc)::value;
             if (int r = PpoOps<L>::pack(p, theta_dev, st)) return r;
@@ -680,6 +766,7 @@ int qr_ppo_grad(qr_ppo* p, const float* theta_dev, const float* obs_dev, const f
         return rc;
     PPO_HIP(hipMemcpyAsync(grad_out_dev, p->d_grad, (size_t)p->num_params * 4, hipMemcpyDeviceToDevice, st));
     PPO_HIP(hipMemsetAsync(p->d_grad, 0, (size_t)p->num_params * 4, st));
+    PPO_HIP(hipMemsetAsync(p->d_acc, 0, 4 * sizeof(double), st));
     return QR_OK;
 }
 
@@ -698,9 +785,9 @@ int qr_ppo_minibatch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam
     return dispatch_L(p->L, [&](auto Lc) {
         constexpr int L = decltype(Lc)::value;
         if (int r = PpoOps<L>::grad(p, b, st)) return r;  // images were packed by the previous call (or qr_ppo_pack)
-        hipLaunchKernelGGL(qr::ppo_norm_kernel, dim3(1), dim3(1024), 0, st, p->d_grad, p->num_params, max_grad_norm, p->d_scalars + 2);
-        hipLaunchKernelGGL(qr::ppo_adam_kernel, dim3((p->num_params + 255) / 256), dim3(256), 0, st, theta_dev, adam_m_dev, adam_v_dev,
-                           p->d_grad, p->num_params, p->d_scalars + 2, lr, beta1, beta2, eps, bc1, bc2s);
+        const int pb = (p->num_params + 255) / 256;
+        hipLaunchKernelGGL(qr::ppo_adam_kernel, dim3(pb), dim3(256), 0, st, theta_dev, adam_m_dev, adam_v_dev, p->d_grad,
+                           p->num_params, p->d_acc, max_grad_norm, lr, beta1, beta2, eps, bc1, bc2s);
         PPO_HIP(hipGetLastError());
         return PpoOps<L>::pack(p, theta_dev, st);
     });

@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(L, rows, seed=0, scale_w=1.0):
+def _setup(L, rows, seed=0, max_minibatch=4096):
     from optimal_quad_control_rl_amd.ppo import ActorCritic, MfmaPpoUpdater
 
     dev = torch.device("cuda", 0)
@@ -24,7 +24,7 @@ def _setup(L, rows, seed=0, scale_w=1.0):
         pol.pi[-1].weight.mul_(30.0)
         pol.log_std.copy_(torch.tensor([-0.3, 0.1, -0.5, 0.2], device=dev))
     ref = copy.deepcopy(pol)
-    up = MfmaPpoUpdater(pol, L, dev, max_minibatch=4096)
+    up = MfmaPpoUpdater(pol, L, dev, max_minibatch=max_minibatch)
     g = torch.Generator(device=dev).manual_seed(seed + 1)
     obs = torch.randn((rows, L), device=dev, generator=g) * 1.5
     with torch.no_grad():
@@ -72,14 +72,15 @@ def _flat_ref_grads(ref):
     return out
 
 
-@pytest.mark.parametrize("L,B,clip", [(17, 1024, 0.2), (17, 1024, 50.0), (24, 512, 0.2), (36, 256, 50.0), (13, 64, 0.2)])
+@pytest.mark.parametrize("L,B,clip", [(17, 1024, 0.2), (17, 1024, 50.0), (24, 512, 0.2), (36, 256, 50.0), (13, 64, 0.2),
+                                      (17, 16384, 0.2), (24, 32768, 50.0)])
 def test_gradient_matches_autograd(L, B, clip):
     """Two references: (1) autograd through the same networks with f16-rounded GEMM operands -- what the kernels compute,
     so the comparison is tight; (2) plain f32 autograd -- there the f16 forward flips the ReLU state of units whose
     pre-activation is ~0 and (with clip = 0.2) the branch of ratios on the clip edge, a few-percent unbiased difference.
     clip = 50 switches the clipping off."""
-    rows = 3000
-    pol, ref, up, obs, act, old_lp, adv, ret = _setup(L, rows, seed=L)
+    rows = max(3000, 4 * B)
+    pol, ref, up, obs, act, old_lp, adv, ret = _setup(L, rows, seed=L, max_minibatch=max(4096, B))
     idx = torch.randperm(rows, device=obs.device)[:B].to(torch.int32).contiguous()
     vf_coef, ent_coef = 0.5, 0.01
     up.stats.zero_()
@@ -143,6 +144,35 @@ def test_minibatch_update_matches_torch_adam():
     # the module the updater re-pointed sees the new weights (aliases of theta)
     assert torch.equal(pol.pi[0].weight.reshape(-1), up.theta[:120 * L])
     assert pol.log_std.data_ptr() == up.theta[-4:].data_ptr()
+
+
+def test_full_epoch_tracks_torch():
+    """One PPO epoch at the training size (16 minibatches of 16 384 rows, same permutation, same start): the policy and
+    value functions after the native updates stay close to those after torch's updates."""
+    L, rows, B = 17, 16 * 16384, 16384
+    pol, ref, up, obs, act, old_lp, adv, ret = _setup(L, rows, seed=11, max_minibatch=B)
+    opt = torch.optim.Adam(ref.parameters(), lr=3e-4, eps=1e-5)
+    perm = torch.randperm(rows, device=obs.device).to(torch.int32)
+    with torch.no_grad():
+        mean0, v0 = ref.pi(obs[:4096]).clone(), ref.value(obs[:4096]).clone()
+    for k in range(rows // B):
+        idx = perm[k * B:(k + 1) * B].contiguous()
+        up.minibatch(obs, act, old_lp, adv, ret, idx, lr=3e-4)
+        loss, *_ = _torch_loss(ref, obs, act, old_lp, adv, ret, idx, 0.2, 0.5, 0.0)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        opt.step()
+    with torch.no_grad():
+        dm_ref, dv_ref = ref.pi(obs[:4096]) - mean0, ref.value(obs[:4096]) - v0
+        dm, dv = pol.pi(obs[:4096]) - mean0, pol.value(obs[:4096]) - v0
+    cos_m = float((dm * dm_ref).sum() / (dm.norm() * dm_ref.norm()))
+    cos_v = float((dv * dv_ref).sum() / (dv.norm() * dv_ref.norm()))
+    print("epoch: change of policy mean / value vs torch: cos", cos_m, cos_v, "rel", float((dm - dm_ref).norm() / dm_ref.norm()),
+          float((dv - dv_ref).norm() / dv_ref.norm()), "log_std", pol.log_std.tolist(), ref.log_std.tolist())
+    assert cos_m > 0.97 and cos_v > 0.97
+    assert float((dm - dm_ref).norm() / dm_ref.norm()) < 0.25 and float((dv - dv_ref).norm() / dv_ref.norm()) < 0.25
+    assert torch.allclose(pol.log_std, ref.log_std, atol=2e-3)
 
 
 def test_argument_validation():

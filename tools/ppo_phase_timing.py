@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Profiling aid: where a wave's time goes inside ppo_phase_a_kernel (instrumented build, -DQR_PHASE_TIMING; queues are
+drained at every stamp, so this measures the dependency chain).  Usage (GPU box): python tools/ppo_phase_timing.py"""
+import ctypes as C, os, subprocess, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from optimal_quad_control_rl_amd import build as B
+dbg = os.path.join(ROOT, "optimal_quad_control_rl_amd", "_dbg", "libquadrace_dbg.so")   # travels with the snapshot (git-ignored)
+os.makedirs(os.path.dirname(dbg), exist_ok=True)
+srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES]
+if "--build-only" in sys.argv or not os.path.exists(dbg) or os.path.getmtime(dbg) < max(os.path.getmtime(f) for f in srcs):
+    flags = [f for f in B.FLAGS if f not in ("-mllvm", "-amdgpu-mfma-vgpr-form")]
+    subprocess.check_call([B._hipcc(), *flags, "-DQR_PHASE_TIMING", "-o", dbg] + srcs)
+if "--build-only" in sys.argv:
+    sys.exit(0)
+B.LIB = dbg
+B.needs_build = lambda: False
+from optimal_quad_control_rl_amd import _lib
+from optimal_quad_control_rl_amd.ppo import ActorCritic, MfmaPpoUpdater
+dev = torch.device("cuda", 0)
+L_, Bn, R = 17, 16384, 65536 * 4
+obs = torch.randn((R, L_), device=dev); act = torch.randn((R, 4), device=dev) * 0.5
+old_lp = torch.randn(R, device=dev) * 0.1 - 3.0; adv = torch.randn(R, device=dev); ret = torch.randn(R, device=dev)
+perm = torch.randperm(R, device=dev).to(torch.int32)
+pol = ActorCritic(L_, 4).to(dev)
+up = MfmaPpoUpdater(pol, L_, dev, Bn)
+lib = _lib.load()
+lib.qr_ppo_debug_set_ticks.argtypes = [C.c_void_p, C.c_void_p]
+waves = 2 * (Bn // 64)
+ticks = torch.zeros((waves, 16), dtype=torch.int64, device=dev)
+for k in range(5):
+    up.minibatch(obs, act, old_lp, adv, ret, perm[k * Bn:(k + 1) * Bn], 3e-4)
+lib.qr_ppo_debug_set_ticks(up._h, C.c_void_p(ticks.data_ptr()))
+reps = []
+for k in range(12):
+    up.minibatch(obs, act, old_lp, adv, ret, perm[k * Bn:(k + 1) * Bn], 3e-4)
+    torch.cuda.synchronize()
+    reps.append(ticks.cpu().numpy().copy())
+t = np.stack(reps)[2:]
+names = ["entry", "image -> LDS + barrier", "obs gather, layer-1 operand, X0^T store", "fwd layer 1", "h1^T store", "fwd layer 2",
+         "h2^T store", "fwd layer 3", "h3^T store", "output layer + loss gradient", "d4, d4^T store, d3", "d3^T store", "d2", "d2^T store",
+         "d1", "d1^T store"]
+for s in range(1, 16):
+    print(f"  {s:2d} {names[s]:42s} {np.median(t[:, :, s] - t[:, :, s - 1]):8.0f} cycles")
+print(f"  in-wave total {np.median(t[:, :, 15] - t[:, :, 0]):8.0f} cycles;  first entry -> last exit {np.median(t[:, :, 15].max(1) - t[:, :, 0].min(1)):8.0f} cycles (100 MHz clock64 ticks x ~24 = shader cycles)")

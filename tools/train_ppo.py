@@ -25,15 +25,18 @@ ap.add_argument("--target-kl", type=float, default=0.02)
 ap.add_argument("--lr-final", type=float, default=0.1)
 ap.add_argument("--fused", action="store_true", help="collect with the closed-loop rollout kernel (qr_rollout_policy)")
 ap.add_argument("--native-update", action="store_true", help="minibatch updates in the matrix-core kernels (qr_ppo_minibatch)")
+ap.add_argument("--ent-coef", type=float, default=0.0)
+ap.add_argument("--gamma", type=float, default=0.999)
+ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 
 trk = square_track() if a.track == "square" else zigzag_track()
 cls = Quadcopter3DGates if a.variant == "e2e" else Quadcopter3DGatesINDI
-env = cls(a.envs, *trk, gates_ahead=1, infos_mode="none", seed=1)
+env = cls(a.envs, *trk, gates_ahead=1, infos_mode="none", seed=1 + a.seed)
 if a.variant == "e2e":
     env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
-model = PPO(env, n_steps=a.n_steps, n_epochs=a.epochs, batch_size=a.envs * a.n_steps // a.minibatches, learning_rate=a.lr,
+model = PPO(env, seed=a.seed, ent_coef=a.ent_coef, gamma=a.gamma, n_steps=a.n_steps, n_epochs=a.epochs, batch_size=a.envs * a.n_steps // a.minibatches, learning_rate=a.lr,
             target_kl=a.target_kl, lr_final_frac=a.lr_final, total_timesteps_hint=int(a.steps), fused_collect=a.fused,
             native_update=a.native_update)
 best = {"gates": -1.0, "state": None}
