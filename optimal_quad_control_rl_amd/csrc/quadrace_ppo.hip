@@ -125,13 +125,32 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) ppo_adv_stats_kernel(const float* __restrict__ adv, const int* __restrict__ idx, int B,
-                                                            double* __restrict__ acc) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+// sum over the block of up to two values: wave shuffles, then the first wave adds the per-wave sums; valid in thread 0
+template <int kThreads>
+__device__ __forceinline__ void block_sum2_f64(double& a, double& b) {
+    __shared__ double red[2][kThreads / 64];
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = a;
+        red[1][threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        a = wave_sum_f64((int)threadIdx.x < kThreads / 64 ? red[0][threadIdx.x] : 0.0);
+        b = wave_sum_f64((int)threadIdx.x < kThreads / 64 ? red[1][threadIdx.x] : 0.0);
+    }
+}
+
+// (same-address f64 atomics serialise at ~15 ns each: one pair per 1024-thread block, not one per wave)
+__global__ void __launch_bounds__(1024) ppo_adv_stats_kernel(const float* __restrict__ adv, const int* __restrict__ idx, int B,
+                                                             double* __restrict__ acc) {
+    const int i = blockIdx.x * 1024 + threadIdx.x;
     if (i == 0) acc[2] = 0.0;
     const double x = i < B ? (double)adv[idx[i]] : 0.0;
-    const double s1 = wave_sum_f64(x), s2 = wave_sum_f64(x * x);
-    if ((threadIdx.x & 63) == 0) {
+    double s1 = x, s2 = x * x;
+    block_sum2_f64<1024>(s1, s2);
+    if (threadIdx.x == 0) {
         unsafeAtomicAdd(acc + 0, s1);
         unsafeAtomicAdd(acc + 1, s2);
     }
@@ -151,8 +170,9 @@ struct PpoBatch {
     const float* theta;      // flat parameters (log_std is read from here)
     const half8* images;     // [2][kImage]
     half8* tbuf;             // [2][kSlots][G][4][64]
-    float* grad;             // flat gradient (atomics)
-    float* stats;            // [0] sum pg loss, [1] sum value loss, [2] sum approx kl, [3] clipped count (atomics)
+    float* wave_out;         // [2][G][8] per-wave sums: policy waves {d log_std[4] / B, surrogate loss, approx kl, clipped, -},
+                             // value waves {-, -, -, -, squared error, ...}; reduced by the norm kernel (no atomics)
+    float* stats;            // [0] sum surrogate loss, [1] sum squared value error, [2] sum approx kl, [3] clipped count
 #ifdef QR_PHASE_TIMING
     unsigned long long* ticks;  // [waves][16] shader-clock stamps (profiling build only, tools/ppo_phase_timing.py)
 #endif
@@ -409,29 +429,27 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
             dls[k] = gl * (z[k] * z[k] - 1.0f);
         }
         const float scale = 1.0f / (float)a.B;
-        float* gls = a.grad + net_off(L, 4).total + net_off(L, 1).total;
+        const float clipped_ratio = fminf(fmaxf(ratio, 1.0f - a.clip), 1.0f + a.clip);
+        float sums[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float sum = wave_sum(dls[k]);
-            if (lane == 0) unsafeAtomicAdd(gls + k, sum * scale - (g == 0 ? a.ent_coef : 0.0f));  // entropy = sum(log_std) + const
-        }
-        if (a.stats) {
-            const float clipped_ratio = fminf(fmaxf(ratio, 1.0f - a.clip), 1.0f + a.clip);
-            const float pg = wave_sum(-fminf(A * ratio, A * clipped_ratio));
-            const float kl = wave_sum((ratio - 1.0f) - log_ratio);
-            const float cf = wave_sum(fabsf(ratio - 1.0f) > a.clip ? 1.0f : 0.0f);
-            if (lane == 0) {
-                unsafeAtomicAdd(a.stats + 0, pg);
-                unsafeAtomicAdd(a.stats + 2, kl);
-                unsafeAtomicAdd(a.stats + 3, cf);
-            }
+        for (int k = 0; k < 4; ++k) sums[k] = wave_sum(dls[k]) * scale;
+        sums[4] = wave_sum(-fminf(A * ratio, A * clipped_ratio));
+        sums[5] = wave_sum((ratio - 1.0f) - log_ratio);
+        sums[6] = wave_sum(fabsf(ratio - 1.0f) > a.clip ? 1.0f : 0.0f);
+        sums[7] = 0.0f;
+        if (lane == 0) {
+            float4* wo = reinterpret_cast<float4*>(a.wave_out + (size_t)g * 8);
+            wo[0] = make_float4(sums[0], sums[1], sums[2], sums[3]);
+            wo[1] = make_float4(sums[4], sums[5], sums[6], sums[7]);
         }
     } else {
         const float err = out4[0] - stash[6 * kPpoBlock];
         dout[0] = a.vf_coef * 2.0f * err;  // vf_coef * d mse / d v  (x B)
-        if (a.stats) {
-            const float vl = wave_sum(err * err);
-            if (lane == 0) unsafeAtomicAdd(a.stats + 1, vl);
+        const float vl = wave_sum(err * err);
+        if (lane == 0) {
+            float4* wo = reinterpret_cast<float4*>(a.wave_out + ((size_t)a.G + g) * 8);
+            wo[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            wo[1] = make_float4(vl, 0.0f, 0.0f, 0.0f);
         }
     }
 
@@ -546,19 +564,46 @@ __global__ void __launch_bounds__(64) ppo_phase_b_kernel(const half8* __restrict
 }
 
 // ---- global gradient norm -> clip scale; Adam ----------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ppo_norm_kernel(float* __restrict__ grad, const float* __restrict__ partial, int chunks, int n,
-                                                       double* __restrict__ acc) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(1024) ppo_norm_kernel(float* __restrict__ grad, const float* __restrict__ partial, int chunks, int n,
+                                                        const float* __restrict__ wave_out, int G, float ent_coef,
+                                                        float* __restrict__ stats, double* __restrict__ acc) {
+    const int i = blockIdx.x * 1024 + threadIdx.x;
     if (i == 0) acc[0] = acc[1] = 0.0;  // the advantage sums of this minibatch have been consumed by phase A
-    float g = 0.0f;
-    if (i < n) {
-        g = grad[i];                     // log_std (accumulated atomically by phase A); zero elsewhere
-        if (i < n - 4)
-            for (int cix = 0; cix < chunks; ++cix) g += partial[(size_t)cix * n + i];
-        grad[i] = g;
+    // the tail block also reduces the per-wave sums of phase A: waves 0..3 -> d loss / d log_std[k], waves 4..7 -> statistics
+    __shared__ float wave_red[8];
+    if (((int)blockIdx.x + 1) * 1024 > n - 4) {  // the block(s) holding the log_std entries (the last one, or the last two)
+        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (w < 8) {
+            // statistics: 4 surrogate (policy waves, slot 4), 5 squared value error (value waves, slot 4), 6 approx kl, 7 clipped
+            const int slot = w < 4 ? w : (w == 4 || w == 5 ? 4 : (w == 6 ? 5 : 6));
+            const float* wv = wave_out + (w == 5 ? (size_t)G * 8 : 0) + slot;
+            float t = 0.0f;
+            for (int q = lane; q < G; q += 64) t += wv[(size_t)q * 8];
+            t = wave_sum(t);
+            if (lane == 0) {
+                wave_red[w] = t;
+                if (w >= 4 && stats && blockIdx.x == gridDim.x - 1) stats[w - 4] += t;  // single writer
+            }
+        }
+        __syncthreads();
     }
-    const double s = wave_sum_f64((double)g * g);
-    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(acc + 2, s);
+    float g = 0.0f;
+    if (i < n - 4) {  // weights and biases: sum the sample-chunk partials of phase B
+        float gs[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // independent loads in flight
+        int cix = 0;
+        for (; cix + 8 <= chunks; cix += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) gs[q] += partial[(size_t)(cix + q) * n + i];
+        }
+        for (; cix < chunks; ++cix) gs[0] += partial[(size_t)cix * n + i];
+        g = ((gs[0] + gs[1]) + (gs[2] + gs[3])) + ((gs[4] + gs[5]) + (gs[6] + gs[7]));
+    } else if (i < n) {  // log_std; entropy = sum(log_std) + const
+        g = wave_red[i - (n - 4)] - ent_coef;
+    }
+    if (i < n) grad[i] = g;
+    double sq = (double)g * g, unused = 0.0;
+    block_sum2_f64<1024>(sq, unused);
+    if (threadIdx.x == 0) unsafeAtomicAdd(acc + 2, sq);
 }
 
 __global__ void __launch_bounds__(256) ppo_adam_kernel(float* __restrict__ theta, float* __restrict__ m, float* __restrict__ v,
@@ -589,6 +634,7 @@ struct qr_ppo {
     qr::half8* d_tbuf = nullptr;
     float* d_grad = nullptr;
     float* d_partial = nullptr;  // [max_chunks][num_params] phase-B outputs
+    float* d_wave = nullptr;     // [2][max groups][8] per-wave sums of phase A
 #ifdef QR_PHASE_TIMING
     unsigned long long* ticks = nullptr;
 #endif
@@ -626,7 +672,7 @@ struct PpoOps {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
         }
-        hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((b.B + 255) / 256), dim3(256), 0, st, b.adv, b.idx, b.B, p->d_acc);
+        hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((b.B + 1023) / 1024), dim3(1024), 0, st, b.adv, b.idx, b.B, p->d_acc);
         hipLaunchKernelGGL(qr::ppo_phase_a_kernel<L>, dim3((b.G + 3) / 4, 2), dim3(qr::kPpoBlock), lds, st, b);
         // split the minibatch's sample groups into chunks: 2 * kBlocksPerNet x chunks waves
         int chunks = p->max_chunks;
@@ -637,8 +683,8 @@ struct PpoOps {
         hipLaunchKernelGGL(qr::ppo_phase_b_kernel<L>, dim3(2 * D::kBlocksPerNet, chunks), dim3(64), 0, st, p->d_tbuf, p->d_partial,
                            p->num_params, b.G, per, 1.0f / (float)b.B);
         // chunk reduction + gradient norm (also leaves the complete gradient in d_grad)
-        hipLaunchKernelGGL(qr::ppo_norm_kernel, dim3((p->num_params + 255) / 256), dim3(256), 0, st, p->d_grad, p->d_partial, chunks,
-                           p->num_params, p->d_acc);
+        hipLaunchKernelGGL(qr::ppo_norm_kernel, dim3((p->num_params + 1023) / 1024), dim3(1024), 0, st, p->d_grad, p->d_partial, chunks,
+                           p->num_params, p->d_wave, b.G, b.ent_coef, b.stats, p->d_acc);
         PPO_HIP(hipGetLastError());
         return QR_OK;
     }
@@ -673,7 +719,7 @@ int fill_batch(qr_ppo* p, qr::PpoBatch& b, const float* theta, const float* obs,
     b.theta = theta;
     b.images = p->d_images;
     b.tbuf = p->d_tbuf;
-    b.grad = p->d_grad;
+    b.wave_out = p->d_wave;
     b.stats = stats;
 #ifdef QR_PHASE_TIMING
     b.ticks = p->ticks;
@@ -711,6 +757,7 @@ int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_tbuf, tbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_grad, (size_t)p->num_params * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_partial, (size_t)p->max_chunks * p->num_params * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_wave, (size_t)2 * (max_minibatch / 64) * 8 * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_acc, 4 * sizeof(double));
     if (e == hipSuccess) e = hipMemset(p->d_grad, 0, (size_t)p->num_params * 4);
     if (e == hipSuccess) e = hipMemset(p->d_acc, 0, 4 * sizeof(double));
@@ -730,6 +777,7 @@ int qr_ppo_destroy(qr_ppo* p) {
     (void)hipFree(p->d_tbuf);
     (void)hipFree(p->d_grad);
     (void)hipFree(p->d_partial);
+    (void)hipFree(p->d_wave);
     (void)hipFree(p->d_acc);
     delete p;
     return QR_OK;
