@@ -328,13 +328,20 @@ def main():
                 except Exception as ex:  # pragma: no cover
                     result["parity"] = {"error": repr(ex)}
             if not args.no_cpu_baseline:
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                try:  # the PPO minibatch update on the matrix cores (qr_ppo_minibatch) vs torch; measured
+                    # before the CPU legs (their worker threads would compete with the launch thread: six launches per update)
+                    from bench_ppo_update import measure as ppo_measure
+
+                    result["ppo_update"] = ppo_measure(L, 16384, 65536 * 8, 100)
+                except Exception as ex:  # pragma: no cover
+                    result["ppo_update"] = {"error": repr(ex)}
                 try:
                     result["host_numpy_path"] = host_path_probe(args.variant, n, ga)
                 except Exception as ex:  # pragma: no cover
                     result["host_numpy_path"] = {"error": repr(ex)}
                 result["cpu_baseline"] = cpu_baseline(args.variant, n, ga, args.cpu_seconds)
                 try:  # the predecessor envs of "3D quad.ipynb" (include/quad3d.h), short measurement
-                    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
                     from bench_quad3d import measure as q3_measure
 
                     result["predecessor_envs"] = {k: q3_measure(k, n, 200, repeats=3, cpu_seconds=2.0) for k in ("hover", "gates")}

@@ -6,16 +6,18 @@
 // (qr_rollout_policy) torch's minibatch update was > 95 % of training time: ~100 small launches around
 // 16 k x 120 x 120 GEMMs.  Here one minibatch is six launches:
 //
-//   adv_stats   mean / unbiased std of the minibatch's advantages (SB3 normalises per minibatch)
+//   adv_stats   sum / sum of squares of the minibatch's advantages (SB3 normalises per minibatch; phase A finishes the maths)
 //   phase A     per wave = 64 samples of one net: forward (f16 MFMA chain of quadrace_policy.hpp), per-sample loss
 //               gradients, backward through the transposed weight images -- activations h_l and deltas d_l never leave
 //               registers in the "lane = sample" form.  Each of them is also emitted in the transposed operand form
 //               (lane = unit, k = sample) by multiplying with an identity operand on the matrix core, and written
-//               to a scratch buffer (f16, ~105 KB per 64 samples and net).
-//   phase B     dW_l = d_l^T x h_(l-1): one wave per 32x32 weight tile and sample chunk (split-K over the minibatch),
-//               v_mfma_f32_32x32x16_f16 with k = sample, f32 atomics into the flat gradient.  Biases ride along as the
+//               to a scratch buffer (f16, ~105 KB per 64 samples and net).  No atomics: log-std gradients and loss
+//               statistics leave as per-wave sums.
+//   phase B     dW_l = d_l^T x h_(l-1): one wave per 2x2 block of 32x32 weight tiles and chunk of the sample groups,
+//               v_mfma_f32_32x32x16_f16 with k = sample, plain stores to partial[chunk][param].  Biases ride along as the
 //               constant-1 unit of every layer.
-//   norm, adam  global gradient norm -> clip scale; Adam on the flat parameter vector (also clears the gradient)
+//   norm        sums the chunk partials and the per-wave sums into the flat gradient, accumulates its squared norm
+//   adam        clip scale from the norm, torch.optim.Adam arithmetic on the flat parameter vector
 //   pack        f32 parameters -> f16 forward and transposed operand images for the next minibatch
 //
 // Operand layouts are those of quadrace_policy.hpp (verified on MI355X with tools/ubench/mfma_layout.hip).
@@ -523,12 +525,20 @@ __global__ void __launch_bounds__(64) ppo_phase_b_kernel(const half8* __restrict
     const int g1 = min(G, g0 + groups_per_chunk);
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     f32x16p acc[2][2] = {{zero, zero}, {zero, zero}};
+    // operands of group g + 1 are in flight while group g is multiplied (a wave is otherwise one round trip per group)
+    half8 a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const size_t e = ((size_t)min(g0, G - 1) * 4 + kk) * 64;
+        a0[kk] = A0[e]; a1[kk] = A1[e]; b0[kk] = B0[e]; b1[kk] = B1[e];
+    }
     for (int g = g0; g < g1; ++g) {
-        half8 a0[4], a1[4], b0[4], b1[4];
+        half8 na0[4], na1[4], nb0[4], nb1[4];
+        const int gn = g + 1 < g1 ? g + 1 : g;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const size_t e = ((size_t)g * 4 + kk) * 64;
-            a0[kk] = A0[e]; a1[kk] = A1[e]; b0[kk] = B0[e]; b1[kk] = B1[e];
+            const size_t e = ((size_t)gn * 4 + kk) * 64;
+            na0[kk] = A0[e]; na1[kk] = A1[e]; nb0[kk] = B0[e]; nb1[kk] = B1[e];
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -536,6 +546,10 @@ __global__ void __launch_bounds__(64) ppo_phase_b_kernel(const half8* __restrict
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kk], b1[kk], acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kk], b0[kk], acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kk], b1[kk], acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            a0[kk] = na0[kk]; a1[kk] = na1[kk]; b0[kk] = nb0[kk]; b1[kk] = nb1[kk];
         }
     }
     // D: register r of lane (c, h) = dW[row = 32 to + rho(r, h)][col = 32 ti + c]

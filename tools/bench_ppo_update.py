@@ -9,51 +9,56 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from optimal_quad_control_rl_amd.ppo import ActorCritic, MfmaPpoUpdater
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--obs-len", type=int, default=17)
-ap.add_argument("--minibatch", type=int, default=16384)
-ap.add_argument("--rows", type=int, default=65536 * 32)
-ap.add_argument("--iters", type=int, default=200)
-a = ap.parse_args()
-dev = torch.device("cuda", 0)
-L, B, R = a.obs_len, a.minibatch, a.rows
-torch.manual_seed(0)
-obs = torch.randn((R, L), device=dev); act = torch.randn((R, 4), device=dev) * 0.5
-old_lp = torch.randn(R, device=dev) * 0.1 - 3.0; adv = torch.randn(R, device=dev); ret = torch.randn(R, device=dev)
-perm = torch.randperm(R, device=dev).to(torch.int32)
+
+def measure(L=17, B=16384, R=65536 * 8, iters=100, with_torch=True):
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    obs = torch.randn((R, L), device=dev); act = torch.randn((R, 4), device=dev) * 0.5
+    old_lp = torch.randn(R, device=dev) * 0.1 - 3.0; adv = torch.randn(R, device=dev); ret = torch.randn(R, device=dev)
+    perm = torch.randperm(R, device=dev).to(torch.int32)
+
+    def timed(fn, n):
+        for k in range(10):
+            fn(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n):
+            fn(k)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    pol = ActorCritic(L, 4).to(dev)
+    up = MfmaPpoUpdater(pol, L, dev, B)
+    nb = R // B
+    t_native = timed(lambda k: up.minibatch(obs, act, old_lp, adv, ret, perm[(k % nb) * B:(k % nb + 1) * B], 3e-4), iters)
+    flops = 2 * B * 3 * 2 * (L * 120 + 2 * 120 * 120 + 2.5 * 120)   # 2 nets x (fwd + 2 bwd GEMMs) x 2 flop/MAC, useful MACs only
+    out = {"what": "one PPO minibatch update (both 3x120 networks: forward, loss, backward, grad-norm clip, Adam): qr_ppo_minibatch "
+                   "vs torch autograd + torch.optim.Adam on the same rows", "obs_len": L, "minibatch": B,
+           "native_us": t_native * 1e6, "native_samples_per_s": B / t_native, "useful_TFLOPs": flops / t_native / 1e12}
+    up.close()
+    if with_torch:
+        ref = ActorCritic(L, 4).to(dev)
+        opt = torch.optim.Adam(ref.parameters(), lr=3e-4, eps=1e-5)
+
+        def torch_step(k):
+            idx = perm[(k % nb) * B:(k % nb + 1) * B].long()
+            x = adv[idx]; x = (x - x.mean()) / (x.std() + 1e-8)
+            lp, ent = ref.log_prob_entropy(obs[idx], act[idx])
+            ratio = (lp - old_lp[idx]).exp()
+            loss = -torch.min(x * ratio, x * ratio.clamp(0.8, 1.2)).mean() + 0.5 * torch.nn.functional.mse_loss(ref.value(obs[idx]), ret[idx])
+            opt.zero_grad(set_to_none=True); loss.backward()
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5); opt.step()
+
+        t_torch = timed(torch_step, max(20, iters // 4))
+        out.update(torch_us=t_torch * 1e6, speedup=t_torch / t_native)
+    return out
 
 
-def timed(fn, iters):
-    for k in range(10):
-        fn(k)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(iters):
-        fn(k)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / iters
-
-
-pol = ActorCritic(L, 4).to(dev)
-up = MfmaPpoUpdater(pol, L, dev, B)
-nb = R // B
-t_native = timed(lambda k: up.minibatch(obs, act, old_lp, adv, ret, perm[(k % nb) * B:(k % nb + 1) * B], 3e-4), a.iters)
-
-ref = ActorCritic(L, 4).to(dev)
-opt = torch.optim.Adam(ref.parameters(), lr=3e-4, eps=1e-5)
-
-
-def torch_step(k):
-    idx = perm[(k % nb) * B:(k % nb + 1) * B].long()
-    x = adv[idx]; x = (x - x.mean()) / (x.std() + 1e-8)
-    lp, ent = ref.log_prob_entropy(obs[idx], act[idx])
-    ratio = (lp - old_lp[idx]).exp()
-    loss = -torch.min(x * ratio, x * ratio.clamp(0.8, 1.2)).mean() + 0.5 * torch.nn.functional.mse_loss(ref.value(obs[idx]), ret[idx])
-    opt.zero_grad(set_to_none=True); loss.backward()
-    torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5); opt.step()
-
-
-t_torch = timed(torch_step, max(20, a.iters // 4))
-flops = 2 * B * 3 * 2 * (L * 120 + 2 * 120 * 120 + 2.5 * 120)   # 2 nets x (fwd + 2 bwd GEMMs) x 2 flop/MAC, useful MACs only
-print(json.dumps({"obs_len": L, "minibatch": B, "native_us": t_native * 1e6, "torch_us": t_torch * 1e6, "speedup": t_torch / t_native,
-                  "native_samples_per_s": B / t_native, "useful_TFLOPs": flops / t_native / 1e12}))
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--obs-len", type=int, default=17)
+    ap.add_argument("--minibatch", type=int, default=16384)
+    ap.add_argument("--rows", type=int, default=65536 * 32)
+    ap.add_argument("--iters", type=int, default=200)
+    a = ap.parse_args()
+    print(json.dumps(measure(a.obs_len, a.minibatch, a.rows, a.iters)))
