@@ -504,11 +504,24 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
 // (Measured: f32 atomics from ~3000 waves cost 17 us per minibatch, as much as the loads and MFMAs themselves.)
 template <int L>
 __global__ void __launch_bounds__(64) ppo_phase_b_kernel(const half8* __restrict__ tbuf, float* __restrict__ partial, int num_params,
-                                                         int G, int groups_per_chunk, float scale) {
+                                                         int G, int groups_per_chunk, int num_chunks, float scale) {
     using D = PpoDims<L>;
     const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
-    const int net = blockIdx.x / D::kBlocksPerNet;
-    int j = blockIdx.x % D::kBlocksPerNet;
+    // XCD-aware mapping: workgroups go round-robin to the 8 XCDs (each with its own L2), so workgroup id % 8 selects the XCD.
+    // All tile blocks of one sample chunk share their operands -> they get the same id % 8 and meet in one L2
+    // (measured: 21.9 -> 15.5 us; placing phase A's groups on the XCD that later reads them gained nothing).
+    constexpr int kJobs = 2 * D::kBlocksPerNet;
+    const int id = blockIdx.x;
+    int chunk, job;
+    if (num_chunks % 8 == 0) {
+        chunk = (id % 8) + 8 * (id / (8 * kJobs));
+        job = (id / 8) % kJobs;
+    } else {
+        chunk = id / kJobs;
+        job = id % kJobs;
+    }
+    const int net = job / D::kBlocksPerNet;
+    int j = job % D::kBlocksPerNet;
     int layer, to0, nto, ti0, nti;
     if (j < 2 * D::kIT2) { layer = 1; to0 = 2 * (j / D::kIT2); nto = 2; ti0 = 2 * (j % D::kIT2); nti = min(2, D::kIT - ti0); }
     else if (j < 2 * D::kIT2 + 4) { j -= 2 * D::kIT2; layer = 2; to0 = 2 * (j >> 1); nto = 2; ti0 = 2 * (j & 1); nti = 2; }
@@ -521,7 +534,7 @@ __global__ void __launch_bounds__(64) ppo_phase_b_kernel(const half8* __restrict
     const half8* B0 = tbuf + ((size_t)net * D::kSlots + slot_b) * slot_stride + lane;
     const half8* A1 = A0 + (nto > 1 ? slot_stride : 0);  // a block without a second row / column re-reads the first
     const half8* B1 = B0 + (nti > 1 ? slot_stride : 0);
-    const int g0 = blockIdx.y * groups_per_chunk;
+    const int g0 = chunk * groups_per_chunk;
     const int g1 = min(G, g0 + groups_per_chunk);
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     f32x16p acc[2][2] = {{zero, zero}, {zero, zero}};
@@ -555,7 +568,7 @@ __global__ void __launch_bounds__(64) ppo_phase_b_kernel(const half8* __restrict
     // D: register r of lane (c, h) = dW[row = 32 to + rho(r, h)][col = 32 ti + c]
     const int O = net == 0 ? 4 : 1;
     const NetOff o = net_off(L, O);
-    float* gn = partial + (size_t)blockIdx.y * num_params + (net == 0 ? 0 : net_off(L, 4).total);
+    float* gn = partial + (size_t)chunk * num_params + (net == 0 ? 0 : net_off(L, 4).total);
     const int in_dim = layer == 1 ? L : kH, out_dim = layer == 4 ? O : kH;   // column `in_dim` is the constant-1 unit = bias
     const int ow = layer == 1 ? o.w1 : (layer == 2 ? o.w2 : (layer == 3 ? o.w3 : o.w4));
     const int ob = layer == 1 ? o.b1 : (layer == 2 ? o.b2 : (layer == 3 ? o.b3 : o.b4));
@@ -686,16 +699,16 @@ struct PpoOps {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
         }
-        hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((b.B + 1023) / 1024), dim3(1024), 0, st, b.adv, b.idx, b.B, p->d_acc);
-        hipLaunchKernelGGL(qr::ppo_phase_a_kernel<L>, dim3((b.G + 3) / 4, 2), dim3(qr::kPpoBlock), lds, st, b);
-        // split the minibatch's sample groups into chunks: 2 * kBlocksPerNet x chunks waves
+        // split the minibatch's sample groups into chunks: 2 * kBlocksPerNet x chunks waves in phase B
         int chunks = p->max_chunks;
         if (chunks > b.G) chunks = b.G;
         if (chunks < 1) chunks = 1;
         const int per = (b.G + chunks - 1) / chunks;
         chunks = (b.G + per - 1) / per;
-        hipLaunchKernelGGL(qr::ppo_phase_b_kernel<L>, dim3(2 * D::kBlocksPerNet, chunks), dim3(64), 0, st, p->d_tbuf, p->d_partial,
-                           p->num_params, b.G, per, 1.0f / (float)b.B);
+        hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((b.B + 1023) / 1024), dim3(1024), 0, st, b.adv, b.idx, b.B, p->d_acc);
+        hipLaunchKernelGGL(qr::ppo_phase_a_kernel<L>, dim3((b.G + 3) / 4, 2), dim3(qr::kPpoBlock), lds, st, b);
+        hipLaunchKernelGGL(qr::ppo_phase_b_kernel<L>, dim3(2 * D::kBlocksPerNet * chunks), dim3(64), 0, st, p->d_tbuf, p->d_partial,
+                           p->num_params, b.G, per, chunks, 1.0f / (float)b.B);
         // chunk reduction + gradient norm (also leaves the complete gradient in d_grad)
         hipLaunchKernelGGL(qr::ppo_norm_kernel, dim3((p->num_params + 1023) / 1024), dim3(1024), 0, st, p->d_grad, p->d_partial, chunks,
                            p->num_params, p->d_wave, b.G, b.ent_coef, b.stats, p->d_acc);
