@@ -211,42 +211,44 @@ __device__ __forceinline__ uint32_t relu_bits(const f32x16p& acc, int t) {
     return w;
 }
 
-// One 128-unit layer: in[et][KS] -> out[et][8].  Forward (BWD = false): out = relu(acc) packed, mask = (acc > 0).
-// Backward (BWD = true): out = acc where mask is set (the ReLU derivative of the layer being entered), else 0.
+// One 128-unit layer for ONE 32-sample tile: in[KS] -> out[8].  Forward (BWD = false): out = relu(acc) packed,
+// mask = (acc > 0).  Backward (BWD = true): out = acc where mask is set (the ReLU derivative of the layer being
+// entered), else 0.  Two output tiles are accumulated side by side (two independent MFMA chains).
 template <int KS, bool BWD>
-__device__ __forceinline__ void mlp_layer(const half8* __restrict__ W, int lane, const half8 (&in)[2][KS], half8 (&out)[2][8],
-                                          uint32_t (&mask)[2][2]) {
+__device__ __forceinline__ void mlp_layer(const half8* __restrict__ W, int lane, const half8 (&in)[KS], half8 (&out)[8],
+                                          uint32_t (&mask)[2]) {
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (!BWD) mask[0][0] = mask[0][1] = mask[1][0] = mask[1][1] = 0u;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int tp = 0; tp < 2; ++tp) {
+        const int t0 = 2 * tp, t1 = 2 * tp + 1;
         f32x16p acc0 = zero, acc1 = zero;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const half8 a = W[(t * KS + s) * 64 + lane];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, in[0][s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, in[1][s], acc1, 0, 0, 0);
+            const half8 a0 = W[(t0 * KS + s) * 64 + lane];
+            const half8 a1 = W[(t1 * KS + s) * 64 + lane];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, in[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, in[s], acc1, 0, 0, 0);
         }
         if (BWD) {
-            out[0][2 * t] = mask_pack(acc0, mask[0][t >> 1], t, 0);
-            out[0][2 * t + 1] = mask_pack(acc0, mask[0][t >> 1], t, 1);
-            out[1][2 * t] = mask_pack(acc1, mask[1][t >> 1], t, 0);
-            out[1][2 * t + 1] = mask_pack(acc1, mask[1][t >> 1], t, 1);
+            out[2 * t0] = mask_pack(acc0, mask[tp], t0, 0);
+            out[2 * t0 + 1] = mask_pack(acc0, mask[tp], t0, 1);
+            out[2 * t1] = mask_pack(acc1, mask[tp], t1, 0);
+            out[2 * t1 + 1] = mask_pack(acc1, mask[tp], t1, 1);
         } else {
-            mask[0][t >> 1] |= relu_bits(acc0, t);
-            mask[1][t >> 1] |= relu_bits(acc1, t);
-            out[0][2 * t] = relu_pack(acc0, 0);
-            out[0][2 * t + 1] = relu_pack(acc0, 1);
-            out[1][2 * t] = relu_pack(acc1, 0);
-            out[1][2 * t + 1] = relu_pack(acc1, 1);
+            mask[tp] = relu_bits(acc0, t0) | relu_bits(acc1, t1);
+            out[2 * t0] = relu_pack(acc0, 0);
+            out[2 * t0 + 1] = relu_pack(acc0, 1);
+            out[2 * t1] = relu_pack(acc1, 0);
+            out[2 * t1 + 1] = relu_pack(acc1, 1);
         }
-        __builtin_amdgcn_sched_barrier(0);  // do not hoist all four tiles' A operands (128 registers) above the first MFMA
+        __builtin_amdgcn_sched_barrier(0);  // keep the second tile pair's A operands below the first pair's MFMAs
     }
 }
 
-// Transposed operand form of a 128-unit matrix held as packs X[st][K-step]: multiply with the identity on the matrix
-// core.  D = X[st] (rows = samples, k = units of tile ut) x Id (k -> column unit)  =>  lane = unit, registers = samples.
-__device__ __forceinline__ void tstore_hidden(const half8 (&X)[2][8], half8* __restrict__ dst, size_t slot_stride, int lane) {
+// Transposed operand form of a 128-unit matrix of one 32-sample tile (st) held as packs X[K-step]: multiply with the
+// identity on the matrix core.  D = X (rows = samples, k = units of tile ut) x Id (k -> column unit)  =>  lane = unit,
+// registers = samples.
+__device__ __forceinline__ void tstore_hidden(const half8 (&X)[8], half8* __restrict__ dst, size_t slot_stride, int lane, int st) {
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const int c = lane & 31, h = lane >> 5;
     half8 id[2];
@@ -255,16 +257,13 @@ __device__ __forceinline__ void tstore_hidden(const half8 (&X)[2][8], half8* __r
 #pragma unroll
         for (int j = 0; j < 8; ++j) id[s][j] = (rho_(8 * s + j, h) == c) ? (_Float16)1.0f : (_Float16)0.0f;
 #pragma unroll
-    for (int ut = 0; ut < 4; ++ut)
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            f32x16p acc = zero;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[st][2 * ut], id[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[st][2 * ut + 1], id[1], acc, 0, 0, 0);
-            dst[ut * slot_stride + (2 * st) * 64] = plain_pack(acc, 0);
-            dst[ut * slot_stride + (2 * st + 1) * 64] = plain_pack(acc, 1);
-            if (st == 1) __builtin_amdgcn_sched_barrier(0);  // keep the unrolled tiles from piling up live accumulators
-        }
+    for (int ut = 0; ut < 4; ++ut) {
+        f32x16p acc = zero;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut], id[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut + 1], id[1], acc, 0, 0, 0);
+        dst[ut * slot_stride + (2 * st) * 64 + lane] = plain_pack(acc, 0);
+        dst[ut * slot_stride + (2 * st + 1) * 64 + lane] = plain_pack(acc, 1);
+    }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -302,7 +301,8 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    const int g = blockIdx.x * (kPpoBlock / 64) + (threadIdx.x >> 6);
+    // wave-uniform group index in a scalar register: the 25+ scratch-slot addresses become scalar bases + one lane offset
+    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * (kPpoBlock / 64) + (threadIdx.x >> 6));
     if (g >= a.G) return;  // whole wave
     PPO_TICK(a, 1);
     const int b = a.idx[g * 64 + lane];
@@ -321,6 +321,8 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
         stash[5 * kPpoBlock] = a.adv[b];
         stash[6 * kPpoBlock] = a.ret[b];
     }
+    const float* stash_base = reinterpret_cast<const float*>(W + D::kImage) + (threadIdx.x & ~63);  // this wave's 64 slots
+    float wsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // per-wave sums: d log_std[4] / B, loss statistics
     const double acc_s1 = a.acc[0], acc_s2 = a.acc[1];
     float log_std_v[4];
     {
@@ -330,7 +332,7 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
     }
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const size_t slot_stride = (size_t)a.G * 256;
-    half8* tb = a.tbuf + ((size_t)net * D::kSlots * a.G + g) * 256 + lane;  // slot 0, this group, kk = 0
+    half8* tb = a.tbuf + ((size_t)net * D::kSlots * a.G + g) * 256;  // slot 0, this group, kk = 0 (scalar); + lane at each use
 
     // ---- layer-1 operand (input k = 16 s + 8 h + j; input L = constant 1), as in policy_forward
     half8 in1[2][KS1];
@@ -353,149 +355,138 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
             in1[1][s] = sat_pack(t1);
         }
     }
-    // transposed inputs: column unit = input index
+    // ---- the wave's 64 samples go through the networks as two 32-sample tiles, one after the other: every MFMA covers 32
+    // samples anyway, and half the activations / deltas / masks live at a time keeps the kernel out of scratch memory
+    // (a scratch reload would wait for all outstanding transposed-operand stores: same in-order counter)
+    const bool valid = h == 0;  // lanes 0..31 carry the tile's per-sample scalars (mean / value / loss gradients)
+#pragma unroll 1
+    for (int et = 0; et < 2; ++et) {
+        half8 in[KS1];
 #pragma unroll
-    for (int ut = 0; ut < D::kIT; ++ut)
+        for (int s = 0; s < KS1; ++s) in[s] = et ? in1[1][s] : in1[0][s];
+        PPO_TICK(a, 2);
+        // transposed inputs: column unit = input index
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
+        for (int ut = 0; ut < D::kIT; ++ut) {
             f32x16p acc = zero;
 #pragma unroll
             for (int s = 0; s < KS1; ++s) {
                 half8 id;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) id[j] = (16 * s + 8 * h + j == 32 * ut + c) ? (_Float16)1.0f : (_Float16)0.0f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(in1[st][s], id, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(in[s], id, acc, 0, 0, 0);
             }
-            tb[(D::kSlotX0 + ut) * slot_stride + (2 * st) * 64] = plain_pack(acc, 0);
-            tb[(D::kSlotX0 + ut) * slot_stride + (2 * st + 1) * 64] = plain_pack(acc, 1);
+            tb[(D::kSlotX0 + ut) * slot_stride + (2 * et) * 64 + lane] = plain_pack(acc, 0);
+            tb[(D::kSlotX0 + ut) * slot_stride + (2 * et + 1) * 64 + lane] = plain_pack(acc, 1);
+        }
+        // ---- forward
+        uint32_t m1[2], m2[2], m3[2];
+        half8 x[8], y[8];
+        mlp_layer<KS1, false>(W, lane, in, x, m1);
+        PPO_TICK(a, 3);
+        tstore_hidden(x, tb + D::kSlotH1 * slot_stride, slot_stride, lane, et);
+        PPO_TICK(a, 4);
+        mlp_layer<8, false>(W + P::kOff2, lane, x, y, m2);
+        PPO_TICK(a, 5);
+        tstore_hidden(y, tb + D::kSlotH2 * slot_stride, slot_stride, lane, et);
+        PPO_TICK(a, 6);
+        mlp_layer<8, false>(W + P::kOff3, lane, y, x, m3);  // x = h3
+        PPO_TICK(a, 7);
+        tstore_hidden(x, tb + D::kSlotH3 * slot_stride, slot_stride, lane, et);
+        PPO_TICK(a, 8);
+        float out4[4];  // rows 0..3 of the output tile: registers 0..3 of lanes 0..31 (sample 32 et + lane)
+        {
+            f32x16p acc = zero;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[P::kOff4 + s * 64 + lane], x[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out4[r] = acc[r];
         }
 
-    // ---- forward
-    PPO_TICK(a, 2);
-    uint32_t m1[2][2], m2[2][2], m3[2][2];
-    half8 x[2][8], y[2][8];
-    mlp_layer<KS1, false>(W, lane, in1, x, m1);
-    PPO_TICK(a, 3);
-    tstore_hidden(x, tb + D::kSlotH1 * slot_stride, slot_stride, lane);
-    PPO_TICK(a, 4);
-    mlp_layer<8, false>(W + P::kOff2, lane, x, y, m2);
-    PPO_TICK(a, 5);
-    tstore_hidden(y, tb + D::kSlotH2 * slot_stride, slot_stride, lane);
-    PPO_TICK(a, 6);
-    mlp_layer<8, false>(W + P::kOff3, lane, y, x, m3);  // x = h3
-    PPO_TICK(a, 7);
-    tstore_hidden(x, tb + D::kSlotH3 * slot_stride, slot_stride, lane);
-    PPO_TICK(a, 8);
-    float out4[4];
-    {
-        f32x16p acc0 = zero, acc1 = zero;
+        // ---- per-sample loss gradients (x B; the 1/B of the batch means is applied in phase B)
+        const float* st_ = stash_base + 32 * et + c;  // the parked per-sample values of sample 32 et + c
+        float dout[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (net == 0) {
+            const float act[4] = {st_[0 * kPpoBlock], st_[1 * kPpoBlock], st_[2 * kPpoBlock], st_[3 * kPpoBlock]};
+            const float old_logp_v = st_[4 * kPpoBlock], adv_v = st_[5 * kPpoBlock];
+            float z[4], inv_std[4], logp = 0.0f;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const half8 w = W[P::kOff4 + s * 64 + lane];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x[0][s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x[1][s], acc1, 0, 0, 0);
-        }
+            for (int k = 0; k < 4; ++k) {
+                const float ls = log_std_v[k];
+                inv_std[k] = __expf(-ls);
+                z[k] = (act[k] - out4[k]) * inv_std[k];
+                logp += -0.5f * z[k] * z[k] - ls - 0.9189385332046727f;
+            }
+            const float log_ratio = valid ? logp - old_logp_v : 0.0f;
+            const float ratio = __expf(log_ratio);
+            // SB3: advantages = (adv - mean) / (std + 1e-8), unbiased std over the minibatch
+            const double amean = acc_s1 / a.B;
+            const double avar = fmax((acc_s2 - a.B * amean * amean) / (a.B > 1 ? a.B - 1 : 1), 0.0);
+            const float A = valid ? (adv_v - (float)amean) * (float)(1.0 / (sqrt(avar) + 1e-8)) : 0.0f;
+            const bool flows = A >= 0.0f ? (ratio <= 1.0f + a.clip) : (ratio >= 1.0f - a.clip);
+            const float gl = (flows && valid) ? -A * ratio : 0.0f;  // d loss / d logp
+            float dls[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float lo, hi;
-            swap32(acc0[r], acc1[r], lo, hi);
-            out4[r] = lo;  // rows 0..3 of this lane's sample
+            for (int k = 0; k < 4; ++k) {
+                dout[k] = gl * z[k] * inv_std[k];
+                dls[k] = gl * (z[k] * z[k] - 1.0f);
+            }
+            const float scale = 1.0f / (float)a.B;
+            const float clipped_ratio = fminf(fmaxf(ratio, 1.0f - a.clip), 1.0f + a.clip);
+            float sums[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sums[k] = wave_sum(dls[k]) * scale;
+            sums[4] = wave_sum(valid ? -fminf(A * ratio, A * clipped_ratio) : 0.0f);
+            sums[5] = wave_sum(valid ? (ratio - 1.0f) - log_ratio : 0.0f);
+            sums[6] = wave_sum(valid && fabsf(ratio - 1.0f) > a.clip ? 1.0f : 0.0f);
+            sums[7] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wsum[k] += sums[k];
+        } else {
+            const float err = valid ? out4[0] - st_[6 * kPpoBlock] : 0.0f;
+            dout[0] = a.vf_coef * 2.0f * err;  // vf_coef * d mse / d v  (x B)
+            wsum[4] += wave_sum(err * err);
         }
-    }
 
-    // ---- per-sample loss gradients (x B; the 1/B of the batch means is applied in phase B)
-    float dout[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (net == 0) {
-        const float act[4] = {stash[0 * kPpoBlock], stash[1 * kPpoBlock], stash[2 * kPpoBlock], stash[3 * kPpoBlock]};
-        const float old_logp_v = stash[4 * kPpoBlock], adv_v = stash[5 * kPpoBlock];
-        float z[4], inv_std[4], logp = 0.0f;
+        PPO_TICK(a, 9);
+        // ---- output deltas as a B operand (k-slot (h, j) = output unit 8 h + j: lanes 0..31 hold units 0..7) and transposed
+        half8 d4;
+        {
+            float v[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float ls = log_std_v[k];
-            inv_std[k] = __expf(-ls);
-            z[k] = (act[k] - out4[k]) * inv_std[k];
-            logp += -0.5f * z[k] * z[k] - ls - 0.9189385332046727f;
-        }
-        const float log_ratio = logp - old_logp_v;
-        const float ratio = __expf(log_ratio);
-        // SB3: advantages = (adv - mean) / (std + 1e-8), unbiased std over the minibatch
-        const double amean = acc_s1 / a.B;
-        const double avar = fmax((acc_s2 - a.B * amean * amean) / (a.B > 1 ? a.B - 1 : 1), 0.0);
-        const float A = (adv_v - (float)amean) * (float)(1.0 / (sqrt(avar) + 1e-8));
-        const bool flows = A >= 0.0f ? (ratio <= 1.0f + a.clip) : (ratio >= 1.0f - a.clip);
-        const float gl = flows ? -A * ratio : 0.0f;  // d loss / d logp
-        float dls[4];
+            for (int j = 0; j < 8; ++j) v[j] = (j < 4 && valid) ? dout[j < 4 ? j : 0] : 0.0f;
+            d4 = sat_pack(v);
+            half8 id;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            dout[k] = gl * z[k] * inv_std[k];
-            dls[k] = gl * (z[k] * z[k] - 1.0f);
+            for (int j = 0; j < 8; ++j) id[j] = (8 * h + j == c) ? (_Float16)1.0f : (_Float16)0.0f;
+            const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(d4, id, zero, 0, 0, 0);
+            tb[D::kSlotD4 * slot_stride + (2 * et) * 64 + lane] = plain_pack(acc, 0);
+            tb[D::kSlotD4 * slot_stride + (2 * et + 1) * 64 + lane] = plain_pack(acc, 1);
         }
-        const float scale = 1.0f / (float)a.B;
-        const float clipped_ratio = fminf(fmaxf(ratio, 1.0f - a.clip), 1.0f + a.clip);
-        float sums[8];
+        // ---- backward: d3 = (W4^T d4) * relu'(z3);  d2 = (W3^T d3) * relu'(z2);  d1 = (W2^T d2) * relu'(z1)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sums[k] = wave_sum(dls[k]) * scale;
-        sums[4] = wave_sum(-fminf(A * ratio, A * clipped_ratio));
-        sums[5] = wave_sum((ratio - 1.0f) - log_ratio);
-        sums[6] = wave_sum(fabsf(ratio - 1.0f) > a.clip ? 1.0f : 0.0f);
-        sums[7] = 0.0f;
-        if (lane == 0) {
-            float4* wo = reinterpret_cast<float4*>(a.wave_out + (size_t)g * 8);
-            wo[0] = make_float4(sums[0], sums[1], sums[2], sums[3]);
-            wo[1] = make_float4(sums[4], sums[5], sums[6], sums[7]);
+        for (int t = 0; t < 4; ++t) {
+            const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[D::kOffT4 + t * 64 + lane], d4, zero, 0, 0, 0);
+            x[2 * t] = mask_pack(acc, m3[t >> 1], t, 0);
+            x[2 * t + 1] = mask_pack(acc, m3[t >> 1], t, 1);
         }
-    } else {
-        const float err = out4[0] - stash[6 * kPpoBlock];
-        dout[0] = a.vf_coef * 2.0f * err;  // vf_coef * d mse / d v  (x B)
-        const float vl = wave_sum(err * err);
-        if (lane == 0) {
-            float4* wo = reinterpret_cast<float4*>(a.wave_out + ((size_t)a.G + g) * 8);
-            wo[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            wo[1] = make_float4(vl, 0.0f, 0.0f, 0.0f);
-        }
+        PPO_TICK(a, 10);
+        tstore_hidden(x, tb + D::kSlotD3 * slot_stride, slot_stride, lane, et);
+        PPO_TICK(a, 11);
+        mlp_layer<8, true>(W + D::kOffT3, lane, x, y, m2);
+        PPO_TICK(a, 12);
+        tstore_hidden(y, tb + D::kSlotD2 * slot_stride, slot_stride, lane, et);
+        PPO_TICK(a, 13);
+        mlp_layer<8, true>(W + D::kOffT2, lane, y, x, m1);
+        PPO_TICK(a, 14);
+        tstore_hidden(x, tb + D::kSlotD1 * slot_stride, slot_stride, lane, et);
+        PPO_TICK(a, 15);
     }
-
-    PPO_TICK(a, 9);
-    // ---- output deltas as a B operand (k-slot (h, j) = output unit 8 h + j) and in transposed form
-    half8 d4[2];
-    {
-        float t0[8], t1[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) swap32(j < 4 ? dout[j < 4 ? j : 0] : 0.0f, 0.0f, t0[j], t1[j]);
-        d4[0] = sat_pack(t0);
-        d4[1] = sat_pack(t1);
-        half8 id;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) id[j] = (8 * h + j == c) ? (_Float16)1.0f : (_Float16)0.0f;
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(d4[st], id, zero, 0, 0, 0);
-            tb[D::kSlotD4 * slot_stride + (2 * st) * 64] = plain_pack(acc, 0);
-            tb[D::kSlotD4 * slot_stride + (2 * st + 1) * 64] = plain_pack(acc, 1);
-        }
+    if (lane == 0) {  // per-wave sums of both tiles (reduced by the norm kernel)
+        float4* wo = reinterpret_cast<float4*>(a.wave_out + ((size_t)net * a.G + g) * 8);
+        wo[0] = make_float4(wsum[0], wsum[1], wsum[2], wsum[3]);
+        wo[1] = make_float4(wsum[4], wsum[5], wsum[6], wsum[7]);
     }
-    // ---- backward: d3 = (W4^T d4) * relu'(z3);  d2 = (W3^T d3) * relu'(z2);  d1 = (W2^T d2) * relu'(z1)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const half8 w = W[D::kOffT4 + t * 64 + lane];
-        const f32x16p acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, d4[0], zero, 0, 0, 0);
-        const f32x16p acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, d4[1], zero, 0, 0, 0);
-        x[0][2 * t] = mask_pack(acc0, m3[0][t >> 1], t, 0);
-        x[0][2 * t + 1] = mask_pack(acc0, m3[0][t >> 1], t, 1);
-        x[1][2 * t] = mask_pack(acc1, m3[1][t >> 1], t, 0);
-        x[1][2 * t + 1] = mask_pack(acc1, m3[1][t >> 1], t, 1);
-    }
-    PPO_TICK(a, 10);
-    tstore_hidden(x, tb + D::kSlotD3 * slot_stride, slot_stride, lane);
-    PPO_TICK(a, 11);
-    mlp_layer<8, true>(W + D::kOffT3, lane, x, y, m2);
-    PPO_TICK(a, 12);
-    tstore_hidden(y, tb + D::kSlotD2 * slot_stride, slot_stride, lane);
-    PPO_TICK(a, 13);
-    mlp_layer<8, true>(W + D::kOffT2, lane, y, x, m1);
-    PPO_TICK(a, 14);
-    tstore_hidden(x, tb + D::kSlotD1 * slot_stride, slot_stride, lane);
-    PPO_TICK(a, 15);
 }
 
 // ---- phase B: weight gradients -------------------------------------------------------------------------------------------
