@@ -3,8 +3,8 @@
 //   Quadcopter3DVec (hover, float64)  Q3 cell 6      Quadcopter3DVecGates (float32)  Q3 cell 14      f_func  Q3 cell 2
 //
 // One lane = one env.  The reference's only state is the row-major `states[N][16]` array, which is also what step_wait
-// returns, so HBM holds exactly that array (64 B / 128 B rows, moved as 16-byte vectors; the 4 / 8 vector accesses of a
-// wave cover whole 128-byte lines between them) plus step / target / episode counters.  Both envs are HBM-bound in
+// returns, so HBM holds exactly that array (64 B / 128 B rows; the step kernel moves a block's rows as one contiguous
+// slab of coalesced 16-byte accesses and transposes through LDS) plus step / target / episode counters.  Both envs are HBM-bound in
 // the limit (about 230 B resp. 420 B per env-step against ~0.6 k resp. ~2 k flops); at 65 536 envs a launch is
 // latency-bound like the race env's, which is what q3_step_many (state in registers across K steps) removes.
 // Arithmetic follows the lambdified f_func term by term (-ffp-contract=off), in the element type of the reference's
@@ -326,21 +326,85 @@ __device__ __forceinline__ void q3_store(const Q3Buffers<T>& B, int i, const Q3E
     B.episode[i] = e.episode;
 }
 
+// Block-cooperative row I/O for the per-step kernel: the block's 256 rows are one contiguous slab (16 / 32 KB); it is moved
+// with fully coalesced 16-byte accesses (consecutive lanes -> consecutive addresses) and transposed to lane = row through
+// LDS (row stride padded by 16 bytes against bank conflicts).  Measured at 1 Mi envs against per-lane row accesses: see
+// DESIGN.md section 10.
+template <typename T>
+struct RowTile {
+    using V = typename Vec16<T>::type;
+    static constexpr int kCh = Vec16<T>::kPerRow;      // 16-byte chunks per row
+    static constexpr int kStride = kCh + 1;            // LDS row stride in chunks (padded)
+    static constexpr int kLdsChunks = kQ3Block * kStride;
+};
+
+template <typename T>
+__device__ __forceinline__ void tile_load_rows(const T* __restrict__ base, int row0, int rows, typename RowTile<T>::V* lds, T s[16]) {
+    using R = RowTile<T>;
+    using V = typename R::V;
+    const V* src = reinterpret_cast<const V*>(base + (size_t)16 * row0);
+#pragma unroll
+    for (int q = 0; q < R::kCh; ++q) {
+        const int cidx = q * kQ3Block + threadIdx.x;   // chunk index within the slab
+        if (cidx < rows * R::kCh) lds[(cidx / R::kCh) * R::kStride + (cidx % R::kCh)] = src[cidx];
+    }
+    __syncthreads();
+    V v[R::kCh];
+#pragma unroll
+    for (int k = 0; k < R::kCh; ++k) v[k] = lds[threadIdx.x * R::kStride + k];
+    memcpy(s, v, sizeof(v));
+}
+
+// writes the block's rows to up to two destinations (the state array and the caller's states_out)
+template <typename T>
+__device__ __forceinline__ void tile_store_rows(T* __restrict__ dst0, T* __restrict__ dst1, int row0, int rows,
+                                                typename RowTile<T>::V* lds, const T s[16]) {
+    using R = RowTile<T>;
+    using V = typename R::V;
+    V v[R::kCh];
+    memcpy(v, s, sizeof(v));
+#pragma unroll
+    for (int k = 0; k < R::kCh; ++k) lds[threadIdx.x * R::kStride + k] = v[k];
+    __syncthreads();
+    V* d0 = reinterpret_cast<V*>(dst0 + (size_t)16 * row0);
+    V* d1 = dst1 ? reinterpret_cast<V*>(dst1 + (size_t)16 * row0) : nullptr;
+#pragma unroll
+    for (int q = 0; q < R::kCh; ++q) {
+        const int cidx = q * kQ3Block + threadIdx.x;
+        if (cidx < rows * R::kCh) {
+            const V x = lds[(cidx / R::kCh) * R::kStride + (cidx % R::kCh)];
+            d0[cidx] = x;
+            if (d1) d1[cidx] = x;
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kQ3Block) void q3_step_kernel(Q3Params P, Q3Buffers<T> B, const float4* __restrict__ actions,
                                                            T* __restrict__ states_out, T* __restrict__ rew_out,
                                                            uint8_t* __restrict__ done_out,
                                                            uint8_t* __restrict__ trunc_out) {
-    const int i = blockIdx.x * kQ3Block + threadIdx.x;
-    if (i >= P.n) return;
+    __shared__ typename RowTile<T>::V lds[RowTile<T>::kLdsChunks];
+    const int row0 = blockIdx.x * kQ3Block;
+    const int rows = min(kQ3Block, P.n - row0);
+    const int i = row0 + threadIdx.x;
+    const bool active = i < P.n;
+    const int ii = active ? i : row0;  // ragged-tail lanes shadow the block's first env (they take part in the barriers)
     Q3Env<T> e;
-    q3_load(B, i, e);
-    const float4 a = actions[i];
+    tile_load_rows<T>(B.states, row0, rows, lds, e.s);
+    if (!active) load_row<T>(B.states, ii, e.s);
+    e.target = B.target[ii];
+    e.steps = B.steps[ii];
+    e.episode = B.episode[ii];
+    const float4 a = actions[ii];
     const float u[4] = {a.x, a.y, a.z, a.w};
     bool done, trunc;
-    const T reward = q3_step_env(P, i, e, u, done, trunc);
-    q3_store(B, i, e);
-    if (states_out) store_row<T>(states_out, i, e.s);
+    const T reward = q3_step_env(P, ii, e, u, done, trunc);
+    tile_store_rows<T>(B.states, states_out, row0, rows, lds, e.s);
+    if (!active) return;
+    B.target[i] = e.target;
+    B.steps[i] = e.steps;
+    B.episode[i] = e.episode;
     if (rew_out) rew_out[i] = reward;
     if (done_out) done_out[i] = done ? 1 : 0;
     if (trunc_out) trunc_out[i] = trunc ? 1 : 0;

@@ -156,3 +156,31 @@ def test_ppo_fused_collect_matches_buffer_contract():
     model.train()
     model.learn(8192 * 64 * 40, log_every=0)
     assert model.stats["ep_len_mean"] > 1.5 * first["ep_len_mean"], (first, model.stats)
+
+
+def test_ppo_native_update_learns():
+    """PPO with the fused collect AND the matrix-core minibatch update (qr_ppo_minibatch): parameters stay finite, the
+    torch modules alias the flat parameter vector the kernels update, and a short run improves survival and reward."""
+    from optimal_quad_control_rl_amd import Quadcopter3DGatesINDI, square_track
+    from optimal_quad_control_rl_amd.ppo import PPO
+
+    env = Quadcopter3DGatesINDI(8192, *square_track(), gates_ahead=1, infos_mode="none", seed=1)
+    model = PPO(env, n_steps=32, n_epochs=10, batch_size=8192 * 32 // 16, learning_rate=3e-4, gamma=0.99, seed=1,
+                fused_collect=True, native_update=True)
+    theta0 = model._updater.theta.clone()
+    model.collect()
+    first = dict(model.stats)
+    model.train()
+    assert model.stats["updates"] == 160 and model._updater.step == 160
+    assert torch.isfinite(model._updater.theta).all() and not torch.equal(model._updater.theta, theta0)
+    assert model.policy.pi[0].weight.data_ptr() == model._updater.theta.data_ptr()
+    assert 0.0 < model.stats["clip_fraction"] < 0.5 and 0.0 < model.stats["approx_kl"] < 0.1
+    model.learn(8192 * 32 * 150, log_every=0)
+    # the untrained policy crashes within a few hundred steps (about -10 per ~400 steps); training must improve on that
+    assert model.stats["reward_per_step"] > first["reward_per_step"] + 0.005, (first, model.stats)
+    assert model.stats["ep_len_mean"] > 450, model.stats
+    assert torch.isfinite(model._updater.theta).all()
+    # the deterministic policy the kernels trained is what torch's predict() evaluates
+    obs = env.reset_device()
+    a = model.predict(obs)
+    assert a.shape == (8192, 4) and torch.isfinite(a).all() and float(a.abs().max()) <= 1.0
