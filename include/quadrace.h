@@ -201,6 +201,12 @@ int qr_ppo_minibatch(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* ad
                      const int32_t* idx_dev, int32_t B, float clip, float vf_coef, float ent_coef, float max_grad_norm,
                      float lr, float beta1, float beta2, float eps, int32_t adam_step, float* stats_dev, void* stream);
 
+/* data-parallel training (one process per GPU): each rank computes qr_ppo_grad on its own rows, the caller averages the
+ * gradients across ranks (a single all-reduce of num_params floats -- ~250 KB -- over RCCL), then every rank applies the
+ * identical update: global-norm clip, Adam, operand re-pack.  grad_dev is consumed (cleared). */
+int qr_ppo_apply(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* adam_v_dev, float* grad_dev, float max_grad_norm,
+                 float lr, float beta1, float beta2, float eps, int32_t adam_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

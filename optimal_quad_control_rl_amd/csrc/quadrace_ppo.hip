@@ -642,6 +642,15 @@ __global__ void __launch_bounds__(256) ppo_adam_kernel(float* __restrict__ theta
     grad[i] = 0.0f;
 }
 
+// squared norm of an externally supplied gradient (data-parallel training: the all-reduced gradient comes back from the caller)
+__global__ void __launch_bounds__(1024) ppo_sqnorm_kernel(const float* __restrict__ grad, int n, double* __restrict__ acc) {
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const double g = i < n ? (double)grad[i] : 0.0;
+    double sq = g * g, unused = 0.0;
+    block_sum2_f64<1024>(sq, unused);
+    if (threadIdx.x == 0) unsafeAtomicAdd(acc + 2, sq);
+}
+
 }  // namespace qr
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -857,6 +866,26 @@ int qr_ppo_minibatch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam
         PPO_HIP(hipGetLastError());
         return PpoOps<L>::pack(p, theta_dev, st);
     });
+}
+
+// Data-parallel training: every rank calls qr_ppo_grad on its shard of the minibatch, the caller averages the gradients
+// (one all-reduce of num_params floats over RCCL), then every rank applies the same update with qr_ppo_apply.
+int qr_ppo_apply(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_dev, float* grad_dev, float max_grad_norm, float lr,
+                 float beta1, float beta2, float eps, int32_t adam_step, void* stream) {
+    if (!p || !theta_dev || !adam_m_dev || !adam_v_dev || !grad_dev || adam_step < 1) return ppofail(QR_E_INVALID, "qr_ppo_apply: bad argument");
+    PPO_HIP(hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    const float bc1 = 1.0f - powf(beta1, (float)adam_step);
+    const float bc2s = sqrtf(1.0f - powf(beta2, (float)adam_step));
+    PPO_HIP(hipMemsetAsync(p->d_acc, 0, 4 * sizeof(double), st));
+    hipLaunchKernelGGL(qr::ppo_sqnorm_kernel, dim3((p->num_params + 1023) / 1024), dim3(1024), 0, st, grad_dev, p->num_params, p->d_acc);
+    hipLaunchKernelGGL(qr::ppo_adam_kernel, dim3((p->num_params + 255) / 256), dim3(256), 0, st, theta_dev, adam_m_dev, adam_v_dev,
+                       grad_dev, p->num_params, p->d_acc, max_grad_norm, lr, beta1, beta2, eps, bc1, bc2s);
+    PPO_HIP(hipGetLastError());
+    const int rc = dispatch_L(p->L, [&](auto Lc) { return PpoOps<decltype(Lc)::value>::pack(p, theta_dev, st); });
+    if (rc != QR_OK) return rc;
+    PPO_HIP(hipMemsetAsync(p->d_acc, 0, 4 * sizeof(double), st));
+    return QR_OK;
 }
 
 }  // extern "C"

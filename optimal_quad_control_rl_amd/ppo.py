@@ -16,6 +16,7 @@ import math
 import time
 
 import torch
+import torch.distributed
 from torch import nn
 
 
@@ -137,7 +138,21 @@ class MfmaPpoUpdater:
                                             self._p(self.stats) if stats else None, self._stream()))
         return g
 
+    def apply(self, grad, lr, max_grad_norm=0.5):
+        """Clip `grad` (flat, consumed) to the global norm and take one Adam step -- the second half of a data-parallel
+        update: `g = up.grad(...); dist.all_reduce(g); g /= world; up.apply(g, lr)`."""
+        assert grad.is_cuda and grad.dtype == torch.float32 and grad.is_contiguous() and grad.numel() == self.theta.numel()
+        self.step += 1
+        self._lib.check(self._L.qr_ppo_apply(self._h, self._p(self.theta), self._p(self.m), self._p(self.v), self._p(grad),
+                                             max_grad_norm, lr, self.betas[0], self.betas[1], self.eps, self.step, self._stream()))
+
     def minibatch(self, obs, act, old_lp, adv, ret, idx, lr, clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5):
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            # data parallel: every rank holds the same parameters and its own envs; average the 63 k-float gradient
+            g = self.grad(obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef, stats=True)
+            torch.distributed.all_reduce(g)
+            g /= torch.distributed.get_world_size()
+            return self.apply(g, lr, max_grad_norm)
         self.step += 1
         self._lib.check(self._L.qr_ppo_minibatch(self._h, self._p(self.theta), self._p(self.m), self._p(self.v), self._p(obs),
                                                  self._p(act), self._p(old_lp), self._p(adv), self._p(ret), self._p(idx),

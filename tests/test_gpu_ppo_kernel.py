@@ -175,6 +175,23 @@ def test_full_epoch_tracks_torch():
     assert torch.allclose(pol.log_std, ref.log_std, atol=2e-3)
 
 
+def test_grad_then_apply_equals_minibatch():
+    """The data-parallel split (qr_ppo_grad -> [all-reduce] -> qr_ppo_apply) takes the same step as qr_ppo_minibatch."""
+    L, rows, B = 17, 8192, 2048
+    pol_a, _, up_a, obs, act, old_lp, adv, ret = _setup(L, rows, seed=21)
+    pol_b, _, up_b, *_ = _setup(L, rows, seed=21)
+    assert torch.equal(up_a.theta, up_b.theta)
+    perm = torch.randperm(rows, device=obs.device).to(torch.int32)
+    for k in range(3):
+        idx = perm[k * B:(k + 1) * B].contiguous()
+        up_a.minibatch(obs, act, old_lp, adv, ret, idx, lr=3e-4)
+        g = up_b.grad(obs, act, old_lp, adv, ret, idx)
+        up_b.apply(g, lr=3e-4)
+    assert up_a.step == up_b.step == 3
+    assert torch.allclose(up_a.theta, up_b.theta, rtol=0, atol=2e-7), float((up_a.theta - up_b.theta).abs().max())
+    assert torch.allclose(up_a.m, up_b.m, rtol=1e-5, atol=1e-9)
+
+
 def test_argument_validation():
     from optimal_quad_control_rl_amd import _lib
 
