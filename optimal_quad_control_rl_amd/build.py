@@ -31,9 +31,9 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libquadrace.so cannot be built")
 
 
-# quadrace_ppo.hip keeps far more matrix-core accumulators live than the env kernels: let the compiler use the AGPR half of
-# the register file for them (with the VGPR form it spills 3x as much)
-NO_VGPR_FORM = {"quadrace_ppo.hip"}
+# sources that should NOT get -amdgpu-mfma-vgpr-form (none at present: since phase A of quadrace_ppo.hip works on one
+# 32-sample tile at a time its accumulators fit in the VGPR half too, which saves ~1 900 v_accvgpr_read per wave)
+NO_VGPR_FORM = set()
 OBJ_DIR = os.path.join(PKG, "_obj")   # per-source objects (git- and gpurun-ignored): only stale sources are recompiled
 
 

@@ -197,18 +197,35 @@ __device__ __forceinline__ half8 plain_pack(const f32x16p& acc, int s) {
     for (int j = 0; j < 8; ++j) b[j] = (_Float16)acc[8 * s + j];
     return b;
 }
-// mask word layout: m[t >> 1] bit 16 * (t & 1) + r  <->  accumulator register r of output tile t
+// ReLU masks as bits, built and applied on packed f16 pairs.  One 32-bit word per pair of output tiles: the dword d of
+// pack s of tile t (accumulator registers 8 s + 2 d and 8 s + 2 d + 1) owns bit  sh = 8 (t & 1) + 4 s + d  for its low half
+// and bit 16 + sh for its high half.
+typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+typedef unsigned short ushort2p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t relu_bits(uint32_t word, const half8& relu_packed, int t, int s) {
+    const u32x4p p = __builtin_bit_cast(u32x4p, relu_packed);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        // relu output >= 0: its f16 bit pattern is non-zero iff the unit is active; min(bits, 1) per half -> 0 / 1
+        const uint32_t bits = p[d];
+        const ushort2p one = {1, 1};
+        const ushort2p halves = __builtin_bit_cast(ushort2p, bits);
+        const uint32_t on = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(halves, one));  // v_pk_min_u16
+        word |= on << (8 * (t & 1) + 4 * s + d);
+    }
+    return word;
+}
 __device__ __forceinline__ half8 mask_pack(const f32x16p& acc, uint32_t word, int t, int s) {
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = ((word >> (16 * (t & 1) + 8 * s + j)) & 1u) ? acc[8 * s + j] : 0.0f;
-    return sat_pack(v);
-}
-__device__ __forceinline__ uint32_t relu_bits(const f32x16p& acc, int t) {
-    uint32_t w = 0;
+    for (int j = 0; j < 8; ++j) v[j] = acc[8 * s + j];
+    u32x4p p = __builtin_bit_cast(u32x4p, sat_pack(v));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) w |= (acc[r] > 0.0f ? 1u : 0u) << (16 * (t & 1) + r);
-    return w;
+    for (int d = 0; d < 4; ++d) {
+        const uint32_t on = (word >> (8 * (t & 1) + 4 * s + d)) & 0x00010001u;
+        p[d] &= on * 0xFFFFu;  // 0x0001 -> 0xFFFF in each half (no carry between the halves)
+    }
+    return __builtin_bit_cast(half8, p);
 }
 
 // One 128-unit layer for ONE 32-sample tile: in[KS] -> out[8].  Forward (BWD = false): out = relu(acc) packed,
@@ -235,11 +252,14 @@ __device__ __forceinline__ void mlp_layer(const half8* __restrict__ W, int lane,
             out[2 * t1] = mask_pack(acc1, mask[tp], t1, 0);
             out[2 * t1 + 1] = mask_pack(acc1, mask[tp], t1, 1);
         } else {
-            mask[tp] = relu_bits(acc0, t0) | relu_bits(acc1, t1);
             out[2 * t0] = relu_pack(acc0, 0);
             out[2 * t0 + 1] = relu_pack(acc0, 1);
             out[2 * t1] = relu_pack(acc1, 0);
             out[2 * t1 + 1] = relu_pack(acc1, 1);
+            uint32_t w = relu_bits(0u, out[2 * t0], t0, 0);
+            w = relu_bits(w, out[2 * t0 + 1], t0, 1);
+            w = relu_bits(w, out[2 * t1], t1, 0);
+            mask[tp] = relu_bits(w, out[2 * t1 + 1], t1, 1);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the second tile pair's A operands below the first pair's MFMAs
     }
