@@ -851,8 +851,7 @@ int qr_ppo_grad(qr_ppo* p, const float* theta_dev, const float* obs_dev, const f
     if (!grad_out_dev) return ppofail(QR_E_INVALID, "qr_ppo_grad: null grad_out");
     PPO_HIP(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
-    PPO_HIP(hipMemsetAsync(p->d_grad, 0, (size_t)p->num_params * 4, st));
-    PPO_HIP(hipMemsetAsync(p->d_acc, 0, 4 * sizeof(double), st));
+    PPO_HIP(hipMemsetAsync(p->d_acc, 0, 4 * sizeof(double), st));  // (d_grad is written in full by the norm kernel)
     if (int rc = dispatch_L(p->L, [&](auto Lc) {
             constexpr int L = decltype(Lc)::value;
             if (int r = PpoOps<L>::pack(p, theta_dev, st)) return r;
@@ -860,7 +859,6 @@ int qr_ppo_grad(qr_ppo* p, const float* theta_dev, const float* obs_dev, const f
         }))
         return rc;
     PPO_HIP(hipMemcpyAsync(grad_out_dev, p->d_grad, (size_t)p->num_params * 4, hipMemcpyDeviceToDevice, st));
-    PPO_HIP(hipMemsetAsync(p->d_grad, 0, (size_t)p->num_params * 4, st));
     PPO_HIP(hipMemsetAsync(p->d_acc, 0, 4 * sizeof(double), st));
     return QR_OK;
 }

@@ -58,6 +58,10 @@ def test_no_cpu_fallback():
 
     with pytest.raises(RuntimeError):
         Quadcopter3DVec(4)
+    # ... and so do the policy / PPO-update kernels
+    assert L.qr_policy_create(17, 0, C.byref(h)) == _lib.QR_E_NO_DEVICE
+    assert L.qr_ppo_create(17, 0, 4096, C.byref(h)) == _lib.QR_E_NO_DEVICE
+    assert b"no CPU fallback" in L.qr_last_error()
 
 
 def test_product_never_imports_oracle():
