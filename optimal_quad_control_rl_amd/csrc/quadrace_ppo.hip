@@ -7,7 +7,7 @@
 // 16 k x 120 x 120 GEMMs.  Here one minibatch is six launches:
 //
 //   adv_stats   sum / sum of squares of the minibatch's advantages (SB3 normalises per minibatch; phase A finishes the maths)
-//   phase A     per wave = 64 samples of one net: forward (f16 MFMA chain of quadrace_policy.hpp), per-sample loss
+//   phase A     per wave = one 32-sample tile of one net (8-wave workgroups): forward (f16 MFMA chain of quadrace_policy.hpp), per-sample loss
 //               gradients, backward through the transposed weight images -- activations h_l and deltas d_l never leave
 //               registers in the "lane = sample" form.  Each of them is also emitted in the transposed operand form
 //               (lane = unit, k = sample) by multiplying with an identity operand on the matrix core, and written
@@ -172,7 +172,7 @@ struct PpoBatch {
     const float* theta;      // flat parameters (log_std is read from here)
     const half8* images;     // [2][kImage]
     half8* tbuf;             // [2][kSlots][G][4][64]
-    float* wave_out;         // [2][G][8] per-wave sums: policy waves {d log_std[4] / B, surrogate loss, approx kl, clipped, -},
+    float* wave_out;         // [2][2 G][8] per-wave sums: policy waves {d log_std[4] / B, surrogate loss, approx kl, clipped, -},
                              // value waves {-, -, -, -, squared error, ...}; reduced by the norm kernel (no atomics)
     float* stats;            // [0] sum surrogate loss, [1] sum squared value error, [2] sum approx kl, [3] clipped count
 #ifdef QR_PHASE_TIMING
@@ -185,7 +185,7 @@ struct PpoBatch {
     do {                                                                                                        \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                             \
         if ((a).ticks && (threadIdx.x & 63) == 0)                                                               \
-            (a).ticks[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + (slot)] = clock64(); \
+            (a).ticks[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = clock64(); \
     } while (0)
 #else
 #define PPO_TICK(a, slot) do { } while (0)
@@ -292,8 +292,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Phase A workgroup: 8 waves = 4 sample groups x 2 tiles of 32 samples.  Every MFMA covers 32 samples anyway, so one wave
+// takes ONE tile through both passes of its network: half the live activations / deltas / masks (no scratch memory -- a
+// scratch reload would wait for all outstanding transposed-operand stores: same in-order counter) and two waves per SIMD
+// to overlap each other's matrix-core, LDS and store latencies.  (The 148 KB of operand images allow one workgroup per CU.)
+constexpr int kPpoBlockA = 512;
+constexpr int kStashRows = 256;  // per-sample scalars of the workgroup's 4 x 64 samples, parked in LDS
+
 template <int L>
-__global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
+__global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) {
     using D = PpoDims<L>;
     using P = PolicyDims<L>;
     constexpr int KS1 = P::kSteps1;
@@ -305,43 +312,43 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
         const float4* src = reinterpret_cast<const float4*>(a.images + (size_t)net * D::kImage);
         float4* dst = reinterpret_cast<float4*>(W);
         constexpr int kBatch = 8;
-        for (int base = 0; base < D::kImage; base += kBatch * kPpoBlock) {
+        for (int base = 0; base < D::kImage; base += kBatch * kPpoBlockA) {
             float4 v[kBatch];
 #pragma unroll
             for (int q = 0; q < kBatch; ++q) {
-                const int i = base + q * kPpoBlock + threadIdx.x;
+                const int i = base + q * kPpoBlockA + threadIdx.x;
                 v[q] = src[i < D::kImage ? i : 0];
             }
 #pragma unroll
             for (int q = 0; q < kBatch; ++q) {
-                const int i = base + q * kPpoBlock + threadIdx.x;
+                const int i = base + q * kPpoBlockA + threadIdx.x;
                 if (i < D::kImage) dst[i] = v[q];
             }
         }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    // wave-uniform group index in a scalar register: the 25+ scratch-slot addresses become scalar bases + one lane offset
-    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * (kPpoBlock / 64) + (threadIdx.x >> 6));
+    // wave-uniform indices in scalar registers: the 25+ scratch-slot addresses become scalar bases + one lane offset
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x * 4 + (wave >> 1);   // sample group of this wave
+    const int et = wave & 1;                       // its 32-sample tile: samples 32 et + c (both lane halves: k-slots by h)
     if (g >= a.G) return;  // whole wave
     PPO_TICK(a, 1);
-    const int b = a.idx[g * 64 + lane];
+    const int b = a.idx[g * 64 + 32 * et + c];
     // every global LOAD of this wave is issued here: loads and stores share one in-order counter, so a load issued after the
-    // transposed-operand stores would wait for all of them to drain
-    // (they are parked in the LDS left over beside the operand images until the loss needs them: LDS traffic is counted
-    // separately, and 7 fewer live registers through the forward pass)
-    float* stash = reinterpret_cast<float*>(W + D::kImage) + threadIdx.x;
-    {
+    // transposed-operand stores would wait for all of them to drain.  The per-sample scalars are parked in the LDS left
+    // over beside the operand images until the loss needs them (LDS traffic is counted separately).
+    float* stash = reinterpret_cast<float*>(W + D::kImage) + wave * 32 + c;
+    if (h == 0) {
         const float4 act_v = net == 0 ? reinterpret_cast<const float4*>(a.act)[b] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        stash[0 * kPpoBlock] = act_v.x;
-        stash[1 * kPpoBlock] = act_v.y;
-        stash[2 * kPpoBlock] = act_v.z;
-        stash[3 * kPpoBlock] = act_v.w;
-        stash[4 * kPpoBlock] = a.old_logp[b];
-        stash[5 * kPpoBlock] = a.adv[b];
-        stash[6 * kPpoBlock] = a.ret[b];
+        stash[0 * kStashRows] = act_v.x;
+        stash[1 * kStashRows] = act_v.y;
+        stash[2 * kStashRows] = act_v.z;
+        stash[3 * kStashRows] = act_v.w;
+        stash[4 * kStashRows] = a.old_logp[b];
+        stash[5 * kStashRows] = a.adv[b];
+        stash[6 * kStashRows] = a.ret[b];
     }
-    const float* stash_base = reinterpret_cast<const float*>(W + D::kImage) + (threadIdx.x & ~63);  // this wave's 64 slots
     float wsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // per-wave sums: d log_std[4] / B, loss statistics
     const double acc_s1 = a.acc[0], acc_s2 = a.acc[1];
     float log_std_v[4];
@@ -354,36 +361,24 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
     const size_t slot_stride = (size_t)a.G * 256;
     half8* tb = a.tbuf + ((size_t)net * D::kSlots * a.G + g) * 256;  // slot 0, this group, kk = 0 (scalar); + lane at each use
 
-    // ---- layer-1 operand (input k = 16 s + 8 h + j; input L = constant 1), as in policy_forward
-    half8 in1[2][KS1];
+    // ---- layer-1 operand: lane (c, h) holds inputs k = 16 s + 8 h + j of sample c; input L = constant 1
+    half8 in[KS1];
     {
-        float o[L];
         const float* row = a.obs + (size_t)b * L;
 #pragma unroll
-        for (int k = 0; k < L; ++k) o[k] = row[k];
-#pragma unroll
         for (int s = 0; s < KS1; ++s) {
-            float t0[8], t1[8];
+            float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int k0 = 16 * s + j, k1 = 16 * s + 8 + j;
-                const float x0 = (k0 < L) ? o[k0 < L ? k0 : 0] : (k0 == L ? 1.0f : 0.0f);
-                const float x1 = (k1 < L) ? o[k1 < L ? k1 : 0] : (k1 == L ? 1.0f : 0.0f);
-                swap32(x0, x1, t0[j], t1[j]);
+                const int k = 16 * s + 8 * h + j;
+                const float x = row[k < L ? k : L - 1];
+                v[j] = k < L ? x : (k == L ? 1.0f : 0.0f);
             }
-            in1[0][s] = sat_pack(t0);
-            in1[1][s] = sat_pack(t1);
+            in[s] = sat_pack(v);  // observations can be large or NaN: keep f16 finite
         }
     }
-    // ---- the wave's 64 samples go through the networks as two 32-sample tiles, one after the other: every MFMA covers 32
-    // samples anyway, and half the activations / deltas / masks live at a time keeps the kernel out of scratch memory
-    // (a scratch reload would wait for all outstanding transposed-operand stores: same in-order counter)
     const bool valid = h == 0;  // lanes 0..31 carry the tile's per-sample scalars (mean / value / loss gradients)
-#pragma unroll 1
-    for (int et = 0; et < 2; ++et) {
-        half8 in[KS1];
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) in[s] = et ? in1[1][s] : in1[0][s];
+    {
         PPO_TICK(a, 2);
         // transposed inputs: column unit = input index
 #pragma unroll
@@ -424,11 +419,11 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
         }
 
         // ---- per-sample loss gradients (x B; the 1/B of the batch means is applied in phase B)
-        const float* st_ = stash_base + 32 * et + c;  // the parked per-sample values of sample 32 et + c
+        const float* st_ = stash;  // the parked per-sample values of sample 32 et + c
         float dout[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (net == 0) {
-            const float act[4] = {st_[0 * kPpoBlock], st_[1 * kPpoBlock], st_[2 * kPpoBlock], st_[3 * kPpoBlock]};
-            const float old_logp_v = st_[4 * kPpoBlock], adv_v = st_[5 * kPpoBlock];
+            const float act[4] = {st_[0 * kStashRows], st_[1 * kStashRows], st_[2 * kStashRows], st_[3 * kStashRows]};
+            const float old_logp_v = st_[4 * kStashRows], adv_v = st_[5 * kStashRows];
             float z[4], inv_std[4], logp = 0.0f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -463,7 +458,7 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) wsum[k] += sums[k];
         } else {
-            const float err = valid ? out4[0] - st_[6 * kPpoBlock] : 0.0f;
+            const float err = valid ? out4[0] - st_[6 * kStashRows] : 0.0f;
             dout[0] = a.vf_coef * 2.0f * err;  // vf_coef * d mse / d v  (x B)
             wsum[4] += wave_sum(err * err);
         }
@@ -502,8 +497,8 @@ __global__ void __launch_bounds__(kPpoBlock, 1) ppo_phase_a_kernel(PpoBatch a) {
         tstore_hidden(x, tb + D::kSlotD1 * slot_stride, slot_stride, lane, et);
         PPO_TICK(a, 15);
     }
-    if (lane == 0) {  // per-wave sums of both tiles (reduced by the norm kernel)
-        float4* wo = reinterpret_cast<float4*>(a.wave_out + ((size_t)net * a.G + g) * 8);
+    if (lane == 0) {  // per-wave sums (reduced by the norm kernel)
+        float4* wo = reinterpret_cast<float4*>(a.wave_out + (((size_t)net * a.G + g) * 2 + et) * 8);
         wo[0] = make_float4(wsum[0], wsum[1], wsum[2], wsum[3]);
         wo[1] = make_float4(wsum[4], wsum[5], wsum[6], wsum[7]);
     }
@@ -681,7 +676,7 @@ struct qr_ppo {
     qr::half8* d_tbuf = nullptr;
     float* d_grad = nullptr;
     float* d_partial = nullptr;  // [max_chunks][num_params] phase-B outputs
-    float* d_wave = nullptr;     // [2][max groups][8] per-wave sums of phase A
+    float* d_wave = nullptr;     // [2][2 x max groups][8] per-wave sums of phase A
 #ifdef QR_PHASE_TIMING
     unsigned long long* ticks = nullptr;
 #endif
@@ -712,7 +707,7 @@ struct PpoOps {
         return QR_OK;
     }
     static int grad(qr_ppo* p, qr::PpoBatch b, hipStream_t st) {
-        const size_t lds = (size_t)D::kImage * 16 + 7 * qr::kPpoBlock * sizeof(float);  // operand images + per-sample stash
+        const size_t lds = (size_t)D::kImage * 16 + 7 * qr::kStashRows * sizeof(float);  // operand images + per-sample stash
         static bool configured = false;
         if (!configured) {
             PPO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L>),
@@ -726,12 +721,12 @@ struct PpoOps {
         const int per = (b.G + chunks - 1) / chunks;
         chunks = (b.G + per - 1) / per;
         hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((b.B + 1023) / 1024), dim3(1024), 0, st, b.adv, b.idx, b.B, p->d_acc);
-        hipLaunchKernelGGL(qr::ppo_phase_a_kernel<L>, dim3((b.G + 3) / 4, 2), dim3(qr::kPpoBlock), lds, st, b);
+        hipLaunchKernelGGL(qr::ppo_phase_a_kernel<L>, dim3((b.G + 3) / 4, 2), dim3(qr::kPpoBlockA), lds, st, b);
         hipLaunchKernelGGL(qr::ppo_phase_b_kernel<L>, dim3(2 * D::kBlocksPerNet * chunks), dim3(64), 0, st, p->d_tbuf, p->d_partial,
                            p->num_params, b.G, per, chunks, 1.0f / (float)b.B);
         // chunk reduction + gradient norm (also leaves the complete gradient in d_grad)
         hipLaunchKernelGGL(qr::ppo_norm_kernel, dim3((p->num_params + 1023) / 1024), dim3(1024), 0, st, p->d_grad, p->d_partial, chunks,
-                           p->num_params, p->d_wave, b.G, b.ent_coef, b.stats, p->d_acc);
+                           p->num_params, p->d_wave, 2 * b.G, b.ent_coef, b.stats, p->d_acc);
         PPO_HIP(hipGetLastError());
         return QR_OK;
     }
@@ -804,7 +799,7 @@ int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_tbuf, tbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_grad, (size_t)p->num_params * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_partial, (size_t)p->max_chunks * p->num_params * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_wave, (size_t)2 * (max_minibatch / 64) * 8 * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_wave, (size_t)2 * 2 * (max_minibatch / 64) * 8 * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_acc, 4 * sizeof(double));
     if (e == hipSuccess) e = hipMemset(p->d_grad, 0, (size_t)p->num_params * 4);
     if (e == hipSuccess) e = hipMemset(p->d_acc, 0, 4 * sizeof(double));

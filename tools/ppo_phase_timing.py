@@ -27,7 +27,7 @@ pol = ActorCritic(L_, 4).to(dev)
 up = MfmaPpoUpdater(pol, L_, dev, Bn)
 lib = _lib.load()
 lib.qr_ppo_debug_set_ticks.argtypes = [C.c_void_p, C.c_void_p]
-waves = 2 * (Bn // 64)
+waves = 2 * (Bn // 64) * 2    # two nets x groups x two 32-sample tiles (one wave each)
 ticks = torch.zeros((waves, 16), dtype=torch.int64, device=dev)
 for k in range(5):
     up.minibatch(obs, act, old_lp, adv, ret, perm[k * Bn:(k + 1) * Bn], 3e-4)
@@ -38,10 +38,10 @@ for k in range(12):
     torch.cuda.synchronize()
     reps.append(ticks.cpu().numpy().copy())
 t = np.stack(reps)[2:]
-names = ["entry", "image -> LDS + barrier", "obs gather, layer-1 operands + ALL of tile pass 0 + X0^T store of pass 1", "fwd layer 1", "h1^T store", "fwd layer 2",
+names = ["entry", "image -> LDS + barrier", "index / obs gather, layer-1 operand, X0^T store", "fwd layer 1", "h1^T store", "fwd layer 2",
          "h2^T store", "fwd layer 3", "h3^T store", "output layer + loss gradient", "d4, d4^T store, d3", "d3^T store", "d2", "d2^T store",
          "d1", "d1^T store"]
-print("phase A of one wave (two sequential 32-sample tile passes; slots 3..15 are stamped by the second pass):")
+print("phase A of one wave (one 32-sample tile through forward, loss and backward):")
 for s in range(1, 16):
     print(f"  {s:2d} {names[s]:42s} {np.median(t[:, :, s] - t[:, :, s - 1]):8.0f} cycles")
 print(f"  in-wave total {np.median(t[:, :, 15] - t[:, :, 0]):8.0f} cycles;  first entry -> last exit {np.median(t[:, :, 15].max(1) - t[:, :, 0].min(1)):8.0f} cycles (100 MHz clock64 ticks x ~24 = shader cycles)")
