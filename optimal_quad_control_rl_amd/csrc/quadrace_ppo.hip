@@ -185,7 +185,7 @@ struct PpoBatch {
     do {                                                                                                        \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                             \
         if ((a).ticks && (threadIdx.x & 63) == 0)                                                               \
-            (a).ticks[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = clock64(); \
+            (a).ticks[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6)) * 16 + (slot)] = clock64(); \
     } while (0)
 #else
 #define PPO_TICK(a, slot) do { } while (0)
@@ -292,15 +292,16 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// Phase A workgroup: 8 waves = 4 sample groups x 2 tiles of 32 samples.  Every MFMA covers 32 samples anyway, so one wave
+// Phase A workgroup: kThreads / 64 waves = kThreads / 128 sample groups x 2 tiles of 32 samples (8 waves; 4 waves for small
+// minibatches, so that 16 k samples still occupy all 256 CUs).  Every MFMA covers 32 samples anyway, so one wave
 // takes ONE tile through both passes of its network: half the live activations / deltas / masks (no scratch memory -- a
 // scratch reload would wait for all outstanding transposed-operand stores: same in-order counter) and two waves per SIMD
 // to overlap each other's matrix-core, LDS and store latencies.  (The 148 KB of operand images allow one workgroup per CU.)
-constexpr int kPpoBlockA = 512;
 constexpr int kStashRows = 256;  // per-sample scalars of the workgroup's 4 x 64 samples, parked in LDS
 
-template <int L>
+template <int L, int kPpoBlockA>
 __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) {
+    constexpr int kGroupsPerBlockA = kPpoBlockA / 128;
     using D = PpoDims<L>;
     using P = PolicyDims<L>;
     constexpr int KS1 = P::kSteps1;
@@ -330,7 +331,7 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     // wave-uniform indices in scalar registers: the 25+ scratch-slot addresses become scalar bases + one lane offset
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = blockIdx.x * 4 + (wave >> 1);   // sample group of this wave
+    const int g = blockIdx.x * kGroupsPerBlockA + (wave >> 1);   // sample group of this wave
     const int et = wave & 1;                       // its 32-sample tile: samples 32 et + c (both lane halves: k-slots by h)
     if (g >= a.G) return;  // whole wave
     PPO_TICK(a, 1);
@@ -710,7 +711,9 @@ struct PpoOps {
         const size_t lds = (size_t)D::kImage * 16 + 7 * qr::kStashRows * sizeof(float);  // operand images + per-sample stash
         static bool configured = false;
         if (!configured) {
-            PPO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L>),
+            PPO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 256>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PPO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 512>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
         }
@@ -721,7 +724,11 @@ struct PpoOps {
         const int per = (b.G + chunks - 1) / chunks;
         chunks = (b.G + per - 1) / per;
         hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((b.B + 1023) / 1024), dim3(1024), 0, st, b.adv, b.idx, b.B, p->d_acc);
-        hipLaunchKernelGGL(qr::ppo_phase_a_kernel<L>, dim3((b.G + 3) / 4, 2), dim3(qr::kPpoBlockA), lds, st, b);
+        // one workgroup per CU (LDS): 4-wave workgroups (2 groups) while that still fits the 256 CUs in one round, else 8 waves
+        if (b.G <= 256)
+            hipLaunchKernelGGL((qr::ppo_phase_a_kernel<L, 256>), dim3((b.G + 1) / 2, 2), dim3(256), lds, st, b);
+        else
+            hipLaunchKernelGGL((qr::ppo_phase_a_kernel<L, 512>), dim3((b.G + 3) / 4, 2), dim3(512), lds, st, b);
         hipLaunchKernelGGL(qr::ppo_phase_b_kernel<L>, dim3(2 * D::kBlocksPerNet * chunks), dim3(64), 0, st, p->d_tbuf, p->d_partial,
                            p->num_params, b.G, per, chunks, 1.0f / (float)b.B);
         // chunk reduction + gradient norm (also leaves the complete gradient in d_grad)
