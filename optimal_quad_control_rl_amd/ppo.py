@@ -138,6 +138,22 @@ class MfmaPpoUpdater:
                                             self._p(self.stats) if stats else None, self._stream()))
         return g
 
+    @staticmethod
+    def data_parallel():
+        """True when minibatch updates must be synchronised across ranks (torch.distributed initialised with more than one
+        rank; QR_PPO_FORCE_DDP=1 takes the same code path on a single rank, for testing)."""
+        import os
+
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return False
+        return torch.distributed.get_world_size() > 1 or os.environ.get("QR_PPO_FORCE_DDP") == "1"
+
+    def broadcast_parameters(self, src=0):
+        """Make every rank start from rank `src`'s parameters and optimiser state."""
+        for t in (self.theta, self.m, self.v):
+            torch.distributed.broadcast(t, src)
+        self.pack()
+
     def apply(self, grad, lr, max_grad_norm=0.5):
         """Clip `grad` (flat, consumed) to the global norm and take one Adam step -- the second half of a data-parallel
         update: `g = up.grad(...); dist.all_reduce(g); g /= world; up.apply(g, lr)`."""
@@ -147,7 +163,7 @@ class MfmaPpoUpdater:
                                              max_grad_norm, lr, self.betas[0], self.betas[1], self.eps, self.step, self._stream()))
 
     def minibatch(self, obs, act, old_lp, adv, ret, idx, lr, clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5):
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        if self.data_parallel():
             # data parallel: every rank holds the same parameters and its own envs; average the 63 k-float gradient
             g = self.grad(obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef, stats=True)
             torch.distributed.all_reduce(g)

@@ -31,14 +31,29 @@ ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 
+# one process per GPU under torchrun (data-parallel PPO: --envs is per GPU, env_id_base = rank * envs keys disjoint reset and
+# action-noise streams; gradients are averaged per minibatch, see MfmaPpoUpdater.minibatch)
+rank, world, local_rank = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
+if "RANK" in os.environ:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert a.native_update, "data-parallel training uses the matrix-core update (--native-update)"
+if rank != 0:
+    sys.stdout = open(os.devnull, "w")
+
 trk = square_track() if a.track == "square" else zigzag_track()
 cls = Quadcopter3DGates if a.variant == "e2e" else Quadcopter3DGatesINDI
-env = cls(a.envs, *trk, gates_ahead=1, infos_mode="none", seed=1 + a.seed)
+env = cls(a.envs, *trk, gates_ahead=1, infos_mode="none", seed=1 + a.seed, env_id_base=rank * a.envs)
 if a.variant == "e2e":
     env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
 model = PPO(env, seed=a.seed, ent_coef=a.ent_coef, gamma=a.gamma, n_steps=a.n_steps, n_epochs=a.epochs, batch_size=a.envs * a.n_steps // a.minibatches, learning_rate=a.lr,
-            target_kl=a.target_kl, lr_final_frac=a.lr_final, total_timesteps_hint=int(a.steps), fused_collect=a.fused,
+            target_kl=a.target_kl, lr_final_frac=a.lr_final, total_timesteps_hint=int(a.steps) // world, fused_collect=a.fused,
             native_update=a.native_update)
+if "RANK" in os.environ:
+    model._updater.broadcast_parameters(0)   # identical start on every rank (the seed already makes it so; this guarantees it)
+    model.noise_seed = a.seed                 # same key, different global env ids -> independent action noise per rank
 best = {"gates": -1.0, "state": None}
 def keep_best(m):
     g = m.stats.get("gates_per_episode", 0.0)
@@ -46,7 +61,7 @@ def keep_best(m):
         best["gates"] = g
         best["state"] = {k: v.clone() for k, v in m.policy.state_dict().items()}
 t0 = time.perf_counter()
-model.learn(int(a.steps), log_every=20, callback=keep_best)
+model.learn(int(a.steps) // world, log_every=20, callback=keep_best)   # --steps counts env-steps of the whole job
 if best["state"] is not None:
     model.policy.load_state_dict(best["state"])  # evaluate the best checkpoint (the reference saves one every 10 rollouts, R:823)
 torch.cuda.synchronize()
@@ -63,8 +78,8 @@ for k in range(1200):
     obs, rew, done, trunc = ev.step_device(model.predict(obs).contiguous())
     gates += (rew > 5).float(); crashes += (done.float() - trunc.float()).clamp(min=0)
 dt = 0.01
-res = dict(fused_collect=a.fused, native_update=a.native_update, variant=a.variant, track=a.track, envs=a.envs, train_steps=model.num_timesteps, train_seconds=train_s,
-           train_Msteps_per_s=model.num_timesteps / train_s / 1e6,
+res = dict(world_size=world, fused_collect=a.fused, native_update=a.native_update, variant=a.variant, track=a.track, envs=a.envs, train_steps=model.num_timesteps * world, train_seconds=train_s,
+           train_Msteps_per_s=model.num_timesteps * world / train_s / 1e6,
            eval_gates_per_12s=float(gates.mean()), eval_crashes_per_12s=float(crashes.mean()),
            eval_seconds_per_gate=float(1200 * dt / gates.mean().clamp(min=1e-9)),
            eval_seconds_per_lap_4gates=float(4 * 1200 * dt / gates.mean().clamp(min=1e-9)), **model.stats)
