@@ -201,6 +201,14 @@ int qr_ppo_minibatch(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* ad
                      const int32_t* idx_dev, int32_t B, float clip, float vf_coef, float ent_coef, float max_grad_norm,
                      float lr, float beta1, float beta2, float eps, int32_t adam_step, float* stats_dev, void* stream);
 
+/* forward pass of one network with the current operand images (net 0: action means; net 1: value in column 0): out_dev [n][4] */
+int qr_ppo_forward(qr_ppo* ppo, int32_t net, int32_t n, const float* obs_dev, float* out_dev, void* stream);
+/* GAE(lambda) over a rollout buffer [T][N] (SB3 RolloutBuffer.compute_returns_and_advantage; done = 0 / 1 floats, truncations
+ * count as terminations) and, when ep_*_dev are given, the running episode return / length / gate count per env with the
+ * sums over finished episodes ACCUMULATED into fin_dev[4] = {sum return, sum length, sum gates, episodes} (VecMonitor, R:769) */
+int qr_ppo_gae(qr_ppo* ppo, int32_t T, int32_t N, const float* rew_dev, const float* done_dev, const float* val_dev,
+               const float* last_val_dev, float gamma, float lam, float* adv_out_dev, float* ret_out_dev, float* ep_ret_dev,
+               float* ep_len_dev, float* ep_gates_dev, float* fin_dev, void* stream);
 /* data-parallel training (one process per GPU): each rank computes qr_ppo_grad on its own rows, the caller averages the
  * gradients across ranks (a single all-reduce of num_params floats -- ~250 KB -- over RCCL), then every rank applies the
  * identical update: global-norm clip, Adam, operand re-pack.  grad_dev is consumed (cleared). */

@@ -60,6 +60,8 @@ SIGNATURES = {
     "qr_ppo_pack": (C.c_int, [_vp, _vp, _vp]),
     "qr_ppo_grad": (C.c_int, [_vp] * 8 + [C.c_int32, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp]),
     "qr_ppo_minibatch": (C.c_int, [_vp] * 10 + [C.c_int32] + [C.c_float] * 8 + [C.c_int32, _vp, _vp]),
+    "qr_ppo_forward": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "qr_ppo_gae": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float, C.c_float] + [_vp] * 7),
     "qr_ppo_apply": (C.c_int, [_vp] * 5 + [C.c_float] * 5 + [C.c_int32, _vp]),
     # include/quad3d.h (predecessor environments of "3D quad.ipynb")
     "q3_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),

@@ -658,6 +658,49 @@ __global__ void __launch_bounds__(256) ppo_adam_kernel(float* __restrict__ theta
     grad[i] = 0.0f;
 }
 
+// ---- GAE(lambda) and episode statistics over a rollout buffer [T][N] (what SB3's RolloutBuffer.compute_returns_and_advantage
+// and VecMonitor do on the host): one lane = one env.  done is 0 / 1 as float; time-limit truncations count as terminations.
+__global__ void __launch_bounds__(256) ppo_gae_kernel(int T, int N, const float* __restrict__ rew, const float* __restrict__ done,
+                                                      const float* __restrict__ val, const float* __restrict__ last_val, float gamma,
+                                                      float lam, float* __restrict__ adv, float* __restrict__ ret,
+                                                      float* __restrict__ ep_ret, float* __restrict__ ep_len,
+                                                      float* __restrict__ ep_gates, float* __restrict__ fin) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f, f3 = 0.0f;
+    if (i < N) {
+        float last = 0.0f, next_val = last_val[i];
+        for (int t = T - 1; t >= 0; --t) {
+            const size_t e = (size_t)t * N + i;
+            const float nonterminal = 1.0f - done[e], v = val[e];
+            const float delta = rew[e] + gamma * next_val * nonterminal - v;
+            last = delta + gamma * lam * nonterminal * last;
+            adv[e] = last;
+            ret[e] = last + v;
+            next_val = v;
+        }
+        if (ep_ret) {
+            float er = ep_ret[i], el = ep_len[i], eg = ep_gates[i];
+            for (int t = 0; t < T; ++t) {
+                const size_t e = (size_t)t * N + i;
+                const float r = rew[e], d = done[e];
+                er += r;
+                el += 1.0f;
+                eg += r > 5.0f ? 1.0f : 0.0f;  // gate reward 10 - 10 * d2g (R:537)
+                f0 += er * d; f1 += el * d; f2 += eg * d; f3 += d;
+                const float keep = 1.0f - d;
+                er *= keep; el *= keep; eg *= keep;
+            }
+            ep_ret[i] = er; ep_len[i] = el; ep_gates[i] = eg;
+        }
+    }
+    if (fin) {  // finished-episode sums: wave reduction, one atomic per wave and statistic
+        f0 = wave_sum(f0); f1 = wave_sum(f1); f2 = wave_sum(f2); f3 = wave_sum(f3);
+        if ((threadIdx.x & 63) == 0 && f3 > 0.0f) {
+            unsafeAtomicAdd(fin + 0, f0); unsafeAtomicAdd(fin + 1, f1); unsafeAtomicAdd(fin + 2, f2); unsafeAtomicAdd(fin + 3, f3);
+        }
+    }
+}
+
 // squared norm of an externally supplied gradient (data-parallel training: the all-reduced gradient comes back from the caller)
 __global__ void __launch_bounds__(1024) ppo_sqnorm_kernel(const float* __restrict__ grad, int n, double* __restrict__ acc) {
     const int i = blockIdx.x * 1024 + threadIdx.x;
@@ -686,6 +729,7 @@ struct qr_ppo {
 
 namespace qr {
 int set_last_error(int code, const std::string& msg);  // quadrace_abi.hip
+hipError_t launch_policy(int L, const half8* w, int n, const float* obs, float* mean, hipStream_t st);  // quadrace_policy.hip
 const half8* ppo_policy_image(const qr_ppo* p) { return p ? p->d_images : nullptr; }
 }  // namespace qr
 
@@ -905,6 +949,30 @@ int qr_ppo_apply(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_d
     const int rc = dispatch_L(p->L, [&](auto Lc) { return PpoOps<decltype(Lc)::value>::pack(p, theta_dev, st); });
     if (rc != QR_OK) return rc;
     PPO_HIP(hipMemsetAsync(p->d_acc, 0, 4 * sizeof(double), st));
+    return QR_OK;
+}
+
+// Forward pass of one of the two networks with the operand images of the last pack (0 = policy means, 1 = value in column 0):
+// out_dev [n][4].  Same kernel as qr_policy_forward.
+int qr_ppo_forward(qr_ppo* p, int32_t net, int32_t n, const float* obs_dev, float* out_dev, void* stream) {
+    if (!p || !obs_dev || !out_dev || n < 1 || net < 0 || net > 1) return ppofail(QR_E_INVALID, "qr_ppo_forward: bad argument");
+    PPO_HIP(hipSetDevice(p->device));
+    const hipError_t e = qr::launch_policy(p->L, p->d_images + (size_t)net * p->image_half8, n, obs_dev, out_dev, (hipStream_t)stream);
+    if (e != hipSuccess) return ppofail(QR_E_HIP, std::string("qr_ppo_forward: ") + hipGetErrorString(e));
+    return QR_OK;
+}
+
+// GAE(lambda) advantages / returns of a rollout [T][N] and (optionally) episode statistics; see ppo_gae_kernel.
+int qr_ppo_gae(qr_ppo* p, int32_t T, int32_t N, const float* rew_dev, const float* done_dev, const float* val_dev,
+               const float* last_val_dev, float gamma, float lam, float* adv_out_dev, float* ret_out_dev, float* ep_ret_dev,
+               float* ep_len_dev, float* ep_gates_dev, float* fin_dev, void* stream) {
+    if (!p || !rew_dev || !done_dev || !val_dev || !last_val_dev || !adv_out_dev || !ret_out_dev || T < 1 || N < 1)
+        return ppofail(QR_E_INVALID, "qr_ppo_gae: bad argument");
+    if (ep_ret_dev && (!ep_len_dev || !ep_gates_dev)) return ppofail(QR_E_INVALID, "qr_ppo_gae: episode state needs all three arrays");
+    PPO_HIP(hipSetDevice(p->device));
+    hipLaunchKernelGGL(qr::ppo_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, T, N, rew_dev, done_dev, val_dev,
+                       last_val_dev, gamma, lam, adv_out_dev, ret_out_dev, ep_ret_dev, ep_len_dev, ep_gates_dev, fin_dev);
+    PPO_HIP(hipGetLastError());
     return QR_OK;
 }
 

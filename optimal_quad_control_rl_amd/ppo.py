@@ -154,6 +154,26 @@ class MfmaPpoUpdater:
             torch.distributed.broadcast(t, src)
         self.pack()
 
+    def forward(self, net, obs):
+        """Forward pass on the matrix cores with the current operand images: net 0 -> action means [n, 4]; net 1 -> values [n]."""
+        assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous()
+        out = torch.empty((obs.shape[0], 4), dtype=torch.float32, device=obs.device)
+        self._lib.check(self._L.qr_ppo_forward(self._h, int(net), int(obs.shape[0]), self._p(obs), self._p(out), self._stream()))
+        return out if net == 0 else out[:, 0]
+
+    def gae(self, rew, done, val, last_val, gamma, lam, ep_state=None, fin=None):
+        """GAE(lambda) over a rollout [T, N] in one kernel -> (advantages, returns); `ep_state` = (ep_ret, ep_len, ep_gates)
+        running per-env episode statistics (updated in place), sums over finished episodes accumulate into `fin` [4]."""
+        T, N = rew.shape
+        for t in (rew, done, val, last_val):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        adv, ret = torch.empty_like(rew), torch.empty_like(rew)
+        er, el, eg = ep_state if ep_state is not None else (None, None, None)
+        self._lib.check(self._L.qr_ppo_gae(self._h, T, N, self._p(rew), self._p(done), self._p(val), self._p(last_val), gamma, lam,
+                                           self._p(adv), self._p(ret), self._p(er), self._p(el), self._p(eg), self._p(fin),
+                                           self._stream()))
+        return adv, ret
+
     def apply(self, grad, lr, max_grad_norm=0.5):
         """Clip `grad` (flat, consumed) to the global norm and take one Adam step -- the second half of a data-parallel
         update: `g = up.grad(...); dist.all_reduce(g); g /= world; up.apply(g, lr)`."""
@@ -255,9 +275,14 @@ class PPO:
             out=(self.buf_obs, self.buf_act, self.buf_lp, self.buf_rew, self._done_u8, self._trunc_u8))
         self.buf_done.copy_(done)
         T, N = self.n_steps, self.n_envs
+        self.num_timesteps += T * N
+        if self._updater is not None:   # values on the matrix cores too; GAE and episode statistics follow in train()
+            self.buf_val.copy_(self._updater.forward(1, self.buf_obs.view(T * N, -1)).view(T, N))
+            self.last_val = self._updater.forward(1, last_obs.contiguous()).contiguous()
+            self._stats_pending = True
+            return
         self.buf_val.copy_(self.policy.value(self.buf_obs.view(T * N, -1)).view(T, N))
         self.last_val = self.policy.value(last_obs)
-        self.num_timesteps += T * N
         self._episode_stats(self.buf_rew, self.buf_done)
 
     @torch.no_grad()
@@ -325,9 +350,22 @@ class PPO:
             self.buf_val[bad] = 0.0
             self.last_val = torch.nan_to_num(self.last_val)
 
+    def _gae_native(self):
+        fin = torch.zeros(4, dtype=torch.float32, device=self.dev)
+        pending = getattr(self, "_stats_pending", False)
+        adv, ret = self._updater.gae(self.buf_rew, self.buf_done, self.buf_val, self.last_val, self.gamma, self.lam,
+                                     (self.ep_ret, self.ep_len, self.ep_gates) if pending else None, fin if pending else None)
+        if pending:
+            self._stats_pending = False
+            f = fin.tolist() + [float(self.buf_rew.mean())]
+            if f[3] > 0:
+                self.stats.update(ep_rew_mean=f[0] / f[3], ep_len_mean=f[1] / f[3], gates_per_episode=f[2] / f[3], episodes=f[3])
+            self.stats["reward_per_step"] = f[4]
+        return adv, ret
+
     def train(self):
         self._sanitise_buffers()
-        adv, ret = self._gae()
+        adv, ret = self._gae_native() if self._updater is not None else self._gae()
         if self.stats["non_finite_rows"]:
             adv = adv.masked_fill(self._bad, 0.0)
             ret = torch.where(self._bad, self.buf_val, ret)

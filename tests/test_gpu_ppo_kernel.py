@@ -202,3 +202,40 @@ def test_argument_validation():
     idx = torch.arange(8192, device=obs.device, dtype=torch.int32) % 256
     with pytest.raises(_lib.QuadraceError):
         up.grad(obs, act, old_lp, adv, ret, idx.contiguous())   # larger than max_minibatch
+
+
+def test_gae_and_value_forward_match_torch():
+    """qr_ppo_gae == the torch GAE / episode-statistics loops of ppo.py; qr_ppo_forward == the networks at f16-operand level."""
+    from optimal_quad_control_rl_amd.ppo import PPO
+
+    class FakeEnv:   # just enough of the env surface for PPO.__init__ and the torch reference loops
+        num_envs, state_len, device = 4096, 17, torch.device("cuda", 0)
+
+        def reset_device(self):
+            return torch.zeros((self.num_envs, self.state_len), device=self.device)
+
+    T, N = 32, 4096
+    ref = PPO(FakeEnv(), n_steps=T, batch_size=N * T // 4, gamma=0.99)
+    pol, _, up, obs, *_ = _setup(17, 8192, seed=3, max_minibatch=4096)
+    g = torch.Generator(device=obs.device).manual_seed(5)
+    rew = torch.randn((T, N), device=obs.device, generator=g) * 0.3
+    rew[torch.rand((T, N), device=obs.device, generator=g) < 0.02] = 9.5          # gate passes
+    done = (torch.rand((T, N), device=obs.device, generator=g) < 0.03).float()
+    val = torch.randn((T, N), device=obs.device, generator=g)
+    last_val = torch.randn(N, device=obs.device, generator=g)
+    ref.buf_rew.copy_(rew); ref.buf_done.copy_(done); ref.buf_val.copy_(val); ref.last_val = last_val
+    adv_ref, ret_ref = ref._gae()
+    ref._episode_stats(rew, done)
+    er, el, eg = (torch.zeros(N, device=obs.device) for _ in range(3))
+    fin = torch.zeros(4, device=obs.device)
+    adv, ret = up.gae(rew.contiguous(), done.contiguous(), val.contiguous(), last_val.contiguous(), 0.99, 0.95, (er, el, eg), fin)
+    assert torch.allclose(adv, adv_ref, rtol=1e-5, atol=1e-5) and torch.allclose(ret, ret_ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(er, ref.ep_ret, atol=1e-4) and torch.equal(el, ref.ep_len) and torch.equal(eg, ref.ep_gates)
+    f = fin.tolist()
+    assert f[3] == float(done.sum()) and abs(f[1] / f[3] - ref.stats["ep_len_mean"]) < 1e-3
+    assert abs(f[0] / f[3] - ref.stats["ep_rew_mean"]) < 1e-3 and abs(f[2] / f[3] - ref.stats["gates_per_episode"]) < 1e-4
+    with torch.no_grad():
+        v_ref, m_ref = pol.value(obs), pol.pi(obs)
+    v, m = up.forward(1, obs), up.forward(0, obs)
+    assert (v - v_ref).abs().max() < 2e-2 * max(1.0, float(v_ref.abs().max()))
+    assert (m - m_ref).abs().max() < 2e-2 * max(1.0, float(m_ref.abs().max()))
