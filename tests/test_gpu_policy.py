@@ -169,8 +169,8 @@ def test_ppo_native_update_learns():
                 fused_collect=True, native_update=True)
     theta0 = model._updater.theta.clone()
     model.collect()
+    model.train()                      # (with the native update, GAE and the episode statistics run here, on the device)
     first = dict(model.stats)
-    model.train()
     assert model.stats["updates"] == 160 and model._updater.step == 160
     assert torch.isfinite(model._updater.theta).all() and not torch.equal(model._updater.theta, theta0)
     assert model.policy.pi[0].weight.data_ptr() == model._updater.theta.data_ptr()
