@@ -64,6 +64,14 @@ class ActorCritic(nn.Module):
         return actions, lp, self.vf(obs).squeeze(-1)
 
 
+def average_across_ranks(t):
+    """In-place mean of a tensor over all ranks of the default process group (RCCL all-reduce on GPU tensors; the only
+    collective of data-parallel training: one flat gradient of ~63 k floats per minibatch)."""
+    torch.distributed.all_reduce(t)
+    t /= torch.distributed.get_world_size()
+    return t
+
+
 class MfmaPpoUpdater:
     """PPO minibatch updates on the matrix cores (`qr_ppo_*`, csrc/quadrace_ppo.hip) for an `ActorCritic` with
     net_arch (120, 120, 120).  The module's parameters are re-pointed at views of ONE flat float32 vector (the layout
@@ -186,9 +194,7 @@ class MfmaPpoUpdater:
         if self.data_parallel():
             # data parallel: every rank holds the same parameters and its own envs; average the 63 k-float gradient
             g = self.grad(obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef, stats=True)
-            torch.distributed.all_reduce(g)
-            g /= torch.distributed.get_world_size()
-            return self.apply(g, lr, max_grad_norm)
+            return self.apply(average_across_ranks(g), lr, max_grad_norm)
         self.step += 1
         self._lib.check(self._L.qr_ppo_minibatch(self._h, self._p(self.theta), self._p(self.m), self._p(self.v), self._p(obs),
                                                  self._p(act), self._p(old_lp), self._p(adv), self._p(ret), self._p(idx),

@@ -91,3 +91,47 @@ def test_pack_unpack_roundtrip():
     done = torch.rand(3, 5) > 0.5
     o, r, d = unpack_rollout(pack_rollout(obs, rew, done.to(torch.uint8)))
     assert torch.equal(o, obs) and torch.equal(r, rew) and torch.equal(d, done)
+
+
+def _ddp_worker(rank, world, port, tmp):
+    """The collective of data-parallel PPO: ranks that start from the same parameters and average their gradients take the
+    same Adam step (here with torch.optim.Adam on CPU standing in for qr_ppo_apply, which needs the GPU)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from optimal_quad_control_rl_amd.ppo import ActorCritic, MfmaPpoUpdater, average_across_ranks
+
+    assert MfmaPpoUpdater.data_parallel()          # initialised, world_size 2
+    torch.manual_seed(0)
+    pol = ActorCritic(17, 4)                        # same initial parameters on both ranks
+    opt = torch.optim.Adam(pol.parameters(), lr=3e-4, eps=1e-5)
+    g = torch.Generator().manual_seed(100 + rank)   # different data per rank
+    obs = torch.randn((256, 17), generator=g)
+    loss = pol.pi(obs).pow(2).mean() + pol.value(obs).pow(2).mean()
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in pol.parameters() if p.grad is not None])
+    local = flat.clone()
+    avg = average_across_ranks(flat)
+    others = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(others, local)
+    assert torch.allclose(avg, torch.stack(others).mean(0), atol=1e-7)
+    off = 0
+    for p in pol.parameters():
+        if p.grad is not None:
+            p.grad.copy_(avg[off:off + p.numel()].view_as(p))
+            off += p.numel()
+    opt.step()
+    after = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
+    both = [torch.empty_like(after) for _ in range(world)]
+    dist.all_gather(both, after)
+    assert torch.equal(both[0], both[1])           # identical parameters on every rank after the step
+    if rank == 0:
+        open(os.path.join(tmp, "ddp_ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gradient_averaging_keeps_ranks_identical(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ddp_ok").exists()
