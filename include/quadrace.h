@@ -10,6 +10,7 @@
  *   qr_set_disturbance            env.disturbance_ranges / _scale       R:355-358, R:772-781
  *   qr_set_limits                 env.max_steps / env.dt                R:345-346, I:648
  *   qr_set_pause                  env.pause                             R:360, R:570-572
+ *   qr_set_pause_if_collision     env.pause_if_collision                R:293, R:573-578
  *   qr_seed                       VecEnv.seed (no-op upstream)          R:600-601
  *   qr_reset                      reset() / reset_(dones)               R:452-496   I:267-299
  *   qr_step                       step_async() + step_wait()            R:498-595   I:301-385
@@ -27,7 +28,9 @@
  *     kernels it enqueues in that call.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). Calls enqueue work and return
  *     without synchronising; results are ordered on that stream.
- *   - a handle is bound to one GPU and is not thread-safe.
+ *   - a handle is bound to one GPU and is not thread-safe.  Every entry point that touches the device makes the
+ *     handle's GPU the current HIP device first (and leaves it current), so one process may drive handles on
+ *     several GPUs; `stream` must belong to that GPU.
  *   - there is NO CPU fallback: qr_create fails with QR_E_NO_DEVICE when no gfx950 device is visible.
  *
  * Layouts at the boundary are the reference's row-major arrays: actions [N][4], obs [N][obs_len],
@@ -98,6 +101,8 @@ int qr_set_disturbance(qr_env* env, const float* ranges, float scale);
 
 int qr_set_limits(qr_env* env, int32_t max_steps, float dt);
 int qr_set_pause(qr_env* env, int32_t pause);
+/* env.pause_if_collision after construction (qr_config.pause_if_collision sets the initial value) */
+int qr_set_pause_if_collision(qr_env* env, int32_t on);
 
 /* Philox4x32-10 key for the in-kernel reset RNG; also zeroes the per-env episode counters. */
 int qr_seed(qr_env* env, uint64_t seed);
@@ -119,8 +124,10 @@ int qr_step(qr_env* env, const float* actions_dev, float* obs_out_dev, float* re
 int qr_step_many(qr_env* env, int32_t num_steps, const float* actions_dev, float* obs_out_dev,
                  float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream);
 
-/* The same K steps as K separate step-kernel launches (exactly what K calls of qr_step enqueue, without the
- * per-call FFI cost): the calling pattern of a closed loop whose policy runs between steps. */
+/* The same K steps as K separate step kernels (the kernels K calls of qr_step enqueue, without the per-call FFI cost):
+ * the calling pattern of a closed loop whose policy runs between steps.  The K launches are captured once into a
+ * hipGraph (K kernel nodes in a chain) and replayed while (K, buffers, env configuration) stay the same: dependent
+ * kernel nodes of a graph start ~1 us sooner after each other than dependent launches on a stream. */
 int qr_step_launches(qr_env* env, int32_t num_steps, const float* actions_dev, float* obs_out_dev,
                      float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream);
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "qr_set_disturbance": (C.c_int, [_vp, _f32p, C.c_float]),
     "qr_set_limits": (C.c_int, [_vp, C.c_int32, C.c_float]),
     "qr_set_pause": (C.c_int, [_vp, C.c_int32]),
+    "qr_set_pause_if_collision": (C.c_int, [_vp, C.c_int32]),
     "qr_seed": (C.c_int, [_vp, C.c_uint64]),
     "qr_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "qr_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -99,7 +100,7 @@ def load(build_if_missing=True):
     if _lib is not None:
         return _lib
     if build_if_missing and _build.needs_build():
-        _build.build_native()
+        _build.build_native_locked()   # one builder at a time (torchrun starts every rank at once)
     if not os.path.exists(_build.LIB):
         raise RuntimeError(f"{_build.LIB} is missing: run `python -m optimal_quad_control_rl_amd.build`")
     L = C.CDLL(_build.LIB)

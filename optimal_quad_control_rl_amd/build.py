@@ -71,13 +71,29 @@ def build_native(force=False, verbose=False, extra_flags=()):
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    tmp = LIB + ".tmp.%d" % os.getpid()   # link beside the target, then rename: a concurrent dlopen never sees a partial file
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
     return LIB
 
 
+def build_native_locked(**kw):
+    """build_native() under an exclusive file lock: ranks started together (torchrun) must not compile into the same
+    object files at once; whoever gets the lock second finds the library fresh and returns immediately."""
+    import fcntl
+
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return build_native(**kw)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 if __name__ == "__main__":
-    build_native(force="--force" in sys.argv, verbose=True)
+    build_native_locked(force="--force" in sys.argv, verbose=True)
     print("built", LIB)

@@ -49,6 +49,16 @@ struct qr_env {
     float dist_scale = 1.0f;  // R:358
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_valid = false;
+    // qr_step_launches: the K step-kernel launches of one call, captured once into a hipGraph and replayed while the
+    // arguments stay the same (measured, tools/ubench/launch_floor.hip: back-to-back dependent launches cost 2.6 us
+    // each on a stream and 1.5 us as consecutive kernel nodes of a graph)
+    struct StepGraph {
+        hipGraphExec_t exec = nullptr;
+        int K = 0;
+        const void *act = nullptr, *obs = nullptr, *rew = nullptr, *done = nullptr, *trunc = nullptr;
+        qr::Params P{};
+    } sg;
+    hipStream_t capture_stream = nullptr;
 };
 
 namespace {
@@ -130,8 +140,16 @@ int upload_tables(qr_env* e) {
     return QR_OK;
 }
 
-int check_ready(const qr_env* e) {
+// A host may hold handles on several GPUs in one process: every entry point that touches the device first makes the
+// handle's GPU current (kernels launch on the CURRENT device; a stream of another device would be rejected).
+int bind_device(const qr_env* e) {
     if (!e) return fail(QR_E_INVALID, "null env handle");
+    QR_HIP(hipSetDevice(e->cfg.device));
+    return QR_OK;
+}
+
+int check_ready(const qr_env* e) {
+    if (int rc = bind_device(e)) return rc;
     if (!e->has_track) return fail(QR_E_STATE, "qr_set_track has not been called");
     return QR_OK;
 }
@@ -216,6 +234,8 @@ int qr_destroy(qr_env* e) {
     (void)hipDeviceSynchronize();
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->sg.exec) (void)hipGraphExecDestroy(e->sg.exec);
+    if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
     if (e->slab) (void)hipFree(e->slab);
     if (e->d_tables) (void)hipFree(e->d_tables);
     delete e;
@@ -254,7 +274,8 @@ int qr_set_track(qr_env* e, const float* gate_pos, const float* gate_yaw, int32_
 }
 
 int qr_get_track_tables(const qr_env* e, float* gate_pos_rel, float* gate_yaw_rel) {
-    if (int rc = check_ready(e)) return rc;
+    if (!e) return fail(QR_E_INVALID, "null env handle");
+    if (!e->has_track) return fail(QR_E_STATE, "qr_set_track has not been called");
     if (gate_pos_rel) std::memcpy(gate_pos_rel, e->gate_pos_rel.data(), sizeof(float) * 3 * e->num_gates);
     if (gate_yaw_rel) std::memcpy(gate_yaw_rel, e->gate_yaw_rel.data(), sizeof(float) * e->num_gates);
     return QR_OK;
@@ -329,6 +350,13 @@ int qr_set_pause(qr_env* e, int32_t pause) {
     return QR_OK;
 }
 
+int qr_set_pause_if_collision(qr_env* e, int32_t on) {
+    if (!e) return fail(QR_E_INVALID, "qr_set_pause_if_collision: null env");
+    e->cfg.pause_if_collision = on ? 1 : 0;
+    if (on) e->P.flags |= qr::kFlagPauseIfCollision; else e->P.flags &= ~qr::kFlagPauseIfCollision;
+    return QR_OK;
+}
+
 int qr_seed(qr_env* e, uint64_t seed) {
     if (!e) return fail(QR_E_INVALID, "qr_seed: null env");
     QR_HIP(hipSetDevice(e->cfg.device));
@@ -379,12 +407,36 @@ int qr_step_launches(qr_env* e, int32_t K, const float* actions_dev, float* obs_
         return fail(QR_E_INVALID, "qr_step_launches: actions/obs/rew/done buffers are required");
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)e->cfg.num_envs;
-    QR_HIP(hipEventRecord(e->ev0, st));
-    for (int k = 0; k < K; ++k) {
-        QR_HIP(qr::launch_step(e->cfg.variant, e->P, actions_dev + (size_t)k * n * 4, obs_out_dev + (size_t)k * n * e->L,
-                               rew_out_dev + (size_t)k * n, done_out_dev + (size_t)k * n,
-                               trunc_out_dev ? trunc_out_dev + (size_t)k * n : nullptr, st));
+    qr_env::StepGraph& g = e->sg;
+    const bool hit = g.exec && g.K == K && g.act == actions_dev && g.obs == obs_out_dev && g.rew == rew_out_dev &&
+                     g.done == done_out_dev && g.trunc == trunc_out_dev && std::memcmp(&g.P, &e->P, sizeof(e->P)) == 0;
+    if (!hit) {  // (re)capture: K kernel nodes in a chain; kernel parameters (incl. Params) are baked into the nodes
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+        if (!e->capture_stream) QR_HIP(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        QR_HIP(hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
+        hipError_t err = hipSuccess;
+        for (int k = 0; k < K && err == hipSuccess; ++k)
+            err = qr::launch_step(e->cfg.variant, e->P, actions_dev + (size_t)k * n * 4, obs_out_dev + (size_t)k * n * e->L,
+                                  rew_out_dev + (size_t)k * n, done_out_dev + (size_t)k * n,
+                                  trunc_out_dev ? trunc_out_dev + (size_t)k * n : nullptr, e->capture_stream);
+        const hipError_t end = hipStreamEndCapture(e->capture_stream, &graph);
+        if (err != hipSuccess || end != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return fail(QR_E_HIP, std::string("qr_step_launches: graph capture failed: ") +
+                                      hipGetErrorString(err != hipSuccess ? err : end));
+        }
+        const hipError_t inst = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (inst != hipSuccess) {
+            g.exec = nullptr;
+            return fail(QR_E_HIP, std::string("qr_step_launches: hipGraphInstantiate: ") + hipGetErrorString(inst));
+        }
+        g.K = K; g.act = actions_dev; g.obs = obs_out_dev; g.rew = rew_out_dev; g.done = done_out_dev; g.trunc = trunc_out_dev;
+        std::memcpy(&g.P, &e->P, sizeof(e->P));  // byte copy: compared with memcmp above
     }
+    QR_HIP(hipEventRecord(e->ev0, st));
+    QR_HIP(hipGraphLaunch(g.exec, st));
     QR_HIP(hipEventRecord(e->ev1, st));
     e->timing_valid = true;
     return QR_OK;
@@ -412,8 +464,11 @@ int qr_rollout_policy(qr_env* e, qr_policy* policy, int32_t K, const float* log_
         sum_log_std += log_std[c];
     }
     A.logp_const = -sum_log_std - 2.0f * 1.8378770664093453f;  // 4 * 0.5 * log(2*pi)
-    A.seed_lo = (uint32_t)noise_seed;
-    A.seed_hi = (uint32_t)(noise_seed >> 32);
+    // Domain separation: the reset stream is Philox(counter = (env id, episode, block), key = env seed), the action
+    // noise Philox(counter = (env id, step), key = noise seed).  With equal seeds the two would share random bits
+    // whenever (episode, block) == (step lo, step hi); the noise key is therefore tweaked by a fixed odd constant.
+    A.seed_lo = (uint32_t)noise_seed ^ 0x9E3779B9u;
+    A.seed_hi = (uint32_t)(noise_seed >> 32) ^ 0x85EBCA6Bu;
     A.step_lo = (uint32_t)first_step;
     A.step_hi = (uint32_t)(first_step >> 32);
     A.deterministic = deterministic ? 1 : 0;
@@ -435,7 +490,7 @@ int qr_observe(qr_env* e, float* obs_out_dev, void* stream) {
 
 int qr_get_state(qr_env* e, float* world_dev, float* dist_dev, int32_t* target_dev, int32_t* steps_dev,
                  uint32_t* episode_dev, void* stream) {
-    if (!e) return fail(QR_E_INVALID, "qr_get_state: null env");
+    if (int rc = bind_device(e)) return rc;
     QR_HIP(qr::launch_get_state(e->cfg.variant, e->P, world_dev, dist_dev, target_dev, steps_dev, episode_dev,
                                 (hipStream_t)stream));
     return QR_OK;
@@ -451,6 +506,7 @@ int qr_set_state(qr_env* e, const float* world_dev, const float* dist_dev, const
 
 int qr_last_step_many_ms(qr_env* e, float* total_ms) {
     if (!e || !total_ms) return fail(QR_E_INVALID, "qr_last_step_many_ms: null argument");
+    if (int rc = bind_device(e)) return rc;
     if (!e->timing_valid) return fail(QR_E_STATE, "qr_last_step_many_ms: no qr_step_many call recorded");
     QR_HIP(hipEventSynchronize(e->ev1));
     QR_HIP(hipEventElapsedTime(total_ms, e->ev0, e->ev1));

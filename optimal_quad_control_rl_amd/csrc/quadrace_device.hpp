@@ -113,6 +113,30 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
 #pragma clang fp contract(off)
     return a * b;
 }
+// Streaming ("nt") stores for everything a step writes.  Nothing a step kernel writes is read again by the same
+// launch, and per-XCD L2s are written back / invalidated at every kernel boundary anyway (the next step's state
+// reads come from the fabric: PMC FETCH_SIZE = the algorithmic read bytes), so keeping these lines as dirty L2
+// residents only defers their write-back to the end-of-kernel drain.  Measured with tools/ubench/launch_floor.hip
+// (the step kernel's 285 B/env traffic, no arithmetic, 65 536 envs, back-to-back launches): 3.82 us plain
+// stores, 3.09-3.11 us nt / write-through stores; an empty kernel of the same shape costs 2.75 us.
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef int i32x2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stream_store(float4* p, const float4 v) {
+    const f32x4s x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<f32x4s*>(p));
+}
+__device__ __forceinline__ void stream_store(float2* p, const float2 v) {
+    const f32x2s x = {v.x, v.y};
+    __builtin_nontemporal_store(x, reinterpret_cast<f32x2s*>(p));
+}
+__device__ __forceinline__ void stream_store(int2* p, const int2 v) {
+    const i32x2s x = {v.x, v.y};
+    __builtin_nontemporal_store(x, reinterpret_cast<i32x2s*>(p));
+}
+__device__ __forceinline__ void stream_store(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void stream_store(uint8_t* p, uint8_t v) { __builtin_nontemporal_store(v, p); }
+
 template <int V>
 struct Env {
     static constexpr int S = (V == kE2E) ? 16 : 13;
@@ -314,6 +338,28 @@ __device__ __forceinline__ float relu_dot16(const float* w, const f32x16& acc) {
     return (s0 + s1) + (s2 + s3);
 }
 
+// max(x, 0) as ONE v_max_f32.  fmaxf() costs two: LLVM first canonicalises an operand it cannot prove quiet
+// (v_max_f32 x, x, x) -- matrix-core results never are signalling NaNs, and v_max_f32 itself returns the non-NaN
+// operand, so relu0(NaN) = 0 = fmaxf(NaN, 0): identical results, 128 fewer VALU instructions per env step.
+__device__ __forceinline__ float relu0(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// dot(w[0..15], relu(acc[0..15])) over this lane's 16 hidden rows as four independent chains, cut into 4-row chunks
+// so that the chunks can be placed between MFMAs
+struct DotAcc {
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    __device__ __forceinline__ float sum() const { return (s0 + s1) + (s2 + s3); }
+};
+__device__ __forceinline__ void dot_chunk(const float* w, const f32x16& acc, int r, DotAcc& d) {
+    d.s0 = fmaf(w[r + 0], relu0(acc[r + 0]), d.s0);
+    d.s1 = fmaf(w[r + 1], relu0(acc[r + 1]), d.s1);
+    d.s2 = fmaf(w[r + 2], relu0(acc[r + 2]), d.s2);
+    d.s3 = fmaf(w[r + 3], relu0(acc[r + 3]), d.s3);
+}
+
 __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const float x[10], float& thrust,
                                              float moment[3]) {
     float b01[2], b23[2], b45[2], b67[2], b89[2], b6one[2];
@@ -324,25 +370,56 @@ __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const f
     pair_to_tiles(x[8], x[9], b89[0], b89[1]);
     pair_to_tiles(x[6], 1.0f, b6one[0], b6one[1]);          // thrust net: k = 6 is vbz, k = 7 carries the bias
     const float bias_sel = (lane < 32) ? 1.0f : 0.0f;        // moment net: k = 10 carries the bias, k = 11 unused
-    float part[2][4];
+    // Software pipeline over the two 32-env tiles.  A wave issues in order and an MFMA issued while the matrix core is
+    // still busy stalls the whole wave, so output-layer VALU work only overlaps the matrix pipe when it sits BETWEEN
+    // two MFMAs in program order.  The 20 MFMAs (20 x 64 cycles = the floor of this phase) are therefore issued as one
+    // stream and the ReLU + dot product of each finished accumulator is cut into 4-row chunks (8 VALU instructions)
+    // that are placed, pinned by sched_barrier, behind the MFMAs of the NEXT accumulator:
+    //   thrust tile 0 (4 MFMA) | moment tile 0 (6 MFMA) + thrust-0 dot | thrust tile 1 (4) + 3 moment-0 dots
+    //   | moment tile 1 (6) + thrust-1 dot | 3 moment-1 dots (exposed)
+    // Same operations on the same operands in the same per-chain order as a plain 16-row loop -> bit-identical results.
+    const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    f32x16 hT0 = zero, hM0 = zero, hT1 = zero, hM1 = zero;
+    DotAcc dT0, dT1, dM0[3], dM1[3];
+#define QR_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, ACC, 0, 0, 0)
+#define QR_PIN() __builtin_amdgcn_sched_barrier(0)
+    QR_MFMA(hT0, m.a[0], b01[0]); QR_MFMA(hT0, m.a[1], b23[0]); QR_MFMA(hT0, m.a[2], b45[0]); QR_MFMA(hT0, m.a[3], b6one[0]);
+    QR_PIN();
+    QR_MFMA(hM0, m.a[4], b01[0]); QR_PIN();
+    QR_MFMA(hM0, m.a[5], b23[0]); dot_chunk(m.w2 + 0, hT0, 0, dT0); QR_PIN();
+    QR_MFMA(hM0, m.a[6], b45[0]); dot_chunk(m.w2 + 0, hT0, 4, dT0); QR_PIN();
+    QR_MFMA(hM0, m.a[7], b67[0]); dot_chunk(m.w2 + 0, hT0, 8, dT0); QR_PIN();
+    QR_MFMA(hM0, m.a[8], b89[0]); dot_chunk(m.w2 + 0, hT0, 12, dT0); QR_PIN();
+    QR_MFMA(hM0, m.a[9], bias_sel); QR_PIN();
+    QR_MFMA(hT1, m.a[0], b01[1]); QR_PIN();
 #pragma unroll
-    for (int et = 0; et < 2; ++et) {
-        f32x16 hT = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        f32x16 hM = hT;
-        hT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[0], b01[et], hT, 0, 0, 0);
-        hM = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[4], b01[et], hM, 0, 0, 0);
-        hT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[1], b23[et], hT, 0, 0, 0);
-        hM = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[5], b23[et], hM, 0, 0, 0);
-        hT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[2], b45[et], hT, 0, 0, 0);
-        hM = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[6], b45[et], hM, 0, 0, 0);
-        hT = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[3], b6one[et], hT, 0, 0, 0);
-        hM = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[7], b67[et], hM, 0, 0, 0);
-        hM = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[8], b89[et], hM, 0, 0, 0);
-        hM = __builtin_amdgcn_mfma_f32_32x32x2f32(m.a[9], bias_sel, hM, 0, 0, 0);
-        part[et][0] = relu_dot16(m.w2 + 0, hT);
-        part[et][1] = relu_dot16(m.w2 + 16, hM);
-        part[et][2] = relu_dot16(m.w2 + 32, hM);
-        part[et][3] = relu_dot16(m.w2 + 48, hM);
+    for (int g = 0; g < 3; ++g) {  // MFMA g + 1 of thrust tile 1 hosts moment-0 output g (4 chunks = 32 VALU)
+        if (g == 0) QR_MFMA(hT1, m.a[1], b23[1]);
+        if (g == 1) QR_MFMA(hT1, m.a[2], b45[1]);
+        if (g == 2) QR_MFMA(hT1, m.a[3], b6one[1]);
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) dot_chunk(m.w2 + 16 + 16 * g, hM0, r, dM0[g]);
+        QR_PIN();
+    }
+    QR_MFMA(hM1, m.a[4], b01[1]); QR_PIN();
+    QR_MFMA(hM1, m.a[5], b23[1]); dot_chunk(m.w2 + 0, hT1, 0, dT1); QR_PIN();
+    QR_MFMA(hM1, m.a[6], b45[1]); dot_chunk(m.w2 + 0, hT1, 4, dT1); QR_PIN();
+    QR_MFMA(hM1, m.a[7], b67[1]); dot_chunk(m.w2 + 0, hT1, 8, dT1); QR_PIN();
+    QR_MFMA(hM1, m.a[8], b89[1]); dot_chunk(m.w2 + 0, hT1, 12, dT1); QR_PIN();
+    QR_MFMA(hM1, m.a[9], bias_sel); QR_PIN();
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) dot_chunk(m.w2 + 16 + 16 * g, hM1, r, dM1[g]);
+#undef QR_MFMA
+#undef QR_PIN
+    float part[2][4];
+    part[0][0] = dT0.sum();
+    part[1][0] = dT1.sum();
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        part[0][1 + g] = dM0[g].sum();
+        part[1][1 + g] = dM1[g].sum();
     }
     float out[4];
 #pragma unroll

@@ -48,21 +48,21 @@ __device__ __forceinline__ int2 pack_ts(const Env<V>& e) {
 
 template <int V>
 __device__ __forceinline__ void store_world(const Params& P, int i, const Env<V>& e) {
-    P.ws[i] = make_float4(e.s[0], e.s[1], e.s[2], e.s[3]);
-    P.ws[P.n_stride + i] = make_float4(e.s[4], e.s[5], e.s[6], e.s[7]);
-    P.ws[2 * P.n_stride + i] = make_float4(e.s[8], e.s[9], e.s[10], e.s[11]);
+    stream_store(P.ws + i, make_float4(e.s[0], e.s[1], e.s[2], e.s[3]));
+    stream_store(P.ws + P.n_stride + i, make_float4(e.s[4], e.s[5], e.s[6], e.s[7]));
+    stream_store(P.ws + 2 * P.n_stride + i, make_float4(e.s[8], e.s[9], e.s[10], e.s[11]));
     if constexpr (V == kE2E) {
-        P.ws[3 * P.n_stride + i] = make_float4(e.s[12], e.s[13], e.s[14], e.s[15]);
+        stream_store(P.ws + 3 * P.n_stride + i, make_float4(e.s[12], e.s[13], e.s[14], e.s[15]));
     } else {
-        P.tn[i] = e.s[12];
+        stream_store(P.tn + i, e.s[12]);
     }
 }
 
 template <int V>
 __device__ __forceinline__ void store_dist(const Params& P, int i, const Env<V>& e) {
     if constexpr (V == kE2E) {
-        P.dA[i] = make_float4(e.d[0], e.d[1], e.d[2], e.d[5]);
-        P.dB[i] = make_float2(e.d[3], e.d[4]);
+        stream_store(P.dA + i, make_float4(e.d[0], e.d[1], e.d[2], e.d[5]));
+        stream_store(P.dB + i, make_float2(e.d[3], e.d[4]));
     }
 }
 
@@ -77,10 +77,10 @@ __device__ __forceinline__ void store_obs(float* __restrict__ obs_out, int i, co
     if constexpr (V == kE2E) {
         float4* r4 = reinterpret_cast<float4*>(row);
 #pragma unroll
-        for (int k = 0; k < L / 4; ++k) r4[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+        for (int k = 0; k < L / 4; ++k) stream_store(r4 + k, make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]));
     } else {
 #pragma unroll
-        for (int k = 0; k < L; ++k) row[k] = o[k];
+        for (int k = 0; k < L; ++k) stream_store(row + k, o[k]);
     }
 }
 
@@ -110,7 +110,7 @@ __device__ __forceinline__ void store_obs_coalesced(float* __restrict__ tile, fl
 #pragma unroll
     for (int t = 0; t < (kVec + 63) / 64; ++t) {
         const int e = t * 64 + lane;
-        if ((t + 1) * 64 <= kVec || e < kVec) g4[e] = t4[e];
+        if ((t + 1) * 64 <= kVec || e < kVec) stream_store(g4 + e, t4[e]);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -134,19 +134,28 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
     const int ii = active ? i : 0;
     QR_TICK(P, 0);
 
-    // issue this lane's HBM loads first; the LDS staging below overlaps their latency
+    // Prologue ordering (one wave per SIMD at N = 65 536: every exposed latency is paid in full).  Loads return in
+    // issue order (one vmcnt counter), so the table loads -- L2 hits, needed first: they go through LDS and a
+    // workgroup barrier -- are issued BEFORE the lane's state loads (HBM round trip): the LDS writes, the barrier and
+    // the 27 LDS reads that fill the residual-MLP weight registers all complete in the shadow of the state loads.
+    const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
+    float* rtab = lds + kTab;                 // [reset table | gate rows | obs tiles]
+    float* gates = rtab + kResetTableFloats;
+    const int tab_off = use_mlp ? 0 : kOffResetImage;                      // float offset into the device table image
+    const int tab_vec = ((use_mlp ? kOffGatesImage : kResetTableFloats) + P.num_gates * kGateStride) / 4;  // <= 316
+    const float4* tsrc = reinterpret_cast<const float4*>(P.tables + tab_off);
+    float4* tdst = reinterpret_cast<float4*>(use_mlp ? lds : rtab);
+    const int t0 = threadIdx.x, t1 = threadIdx.x + kBlock;
+    const float4 tv0 = tsrc[t0 < tab_vec ? t0 : 0];
+    const float4 tv1 = tsrc[t1 < tab_vec ? t1 : 0];
     Env<V> e;
     load_env<V>(P, ii, e);
     const float4 act = actions[ii];
     QR_TICK(P, 1);
-
-    // one cooperative pass brings [MLP table | gate rows] (<= 4.6 KiB, L2 resident) into LDS; the per-lane weight
-    // registers are then filled from LDS instead of 26 more global loads on the critical path
-    const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
-    float* rtab = lds + kTab;                 // [reset table | gate rows | obs tiles]
-    float* gates = rtab + kResetTableFloats;
-    if (use_mlp) stage_tables(P, lds, 0, kOffGatesImage + P.num_gates * kGateStride);
-    else stage_tables(P, rtab, kOffResetImage, kResetTableFloats + P.num_gates * kGateStride);
+    // unconditional: slots past the table image receive a copy of element 0 and land in unused gate rows / the obs
+    // tiles (written later) -- a predicated second load would be sunk below the state loads and wait for all of them
+    tdst[t0] = tv0;
+    tdst[t1] = tv1;
     __syncthreads();
     MlpRegs mlp;
     if (use_mlp) mlp_load_regs(lds, lane, mlp);
@@ -160,10 +169,10 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
     const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc,
                                      did_reset);
     if (active) {
-        rew_out[i] = reward;
-        done_out[i] = done ? 1 : 0;
-        if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
-        P.ts[i] = pack_ts<V>(e);
+        stream_store(rew_out + i, reward);
+        stream_store(done_out + i, (uint8_t)(done ? 1 : 0));
+        if (trunc_out) stream_store(trunc_out + i, (uint8_t)(trunc ? 1 : 0));
+        stream_store(P.ts + i, pack_ts<V>(e));
     }
     if (P.flags & kFlagPause) return;  // world state and observation untouched (R:570-572)
     QR_TICK(P, 6);
@@ -252,9 +261,9 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
                                              did_reset);
             any_reset |= did_reset;
             if (active) {
-                rew_out[(size_t)k * n + i] = reward;
-                done_out[(size_t)k * n + i] = done ? 1 : 0;
-                if (trunc_out) trunc_out[(size_t)k * n + i] = trunc ? 1 : 0;
+                stream_store(rew_out + (size_t)k * n + i, reward);
+                stream_store(done_out + (size_t)k * n + i, (uint8_t)(done ? 1 : 0));
+                if (trunc_out) stream_store(trunc_out + (size_t)k * n + i, (uint8_t)(trunc ? 1 : 0));
             }
             QR_TICK(P, 6);
             if (!(P.flags & kFlagPause)) {
@@ -350,8 +359,8 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
         if (full_wave) store_obs_coalesced<V, GA>(tile, obs_out + (size_t)k * n * L, (size_t)wave_first, lane, o);
         else if (active) store_obs<V, GA>(obs_out + (size_t)k * n * L, i, o);
         if (active) {
-            act_out[(size_t)k * n + i] = make_float4(a[0], a[1], a[2], a[3]);
-            logp_out[(size_t)k * n + i] = logp;
+            stream_store(act_out + (size_t)k * n + i, make_float4(a[0], a[1], a[2], a[3]));
+            stream_store(logp_out + (size_t)k * n + i, logp);
         }
         QR_TICK(P, 11);
         const float u[4] = {fminf(fmaxf(a[0], -1.0f), 1.0f), fminf(fmaxf(a[1], -1.0f), 1.0f),
@@ -361,9 +370,9 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
                                          did_reset);
         any_reset |= did_reset;
         if (active) {
-            rew_out[(size_t)k * n + i] = reward;
-            done_out[(size_t)k * n + i] = done ? 1 : 0;
-            if (trunc_out) trunc_out[(size_t)k * n + i] = trunc ? 1 : 0;
+            stream_store(rew_out + (size_t)k * n + i, reward);
+            stream_store(done_out + (size_t)k * n + i, (uint8_t)(done ? 1 : 0));
+            if (trunc_out) stream_store(trunc_out + (size_t)k * n + i, (uint8_t)(trunc ? 1 : 0));
         }
         QR_TICK(P, 12);
         observe<V, GA>(P, gates, e, o);
@@ -490,6 +499,11 @@ __global__ void __launch_bounds__(kBlock) clear_episode_kernel(Params P) {
 static inline dim3 grid_for(int n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 // compile-time (variant, gates_ahead) dispatch: keeps every observation index static (registers, no scratch)
+#ifdef QR_GA_ONLY  // developer builds (ISA inspection, tools/phase_timing.py): instantiate one gates_ahead value only
+#define QR_DISPATCH_GA(V, KERNEL, ...)                                                                  \
+    if (P.gates_ahead != QR_GA_ONLY) return hipErrorInvalidValue;                                       \
+    hipLaunchKernelGGL((KERNEL<V, QR_GA_ONLY>), grid_for(P.n), dim3(kBlock), 0, st, __VA_ARGS__);
+#else
 #define QR_DISPATCH_GA(V, KERNEL, ...)                                                                  \
     switch (P.gates_ahead) {                                                                            \
         case 0: hipLaunchKernelGGL((KERNEL<V, 0>), grid_for(P.n), dim3(kBlock), 0, st, __VA_ARGS__); break; \
@@ -499,6 +513,7 @@ static inline dim3 grid_for(int n) { return dim3((unsigned)((n + kBlock - 1) / k
         case 4: hipLaunchKernelGGL((KERNEL<V, 4>), grid_for(P.n), dim3(kBlock), 0, st, __VA_ARGS__); break; \
         default: return hipErrorInvalidValue;                                                           \
     }
+#endif
 
 hipError_t launch_step(int variant, const Params& P, const float* actions, float* obs, float* rew, uint8_t* done,
                        uint8_t* trunc, hipStream_t st) {
@@ -538,6 +553,11 @@ hipError_t launch_rollout_policy(int variant, const Params& P, const PolicyArgs&
                                  float* logp, float* rew, uint8_t* done, uint8_t* trunc, float* last_obs,
                                  hipStream_t st) {
 #define QR_RP(V, GA) return launch_rollout_policy_vg<V, GA>(P, A, K, obs, act, logp, rew, done, trunc, last_obs, st)
+#ifdef QR_GA_ONLY
+    if (P.gates_ahead != QR_GA_ONLY) return hipErrorInvalidValue;
+    if (variant == kE2E) QR_RP(kE2E, QR_GA_ONLY);
+    QR_RP(kINDI, QR_GA_ONLY);
+#else
     if (variant == kE2E) {
         switch (P.gates_ahead) { case 0: QR_RP(kE2E, 0); case 1: QR_RP(kE2E, 1); case 2: QR_RP(kE2E, 2);
                                  case 3: QR_RP(kE2E, 3); case 4: QR_RP(kE2E, 4); }
@@ -545,6 +565,7 @@ hipError_t launch_rollout_policy(int variant, const Params& P, const PolicyArgs&
         switch (P.gates_ahead) { case 0: QR_RP(kINDI, 0); case 1: QR_RP(kINDI, 1); case 2: QR_RP(kINDI, 2);
                                  case 3: QR_RP(kINDI, 3); case 4: QR_RP(kINDI, 4); }
     }
+#endif
 #undef QR_RP
     return hipErrorInvalidValue;
 }

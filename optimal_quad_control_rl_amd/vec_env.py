@@ -85,6 +85,53 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _DeviceBackedArray(np.ndarray):
+    """Host copy of a device-resident env attribute that writes itself back when it is modified in place.
+
+    In the reference `world_states`, `disturbances`, `target_gates` and `step_counts` are plain NumPy arrays owned by
+    the env, and callers edit them in place (`env.world_states[i] = ...`, `env.target_gates[:] = 0`, `R:4499-4500`).
+    Here the state lives in HBM, so the attribute is a snapshot; item / slice assignment and the in-place operators
+    on the snapshot -- or on any view derived from it -- push the whole (small, evaluation-time) array back to the
+    device, which keeps that idiom working instead of silently editing a temporary."""
+
+    def __new__(cls, arr, writeback):
+        obj = np.asarray(arr).view(cls)
+        obj._root, obj._writeback = obj, writeback
+        return obj
+
+    def __array_finalize__(self, src):
+        if src is None:
+            return
+        root = getattr(src, "_root", None)
+        same_memory = root is not None and np.shares_memory(self, root) if root is not None else False
+        self._root = root if same_memory else None          # copies / results of arithmetic are ordinary arrays
+        self._writeback = getattr(src, "_writeback", None) if same_memory else None
+
+    def _push(self):
+        if getattr(self, "_writeback", None) is not None and self._root is not None:
+            self._writeback(np.asarray(self._root))
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        self._push()
+
+    def _inplace(name):
+        def op(self, other):
+            r = getattr(np.ndarray, name)(self, other)
+            self._push()
+            return r
+        op.__name__ = name
+        return op
+
+    for _n in ("__iadd__", "__isub__", "__imul__", "__itruediv__", "__ifloordiv__", "__imod__", "__iand__", "__ior__"):
+        locals()[_n] = _inplace(_n)
+    del _n, _inplace
+
+    def fill(self, value):
+        super().fill(value)
+        self._push()
+
+
 def _f32p(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
@@ -117,11 +164,11 @@ class Quadcopter3DGates(_Base):
         self.gate_yaw = np.asarray(gate_yaw).astype(np.float32)
         self.num_gates = int(self.gate_pos.shape[0])
         self.gates_ahead = int(gates_ahead)
-        self.pause_if_collision = bool(pause_if_collision)
+        self._pause_if_collision = bool(pause_if_collision)
         self.infos_mode = infos_mode
 
         cfg = _lib.QrConfig(self.VARIANT, int(num_envs), self.gates_ahead, self._dev_index,
-                            int(self.pause_if_collision), 0, int(env_id_base))
+                            int(self._pause_if_collision), 0, int(env_id_base))
         h = C.c_void_p()
         _lib.check(self._L.qr_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -218,6 +265,16 @@ class Quadcopter3DGates(_Base):
         _lib.check(self._L.qr_set_pause(self._h, int(self._pause)))
 
     @property
+    def pause_if_collision(self):
+        return self._pause_if_collision
+
+    @pause_if_collision.setter
+    def pause_if_collision(self, v):  # R:293 is a plain attribute read by step_wait (R:573): assignable at any time
+        self._pause_if_collision = bool(v)
+        if getattr(self, "_h", None) is not None:
+            _lib.check(self._L.qr_set_pause_if_collision(self._h, int(self._pause_if_collision)))
+
+    @property
     def disturbance_ranges(self):
         return self._disturbance_ranges
 
@@ -266,7 +323,7 @@ class Quadcopter3DGates(_Base):
 
     @property
     def world_states(self):
-        return self.get_state_tensors()[0].cpu().numpy()
+        return _DeviceBackedArray(self.get_state_tensors()[0].cpu().numpy(), lambda a: self.set_state_tensors(world=a))
 
     @world_states.setter
     def world_states(self, v):
@@ -275,7 +332,7 @@ class Quadcopter3DGates(_Base):
     @property
     def disturbances(self):
         d = self.get_state_tensors()[1]
-        return None if d is None else d.cpu().numpy()
+        return None if d is None else _DeviceBackedArray(d.cpu().numpy(), lambda a: self.set_state_tensors(dist=a))
 
     @disturbances.setter
     def disturbances(self, v):
@@ -283,7 +340,8 @@ class Quadcopter3DGates(_Base):
 
     @property
     def target_gates(self):
-        return self.get_state_tensors()[2].cpu().numpy().astype(np.int64)
+        return _DeviceBackedArray(self.get_state_tensors()[2].cpu().numpy().astype(np.int64),
+                                  lambda a: self.set_state_tensors(target=np.asarray(a, dtype=np.int32)))
 
     @target_gates.setter
     def target_gates(self, v):
@@ -291,7 +349,8 @@ class Quadcopter3DGates(_Base):
 
     @property
     def step_counts(self):
-        return self.get_state_tensors()[3].cpu().numpy().astype(np.int64)
+        return _DeviceBackedArray(self.get_state_tensors()[3].cpu().numpy().astype(np.int64),
+                                  lambda a: self.set_state_tensors(steps=np.asarray(a, dtype=np.int32)))
 
     @step_counts.setter
     def step_counts(self, v):
