@@ -12,22 +12,27 @@ every step's obs / reward / done go to a full rollout buffer [K][N][...] (what P
 step writes fresh HBM.  Inputs are resident in HBM before the timed region.
 
 Two ways to run those K steps through the C ABI are timed, both producing bit-identical outputs:
-  * `value`: qr_step_many -- ONE fused rollout kernel for the K steps (env state stays in registers between steps;
-    the MI355X-native way to replay a recorded action sequence: no per-step launch, state round trip or
-    end-of-kernel write-back);
-  * `per_step_launch`: qr_step_launches -- K step kernels, one per env.step(), the calling pattern of a closed
-    loop whose policy runs between steps (what the reference's SB3 loop does).
-With --gpus N each rank simulates its own 65 536-env shard (weak scaling, no data-path collective); the
-rollout-boundary RCCL all-gather of [obs|reward|done] is measured separately ("exchange").
+  * `value`: qr_step_many -- ONE fused rollout kernel for the K steps (env state stays in registers between steps);
+  * `per_step_launch`: qr_step_launches -- K step kernels, one per env.step() (closed-loop calling pattern).
+Timing: the K-step region is repeated back-to-back R times inside ONE barrier + synchronize bracket, R chosen (the
+same on every rank) so that the bracket holds >= 20 ms of work; `ms_per_step` = bracket / (R K); the whole bracket is
+measured `--repeats` times (median reported, all values listed).  `steps` stays K.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel of the timed region: SURVEY 8(d)
-algorithmic bytes per launch / hipEvent launch duration on the launch stream; `traffic` = HBM bytes per launch from
-the rocprofv3 FETCH_SIZE/WRITE_SIZE passes in profiles/pmc_summary.json), "cpu_baseline" (the CPU oracle -- a C port
-of the reference, parity-pinned -- timed on this box's host cores on a bounded sample), "parity" (north_star
-single-trajectory max |d state| vs the reference's recorded step()).
+Roofline objects (every `frac` is against the roof that binds that kernel, and can be recomputed from `profiles/`):
+  * fused rollout kernel (the dominant kernel of `value`): bound "hbm" on the bytes THAT kernel moves (action in, obs / reward /
+    done out: 118 B E2E, 90 B INDI per env-step; `traffic` = the PMC FETCH_SIZE / WRITE_SIZE measurement, profiles/pmc_summary.json),
+    with the f32 vector + matrix-core flop rate (PMC instruction counts, profiles/r02_pmc_compute.json) vs the 157.3 TFLOP/s
+    f32 vector peak beside it as `valu` -- the larger fraction names the binding roof;
+  * per-step kernel: bound "hbm" -- SURVEY 8(d) algorithmic bytes (= the measured traffic, ratio 1.01) / average launch
+    duration vs 8 TB/s, with the launch floor of an empty kernel of the same shape (profiles/r02_launch_floor.json);
+  * closed-loop kernel: bound "mfma" -- policy-MLP f16 flop per env-step / duration vs the 2.5 PFLOP/s dense f16 peak.
+Extra objects: "indi" (BASELINE config 3, same measurements), "config4" (N > 1: 32 768 envs per GPU + RCCL all-gather of
+the rollout), "cpu_baseline" (the CPU oracle -- a C port of the reference, parity-pinned -- on this box's host cores, bounded
+sample), "parity" (north_star single-trajectory max |d state| vs the reference's recorded step()).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -37,13 +42,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+VALU_F32_PEAK_TF = 157.3  # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
+MFMA_F16_PEAK_TF = 2500.0  # dense f16 / bf16 matrix peak
 BYTES_PER_ENV_STEP = {"e2e": lambda ga: 189 + 4 * (20 + 4 * ga), "indi": lambda ga: 141 + 4 * (13 + 4 * ga)}
 # e2e: read world 64 + dist 24 + action 16 + target 4 + steps 4 = 112; write world 64 + obs 4*(20+4G) + reward 4
 #      + done 1 + target 4 + steps 4  -> 285 B at G=1.  indi: read 52+16+4+4 = 76; write 52 + 4*(13+4G) + 13 -> 209 B.
+# fused rollout kernel (qr_step_many): the env state never leaves registers, so per env-step it moves only the action in and
+# obs / reward / done / trunc out: E2E 16 + 4*(20+4G) + 6 = 118 B, INDI 16 + 4*(13+4G) + 6 = 90 B at G=1 (PMC: 121.5 / 92.3 B)
+FUSED_BYTES_PER_ENV_STEP = {"e2e": lambda ga: 16 + 4 * (20 + 4 * ga) + 6, "indi": lambda ga: 16 + 4 * (13 + 4 * ga) + 6}
+MIN_TIMED_MS = 20.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -51,13 +62,14 @@ def parse():
     ap.add_argument("--variant", default="e2e", choices=["e2e", "indi"])
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--gates-ahead", type=int, default=1)
-    ap.add_argument("--repeats", type=int, default=5, help="timed repetitions of the K-step region (median reported)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed repetitions of the >= 20 ms bracket (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exchange", action="store_true")
     ap.add_argument("--no-residual", action="store_true", help="experiment: E2E without the residual MLPs")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the indi / ppo / predecessor / host-path objects")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def make_env(variant, n, ga, env_id_base, seed=0, residual="default"):
@@ -72,6 +84,221 @@ def make_env(variant, n, ga, env_id_base, seed=0, residual="default"):
         env = Quadcopter3DGatesINDI(n, *square_track(), gates_ahead=ga, seed=seed, env_id_base=env_id_base,
                                     infos_mode="none")
     return env
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# distributed plumbing: one process per GPU (RCCL) -- or per CPU rank over gloo in tests/test_bench_gloo.py
+# ---------------------------------------------------------------------------------------------------------------------
+class Runtime:
+    def __init__(self, rank=0, local_rank=0, world=1, device=None, use_cuda=True):
+        self.rank, self.local_rank, self.world, self.device, self.use_cuda = rank, local_rank, world, device, use_cuda
+
+    @classmethod
+    def from_env(cls, expected_world):
+        import torch
+        import torch.distributed as dist
+
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if expected_world != world and world > 1:
+            raise SystemExit(f"--gpus {expected_world} but WORLD_SIZE={world}")
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        return cls(rank, local_rank, world, torch.device("cuda", local_rank), True)
+
+    def env_id_base(self, envs_per_rank):
+        """global index of this rank's env 0: rank r owns global envs [r n, (r + 1) n) (keys the reset RNG stream)"""
+        return self.rank * int(envs_per_rank)
+
+    def sync(self):
+        if self.use_cuda:
+            import torch
+
+            torch.cuda.synchronize()
+
+    def barrier(self):
+        self.sync()
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+            self.sync()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return float(x)
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor([float(x)], device=self.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def finish(self):
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def timed_region(rt, fn, repeats, min_ms=MIN_TIMED_MS, max_reps=100000):
+    """Time fn() (= EXACTLY K steps) with barrier + synchronize on both sides.  fn is repeated R times inside one bracket
+    so that the bracket holds >= min_ms of work (R is derived from an all-reduced estimate: identical on every rank);
+    returns (seconds per fn() = median bracket / R, maximum over ranks; list of per-bracket seconds per fn(); R)."""
+    def bracket(R):
+        rt.barrier()
+        t0 = time.perf_counter()
+        for _ in range(R):
+            fn()
+        rt.barrier()
+        return time.perf_counter() - t0
+
+    R = 1
+    for _ in range(6):  # grow R until one bracket holds >= min_ms (decisions on the all-reduced time: same R on every rank)
+        el = rt.max_over_ranks(bracket(R))
+        if el >= min_ms * 1e-3 or R >= max_reps:
+            break
+        R = int(min(max_reps, max(R + 1, math.ceil(1.15 * R * min_ms * 1e-3 / max(el, 1e-7)))))
+    ts = [bracket(R) / R for _ in range(max(1, repeats))]
+    return rt.max_over_ranks(float(np.median(ts))), ts, R
+
+
+def _load_json(*path):
+    try:
+        return json.load(open(os.path.join(ROOT, *path)))
+    except Exception:
+        return {}
+
+
+def exchange_probe(rt, obs, rew, done):
+    """rollout-boundary exchange (config 4): all-gather of the packed [obs | reward | done] shard"""
+    import torch
+    import torch.distributed as dist
+    from optimal_quad_control_rl_amd.sharded import pack_rollout
+
+    packed = pack_rollout(obs, rew, done)
+    gathered = torch.empty((rt.world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(gathered, packed)
+    rt.barrier()
+    t0 = time.perf_counter()
+    dist.all_gather_into_tensor(gathered, packed)
+    rt.barrier()
+    dt = rt.max_over_ranks(time.perf_counter() - t0)
+    nbytes = packed.numel() * packed.element_size()
+    return {"op": "all_gather_into_tensor", "steps": int(packed.shape[0]), "bytes_per_rank": nbytes, "ms": dt * 1e3,
+            "GBps_in_per_gpu": nbytes * (rt.world - 1) / dt / 1e9, "gathered_shape": list(gathered.shape)}
+
+
+def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
+    """Times the fused rollout, the per-step launches and the closed-loop kernel of one env shard; returns the objects of
+    the JSON line (rates are whole-job: n x world envs)."""
+    import torch
+
+    L, dev = env.state_len, env.device
+    gen = torch.Generator(device=dev).manual_seed(rt.rank)  # torch Philox, seed = rank
+    KB = max(K, W, 1)
+    actions = torch.rand((KB, n, 4), device=dev, generator=gen) * 2 - 1
+    out = (torch.empty((KB, n, L), dtype=torch.float32, device=dev), torch.empty((KB, n), dtype=torch.float32, device=dev),
+           torch.empty((KB, n), dtype=torch.uint8, device=dev), torch.empty((KB, n), dtype=torch.uint8, device=dev))
+
+    def view(k):
+        return tuple(t[:k] for t in out)
+
+    env.reset_device()
+    if W > 0:
+        env.rollout_device(actions[:W], view(W))
+    total_steps = n * rt.world * K
+    pmc = _load_json("profiles", "pmc_summary.json").get(f"{variant}_n{n}_ga{ga}", {})
+    pmcc = _load_json("profiles", "r02_pmc_compute.json").get("kernels", {})
+    vidx = 0 if variant == "e2e" else 1
+    floor = _load_json("profiles", "r02_launch_floor.json").get("us_per_launch", {})
+    bytes_per_step = BYTES_PER_ENV_STEP[variant](ga) * n
+
+    # (1) fused rollout: qr_step_many = ONE kernel for the K steps, env state register-resident between steps
+    fused_s, fused_ts, fused_R = timed_region(rt, lambda: env.rollout_device(actions[:K], view(K)), repeats)
+    fused_kernel_ms = env.last_rollout_ms()  # hipEvents around the last launch, on the launch stream
+    launch_s = fused_kernel_ms * 1e-3
+    flop = pmcc.get(f"rollout_kernel<{vidx}, {ga}>", {}).get("derived", {}).get("f32_flop_per_env_step")
+    traffic = pmc.get("fused_hbm_bytes_per_step")
+    fused_bytes = FUSED_BYTES_PER_ENV_STEP[variant](ga) * n
+    ach = fused_bytes * K / launch_s / 1e9
+    tf = None if flop is None else flop * n * K / launch_s / 1e12
+    roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None if traffic is None else traffic * K,
+                "kernel": f"qr::rollout_kernel<{variant},ga={ga}> (one launch = {K} steps)",
+                "launch_us": fused_kernel_ms * 1e3, "us_per_step": fused_kernel_ms * 1e3 / K,
+                "bytes_per_launch": fused_bytes * K, "bytes_per_env_step": FUSED_BYTES_PER_ENV_STEP[variant](ga),
+                "note": "algorithmic bytes of THIS kernel: the env state stays in registers for the K steps, so a step moves its action in "
+                        "and obs / reward / done / trunc out (PMC-measured traffic agrees within 3 %); the SURVEY 8(d) per-step figure "
+                        "(%d B, state read + written every step) describes the per-step kernel and is used only there"
+                        % BYTES_PER_ENV_STEP[variant](ga),
+                "valu": {"bound": "valu", "achieved": tf, "peak": VALU_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": None if tf is None else tf / VALU_F32_PEAK_TF, "flop_per_env_step": flop,
+                         "flop_source": "PMC: 64 x (ADD + MUL + TRANS + 2 FMA f32 wave-instructions) + 512 x MFMA_MOPS_F32 per env-step, "
+                                        "profiles/r02_pmc_compute.json; the larger of the two fractions names the binding roof"}}
+    res = {"value": total_steps / fused_s, "ms_per_step": fused_s * 1e3 / K, "repeats": len(fused_ts), "launches_per_bracket": fused_R,
+           "timed_ms_per_bracket": fused_s * fused_R * 1e3, "all_ms_per_step": [t * 1e3 / K for t in fused_ts], "roofline": roofline}
+
+    # (2) per-step launches: K step kernels (one per env.step()), captured once into a graph by qr_step_launches and replayed
+    step_s, step_ts, step_R = timed_region(rt, lambda: env.step_sequence_device(actions[:K], view(K)), repeats)
+    region_ms = env.last_rollout_ms()       # hipEvents bracketing the K back-to-back step kernels on the launch stream
+    res["done_fraction"] = float(out[2][:K].float().mean().item())
+    kernel_ms = region_ms / K
+    ach = bytes_per_step / (kernel_ms * 1e-3) / 1e9
+    res["per_step_launch"] = {
+        "what": "qr_step_launches: the same K steps as K step kernels (one per env.step(); bit-identical outputs), the "
+                "closed-loop calling pattern; the K launches are one captured graph, replayed",
+        "value": total_steps / step_s, "unit": "env-steps/s", "ms_per_step": step_s * 1e3 / K, "launches_per_bracket": step_R * K,
+        "timed_ms_per_bracket": step_s * step_R * 1e3, "all_ms_per_step": [t * 1e3 / K for t in step_ts],
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": pmc.get("hbm_bytes_per_launch"), "kernel": f"qr::step_kernel<{variant},ga={ga}>",
+                     "kernel_us": kernel_ms * 1e3, "bytes_per_launch": bytes_per_step, "launches_timed": K,
+                     "launch_floor_us": {k: floor.get(k) for k in ("empty_b256", "empty_b256_graph", "copy_nt_b256", "copy_nt_b256_graph")
+                                         if k in floor},
+                     "launch_floor_note": "tools/ubench/launch_floor.hip at the same shape (256 workgroups x 256 threads, back-to-back "
+                                          "dependent launches): empty kernel / a kernel that only moves the E2E step's 285 B per env"}}
+
+    # (3) closed loop (config 5 collect phase): policy MLP + sampling + env step in one kernel
+    if closed_loop:
+        try:
+            from optimal_quad_control_rl_amd.policy import MfmaPolicy
+            from optimal_quad_control_rl_amd.ppo import ActorCritic
+
+            torch.manual_seed(0)
+            net = ActorCritic(L, 4).to(dev)  # random-init weights of the reference's policy architecture (R:783)
+            pol = MfmaPolicy(L, dev.index).load_torch(net.pi)
+            Kc = min(K, 256)
+            state = {"out": None, "r": 0}
+
+            def cl():
+                r = env.rollout_policy_device(pol, Kc, torch.zeros(4), noise_seed=rt.rank, first_step=state["r"] * Kc, out=state["out"])
+                state["out"], state["r"] = r[:6], state["r"] + 1
+
+            cl()
+            cl_s, cl_ts, cl_R = timed_region(rt, cl, min(repeats, 3))
+            cl_ms = env.last_rollout_ms()
+            pol_flop = 2.0 * ((L + 1) * 128 + 2 * 128 * 128 + 128 * 32)   # issued f16 MACs x 2 (padded tiles, as executed)
+            cl_tf = pol_flop * n * Kc / (cl_ms * 1e-3) / 1e12
+            res["closed_loop"] = {
+                "what": "qr_rollout_policy: K x [obs -> policy MLP (L->120->120->120->4, f16 MFMA) -> Gaussian sample -> env.step] in "
+                        "ONE kernel (PPO collect phase); random-init policy weights",
+                "steps": Kc, "ms_per_step": cl_s * 1e3 / Kc, "value": n * rt.world * Kc / cl_s, "unit": "env-steps/s",
+                "kernel_us_per_step": cl_ms * 1e3 / Kc,
+                "roofline": {"bound": "mfma", "achieved": cl_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": cl_tf / MFMA_F16_PEAK_TF,
+                             "flop_per_env_step": pol_flop, "traffic": None,
+                             "note": "f16 matrix-core flop of the policy MLP as issued (160-180 v_mfma_f32_32x32x16_f16 per 64 envs); the "
+                                     "kernel is one wave per SIMD: issue-order-bound between MFMA chain, sampling and the env step "
+                                     "(profiles/r02_pmc_compute.json: MFMA busy ~39 % of wave cycles)"}}
+            del state
+        except Exception as ex:  # pragma: no cover
+            res["closed_loop"] = {"error": repr(ex)}
+    res["_buffers"] = (out, K)
+    return res
 
 
 def parity_probe():
@@ -151,206 +378,119 @@ def cpu_baseline(variant, n, ga, seconds):
             "value_1core": out[1][0], "host_cores": cores}
 
 
+def workload_text(variant, n, ga):
+    return (f"{n} envs/GPU, " + ("Bebop E2E (motor-cmd actions) + NNDroneModel residual MLPs + training disturbance ranges, 7-gate zigzag"
+                                 if variant == "e2e" else "INDI inner-loop variant, 4-gate square (x2)")
+            + f", gates_ahead={ga}, U(-1,1) actions pre-generated on device [K][N][4], outputs to a [K][N] rollout buffer")
+
+
+def run(args, rt, env_factory=make_env, closed_loop=True):
+    """The measurement proper (also driven with a CPU stand-in over gloo by tests/test_bench_gloo.py)."""
+    n, K, W, ga = args.envs, args.steps, args.warmup, args.gates_ahead
+    env = env_factory(args.variant, n, ga, rt.env_id_base(n), 0, None if args.no_residual else "default")
+    m = measure_env(rt, env, args.variant, n, K, W, ga, args.repeats, closed_loop=closed_loop)
+    (out, _) = m.pop("_buffers")
+    L = env.state_len
+    result = {
+        "metric": "env-steps/sec at N=%d envs per GPU (Quadcopter3DGates.step, " % n
+                  + ("E2E + residual MLPs" if args.variant == "e2e" else "INDI inner loop") + ")",
+        "value": m.pop("value"), "unit": "env-steps/s", "n_gpus": rt.world, "steps": K, "warmup": W,
+        "ms_per_step": m.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload_text(args.variant, n, ga), "envs_per_gpu": n, "variant": args.variant, "gates_ahead": ga,
+                   "obs_len": L, "sharding": f"{rt.world} independent shard(s), env_id_base = rank*N"},
+        "path": "qr_step_many (fused K-step rollout kernel)",
+    }
+    result.update(m)
+
+    # --- rollout-boundary exchange: RCCL all-gather of [obs | reward | done] of this run's shard ------------------------
+    if rt.world > 1 and not args.no_exchange:
+        Kx = min(K, 64)
+        result["exchange"] = exchange_probe(rt, out[0][:Kx], out[1][:Kx], out[2][:Kx])
+    del out
+
+    # --- BASELINE config 4: 32 768 envs per GPU (262 144 on 8), all-gather of every rollout --------------------------------
+    if rt.world > 1 and not args.no_exchange and not args.no_extras:
+        import torch
+
+        n4, K4 = 32768 if n >= 32768 else n, min(K, 64)
+        env4 = env_factory(args.variant, n4, ga, rt.env_id_base(n4), 0, None if args.no_residual else "default")
+        env4.reset_device()
+        dev = env4.device
+        gen = torch.Generator(device=dev).manual_seed(1000 + rt.rank)
+        a4 = torch.rand((K4, n4, 4), device=dev, generator=gen) * 2 - 1
+        o4 = None
+        state = {}
+
+        def roll4():
+            state["o"] = env4.rollout_device(a4, state.get("o"))
+
+        roll4()
+        s4, ts4, R4 = timed_region(rt, roll4, min(args.repeats, 3))
+        ex4 = exchange_probe(rt, state["o"][0], state["o"][1], state["o"][2])
+        sim_ms = s4 * 1e3
+        result["config4"] = {
+            "what": "BASELINE config 4: %d envs sharded over %d GPUs (%d per GPU); per rollout of %d steps: fused rollout kernel, then one "
+                    "RCCL all-gather of the packed [obs | reward | done] shard" % (n4 * rt.world, rt.world, n4, K4),
+            "envs_total": n4 * rt.world, "envs_per_gpu": n4, "steps": K4, "simulate_ms": sim_ms, "simulate_value": n4 * rt.world * K4 / s4,
+            "exchange": ex4, "xgmi_in_peak_GBps_per_gpu": 7 * 153.0,
+            "value_incl_exchange": n4 * rt.world * K4 / (s4 + ex4["ms"] * 1e-3), "unit": "env-steps/s"}
+        del state, a4, o4
+        env4.close()
+
+    if rt.rank == 0 and rt.world == 1 and rt.use_cuda:
+        if not args.no_parity:
+            try:
+                result["parity"] = parity_probe()
+            except Exception as ex:  # pragma: no cover
+                result["parity"] = {"error": repr(ex)}
+        if not args.no_extras:
+            # --- BASELINE config 3 (INDI inner loop) driver-timed beside config 2 -----------------------------------------
+            other = "indi" if args.variant == "e2e" else "e2e"
+            try:
+                env_o = env_factory(other, n, ga, rt.env_id_base(n), 0, "default")
+                mo = measure_env(rt, env_o, other, n, K, W, ga, min(args.repeats, 3), closed_loop=closed_loop)
+                mo.pop("_buffers")
+                mo["unit"] = "env-steps/s"
+                mo["config"] = {"workload": workload_text(other, n, ga), "variant": other}
+                if not args.no_cpu_baseline:
+                    mo["cpu_baseline"] = cpu_baseline(other, n, ga, min(args.cpu_seconds, 6.0))
+                result[other] = mo
+                env_o.close()
+            except Exception as ex:  # pragma: no cover
+                result[other] = {"error": repr(ex)}
+        if not args.no_cpu_baseline and not args.no_extras:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            try:  # SURVEY 8(f) #1: the PPO minibatch update on the matrix cores (qr_ppo_minibatch) vs torch; measured
+                # before the CPU legs (their worker threads would compete with the launch thread)
+                from bench_ppo_update import measure as ppo_measure
+
+                result["ppo_update"] = ppo_measure(L, 16384, 65536 * 8, 100)
+            except Exception as ex:  # pragma: no cover
+                result["ppo_update"] = {"error": repr(ex)}
+            try:
+                result["host_numpy_path"] = host_path_probe(args.variant, n, ga)
+            except Exception as ex:  # pragma: no cover
+                result["host_numpy_path"] = {"error": repr(ex)}
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.variant, n, ga, args.cpu_seconds)
+        if not args.no_cpu_baseline and not args.no_extras:
+            try:  # SURVEY 8(f) #4: the predecessor envs of "3D quad.ipynb" (include/quad3d.h), short measurement
+                from bench_quad3d import measure as q3_measure
+
+                result["predecessor_envs"] = {k: q3_measure(k, n, 200, repeats=3, cpu_seconds=2.0) for k in ("hover", "gates")}
+            except Exception as ex:  # pragma: no cover
+                result["predecessor_envs"] = {"error": repr(ex)}
+    return result
+
+
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    n, K, W, ga = args.envs, args.steps, args.warmup, args.gates_ahead
-    env = make_env(args.variant, n, ga, env_id_base=rank * n, seed=0, residual=None if args.no_residual else "default")
-    L = env.state_len
-    dev = env.device
-    gen = torch.Generator(device=dev).manual_seed(rank)  # torch Philox, seed = rank
-    KB = max(K, W, 1)
-    actions = torch.rand((KB, n, 4), device=dev, generator=gen) * 2 - 1
-    out = (torch.empty((KB, n, L), dtype=torch.float32, device=dev), torch.empty((KB, n), dtype=torch.float32, device=dev),
-           torch.empty((KB, n), dtype=torch.uint8, device=dev), torch.empty((KB, n), dtype=torch.uint8, device=dev))
-
-    def view(k):
-        return tuple(t[:k] for t in out)
-
-    env.reset_device()
-    if W > 0:
-        env.rollout_device(actions[:W], view(W))
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def timed(fn):
-        ts = []
-        for _ in range(max(1, args.repeats)):
-            barrier()
-            t0 = time.perf_counter()
-            fn()  # EXACTLY K steps
-            barrier()
-            ts.append(time.perf_counter() - t0)
-        el = float(np.median(ts))
-        if world > 1:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el, ts
-
-    # (1) fused rollout: qr_step_many = ONE kernel for the K steps, env state register-resident between steps
-    fused_elapsed, fused_times = timed(lambda: env.rollout_device(actions[:K], view(K)))
-    fused_kernel_ms = env.last_rollout_ms()  # hipEvents around the single launch, on the launch stream
-    # (2) per-step launches: K x qr_step, one kernel per env.step() (closed-loop calling pattern)
-    elapsed, times = timed(lambda: env.step_sequence_device(actions[:K], view(K)))
-    step_region_ms = env.last_rollout_ms()  # hipEvents bracketing the K back-to-back step kernels on the launch stream
-    dones_frac = float(out[2][:K].float().mean().item())
-
-    # --- roofline ------------------------------------------------------------------------------------------------
-    # Algorithmic bytes per env-step: 285 B (E2E, G=1) / 209 B (INDI): state read+written
-    # once, action read once, outputs written once.
-    bytes_per_step = BYTES_PER_ENV_STEP[args.variant](ga) * n
-    pmc = {}
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path)).get(f"{args.variant}_n{n}_ga{ga}", {})
-        except Exception:
-            pmc = {}
-    # (a) fused rollout kernel: ONE launch = K steps; duration from hipEvents around that launch on its stream
-    fused_launch_s = fused_kernel_ms * 1e-3
-    fused_ach = bytes_per_step * K / fused_launch_s / 1e9
-    fused_traffic = pmc.get("fused_hbm_bytes_per_step")
-    roofline = {"bound": "hbm", "achieved": fused_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fused_ach / HBM_PEAK_GBS,
-                "traffic": None if fused_traffic is None else fused_traffic * K,
-                "kernel": f"qr::rollout_kernel<{args.variant},ga={ga}> (one launch = {K} steps)",
-                "launch_us": fused_kernel_ms * 1e3, "us_per_step": fused_kernel_ms * 1e3 / K,
-                "bytes_per_launch": bytes_per_step * K,
-                "note": "algorithmic bytes per SURVEY 8(d); the fused kernel keeps the env state in registers, so its real "
-                        "HBM traffic (PMC) is the action + output bytes only: frac_of_measured_traffic is its true HBM "
-                        "utilisation -- the kernel is VALU/latency bound, not HBM bound",
-                "frac_of_measured_traffic": None if fused_traffic is None else fused_traffic / (fused_launch_s / K) / 1e9 / HBM_PEAK_GBS}
-    # (b) per-step kernel: the K step kernels run back-to-back on one stream (rocprofv3: median gap 0 ns), so the
-    #     hipEvent time over the timed region / K is the average launch duration (per-launch event pairs are also
-    #     reported, but the markers themselves stretch an ~8 us kernel by 2-3 us)
-    mean_kernel_ms = step_region_ms / K
-    Kp = min(K, 200)
-    pair_kernel_ms, _ = env.profile_rollout(actions[:Kp], view(Kp))
-    step_ach = bytes_per_step / (mean_kernel_ms * 1e-3) / 1e9
-    step_roofline = {"bound": "hbm", "achieved": step_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_ach / HBM_PEAK_GBS,
-                     "traffic": pmc.get("hbm_bytes_per_launch"), "kernel": f"qr::step_kernel<{args.variant},ga={ga}>",
-                     "kernel_us": mean_kernel_ms * 1e3, "bytes_per_launch": bytes_per_step, "launches_timed": K,
-                     "kernel_us_event_pair_per_launch": pair_kernel_ms * 1e3}
-
-    # --- closed loop (config 5 collect phase): policy MLP + sampling + env step in one kernel --------------------------
-    closed_loop = None
-    try:
-        from optimal_quad_control_rl_amd.policy import MfmaPolicy
-        from optimal_quad_control_rl_amd.ppo import ActorCritic
-
-        torch.manual_seed(0)
-        net = ActorCritic(L, 4).to(dev)  # random-init weights of the reference's policy architecture (R:783)
-        pol = MfmaPolicy(L, dev.index).load_torch(net.pi)
-        Kc = min(K, 256)
-        cl_out = None
-        cl_t = []
-        for r in range(3):
-            barrier()
-            t0 = time.perf_counter()
-            cl_res = env.rollout_policy_device(pol, Kc, torch.zeros(4), noise_seed=rank, first_step=r * Kc, out=cl_out)
-            barrier()
-            cl_t.append(time.perf_counter() - t0)
-            cl_out = cl_res[:6]
-        cl_el = float(np.median(cl_t[1:]))
-        closed_loop = {"what": "qr_rollout_policy: K x [obs -> policy MLP (L->120->120->120->4, f16 MFMA) -> Gaussian sample -> "
-                               "env.step] in ONE kernel (PPO collect phase); random-init policy weights",
-                       "steps": Kc, "ms_per_step": cl_el * 1e3 / Kc, "value": n * world * Kc / cl_el, "unit": "env-steps/s",
-                       "kernel_us_per_step": env.last_rollout_ms() * 1e3 / Kc}
-        del cl_out, cl_res
-    except Exception as ex:  # pragma: no cover
-        closed_loop = {"error": repr(ex)}
-
-    # --- rollout-boundary exchange (config 4): RCCL all-gather of [obs | reward | done] --------------------------
-    exchange = None
-    if world > 1 and not args.no_exchange:
-        from optimal_quad_control_rl_amd.sharded import pack_rollout
-
-        Kx = min(K, 64)
-        packed = pack_rollout(out[0][:Kx], out[1][:Kx], out[2][:Kx])
-        gathered = torch.empty((world * Kx,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered, packed)
-        barrier()
-        t0 = time.perf_counter()
-        dist.all_gather_into_tensor(gathered, packed)
-        barrier()
-        dt = time.perf_counter() - t0
-        exchange = {"op": "all_gather_into_tensor(RCCL)", "steps": Kx, "bytes_per_rank": packed.numel() * 4,
-                    "ms": dt * 1e3, "GBps_in_per_gpu": packed.numel() * 4 * (world - 1) / dt / 1e9}
-
-    if rank == 0:
-        total_steps = n * world * K
-        result = {
-            "metric": "env-steps/sec at N=65536 envs per GPU (Quadcopter3DGates.step, "
-                      + ("E2E + residual MLPs" if args.variant == "e2e" else "INDI inner loop") + ")",
-            "value": total_steps / fused_elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": fused_elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n} envs/GPU, " + ("Bebop E2E (motor-cmd actions) + NNDroneModel residual MLPs + "
-                                                         "training disturbance ranges, 7-gate zigzag"
-                                                         if args.variant == "e2e" else "INDI inner-loop variant, 4-gate square (x2)")
-                       + f", gates_ahead={ga}, U(-1,1) actions pre-generated on device [K][N][4], outputs to a [K][N] rollout buffer",
-                       "envs_per_gpu": n, "variant": args.variant, "gates_ahead": ga, "obs_len": L,
-                       "sharding": f"{world} independent shard(s), env_id_base = rank*N"},
-            "path": "qr_step_many (fused K-step rollout kernel)",
-            "repeats": len(fused_times), "all_ms_per_step": [t * 1e3 / K for t in fused_times], "done_fraction": dones_frac,
-            "roofline": roofline,
-            "per_step_launch": {
-                "what": "qr_step_launches: the same K steps as K step-kernel launches (one per env.step(); bit-identical "
-                        "outputs) -- the closed-loop calling pattern",
-                "value": total_steps / elapsed, "unit": "env-steps/s", "ms_per_step": elapsed * 1e3 / K,
-                "all_ms_per_step": [t * 1e3 / K for t in times], "roofline": step_roofline},
-        }
-        if closed_loop:
-            result["closed_loop"] = closed_loop
-        if exchange:
-            result["exchange"] = exchange
-        if world == 1:
-            if not args.no_parity:
-                try:
-                    result["parity"] = parity_probe()
-                except Exception as ex:  # pragma: no cover
-                    result["parity"] = {"error": repr(ex)}
-            if not args.no_cpu_baseline:
-                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
-                try:  # the PPO minibatch update on the matrix cores (qr_ppo_minibatch) vs torch; measured
-                    # before the CPU legs (their worker threads would compete with the launch thread: six launches per update)
-                    from bench_ppo_update import measure as ppo_measure
-
-                    result["ppo_update"] = ppo_measure(L, 16384, 65536 * 8, 100)
-                except Exception as ex:  # pragma: no cover
-                    result["ppo_update"] = {"error": repr(ex)}
-                try:
-                    result["host_numpy_path"] = host_path_probe(args.variant, n, ga)
-                except Exception as ex:  # pragma: no cover
-                    result["host_numpy_path"] = {"error": repr(ex)}
-                result["cpu_baseline"] = cpu_baseline(args.variant, n, ga, args.cpu_seconds)
-                try:  # the predecessor envs of "3D quad.ipynb" (include/quad3d.h), short measurement
-                    from bench_quad3d import measure as q3_measure
-
-                    result["predecessor_envs"] = {k: q3_measure(k, n, 200, repeats=3, cpu_seconds=2.0) for k in ("hover", "gates")}
-                except Exception as ex:  # pragma: no cover
-                    result["predecessor_envs"] = {"error": repr(ex)}
+    rt = Runtime.from_env(args.gpus)
+    result = run(args, rt)
+    if rt.rank == 0:
         print(json.dumps(result))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    rt.finish()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,113 @@
+"""bench.py's multi-rank code path on CPU: two gloo ranks drive bench.run() with a stand-in env built on the TEST-ONLY
+oracle -- rank -> env_id_base mapping, the barrier / max-over-ranks timing bracket (same repeat count on every rank), the
+rollout-boundary all-gather ("exchange") and the BASELINE config-4 object.  On the GPU box the same function runs the HIP
+product over RCCL (python -m torch.distributed.run ... bench.py --gpus N)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+class CpuBenchEnv:
+    """The device API bench.measure_env() uses, on the CPU oracle."""
+
+    created = []
+
+    def __init__(self, variant, n, ga, env_id_base, seed=0, residual=None):
+        import parity as P
+        from oracle import oracle as O
+        from oracle_adapter import OracleAdapter
+
+        v = O.E2E if variant == "e2e" else O.INDI
+        self.a = OracleAdapter(v, n, P.tracks()["zigzag" if variant == "e2e" else "square"], gates_ahead=ga, seed=seed,
+                               env_id_base=env_id_base)
+        self.num_envs, self.device = n, torch.device("cpu")
+        self.state_len = (16 + 4 * ga + 4) if variant == "e2e" else (13 + 4 * ga)
+        self._ms = 0.0
+        CpuBenchEnv.created.append((variant, n, env_id_base))
+
+    def reset_device(self):
+        return torch.from_numpy(self.a.reset())
+
+    def rollout_device(self, actions, out=None):
+        import time
+
+        K = actions.shape[0]
+        if out is None:
+            out = (torch.empty((K, self.num_envs, self.state_len)), torch.empty((K, self.num_envs)),
+                   torch.empty((K, self.num_envs), dtype=torch.uint8), torch.empty((K, self.num_envs), dtype=torch.uint8))
+        t0 = time.perf_counter()
+        for k in range(K):
+            o, r, d, t = self.a.step(actions[k].numpy())
+            out[0][k] = torch.from_numpy(o)
+            out[1][k] = torch.from_numpy(r)
+            out[2][k] = torch.from_numpy(d.astype(np.uint8))
+            out[3][k] = torch.from_numpy(t.astype(np.uint8))
+        self._ms = (time.perf_counter() - t0) * 1e3
+        return out
+
+    step_sequence_device = rollout_device
+
+    def last_rollout_ms(self):
+        return self._ms
+
+    def close(self):
+        pass
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+
+    args = bench.parse(["--gpus", str(world), "--steps", "6", "--warmup", "2", "--envs", "64", "--repeats", "2",
+                        "--no-cpu-baseline", "--no-parity", "--variant", "indi"])
+    rt = bench.Runtime(rank, 0, world, torch.device("cpu"), use_cuda=False)
+    assert rt.env_id_base(64) == rank * 64
+    res = bench.run(args, rt, env_factory=CpuBenchEnv, closed_loop=False)
+    # every env this rank built is keyed by rank * n (main shard and the config-4 shard)
+    assert CpuBenchEnv.created and all(base == rank * n for (_, n, base) in CpuBenchEnv.created), CpuBenchEnv.created
+    # same repeat count and same (max-reduced) time on every rank
+    probe = torch.tensor([res["launches_per_bracket"], res["ms_per_step"]], dtype=torch.float64)
+    both = [torch.empty_like(probe) for _ in range(world)]
+    dist.all_gather(both, probe)
+    assert torch.equal(both[0], both[1])
+    if rank == 0:
+        json.dumps(res)  # serialisable
+        assert res["n_gpus"] == world and res["steps"] == 6 and res["scaling"] == "weak"
+        assert abs(res["value"] - 64 * world * 6 / (res["ms_per_step"] * 1e-3 * 6)) < 1e-6 * res["value"]
+        assert res["timed_ms_per_bracket"] >= 0.9 * bench.MIN_TIMED_MS
+        ex = res["exchange"]
+        assert ex["gathered_shape"] == [world * 6, 64, 17 + 2] and ex["bytes_per_rank"] == 6 * 64 * 19 * 4
+        c4 = res["config4"]
+        assert c4["envs_total"] == 64 * world and c4["exchange"]["gathered_shape"][0] == world * c4["steps"]
+        assert res["per_step_launch"]["roofline"]["bound"] == "hbm" and res["roofline"]["bound"] == "hbm" and res["roofline"]["frac"] < 1.0
+        open(os.path.join(tmp, "ok"), "w").write("ok")
+    rt.finish()
+
+
+def test_bench_multirank_path_world2(tmp_path):
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def test_timed_region_fills_the_bracket():
+    import time
+
+    import bench
+
+    rt = bench.Runtime(0, 0, 1, torch.device("cpu"), use_cuda=False)
+    per, ts, R = bench.timed_region(rt, lambda: time.sleep(0.001), repeats=2, min_ms=20.0)
+    assert R >= 10 and 0.0009 < per < 0.003 and len(ts) == 2

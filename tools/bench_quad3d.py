@@ -22,7 +22,25 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
-BYTES = {"hover": 417, "gates": 229}
+BYTES = {"hover": 417, "gates": 229}   # per-step kernel: algorithmic = measured (profiles/r01_pmc_quad3d_summary.json)
+# fused rollout (q3_step_many): the state stays in registers and only the final state is written, so a step moves its action
+# (16 B in) and its reward + done flag out: hover 16 + 8 + 1, gates 16 + 4 + 1 -- that kernel is VALU / latency bound
+# (f64 arithmetic for hover), and an HBM fraction built on the per-step bytes would exceed 1
+FUSED_BYTES = {"hover": 25, "gates": 21}
+VALU_F32_PEAK_TF, VALU_F64_PEAK_TF = 157.3, 78.6
+
+
+def _flop_per_env_step(kind):
+    """f64 (hover) / f32 (gates) vector flop per env-step of q3_rollout_kernel, counted by the PMC instruction counters
+    (tools/pmc_compute.py -> profiles/r02_pmc_compute.json); None when that profile is absent"""
+    try:
+        ks = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_compute.json")))["kernels"]
+    except Exception:
+        return None
+    for name, v in ks.items():
+        if "q3_rollout_kernel" in name and (("double" in name) == (kind == "hover")):
+            return v["derived"].get("f64_vector_flop_per_env_step" if kind == "hover" else "f32_vector_flop_per_env_step")
+    return None
 Q3_TRACK = (np.array([[-1.5, -2, -1.5], [1.5, 2, -1.5], [1.5, -2, -1.5], [-1.5, 2, -1.5]] * 2, dtype=np.float64),
             np.array([0, 0, np.pi, np.pi] * 2), np.array([-4, -2, -1.5]))     # Q3 cell 16
 
@@ -62,11 +80,19 @@ def measure(kind, n=65536, K=200, repeats=3, cpu_seconds=3.0):
     out = {"env": "Quadcopter3DVec (hover, f64)" if kind == "hover" else "Quadcopter3DVecGates (f32, 8-gate track of Q3 cell 16)",
            "envs": n, "steps": K, "actions": "U(-1,1) pre-generated on device", "bytes_per_env_step": BYTES[kind],
            "done_fraction": float(done.float().mean())}
-    for name, t in (("per_step_launch", t_step), ("fused_rollout", t_fused)):
-        gbs = BYTES[kind] * n * K / t / 1e9
-        out[name] = {"us_per_step": t / K * 1e6, "env_steps_per_s": n * K / t,
-                     "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": gbs / HBM_PEAK_GBS}}
+    gbs = BYTES[kind] * n * K / t_step / 1e9
+    out["per_step_launch"] = {"us_per_step": t_step / K * 1e6, "env_steps_per_s": n * K / t_step,
+                              "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": gbs / HBM_PEAK_GBS, "bytes_per_env_step": BYTES[kind]}}
+    peak = VALU_F64_PEAK_TF if kind == "hover" else VALU_F32_PEAK_TF
+    flop = _flop_per_env_step(kind)
+    tf = None if flop is None else flop * n * K / t_fused / 1e12
+    fgbs = FUSED_BYTES[kind] * n * K / t_fused / 1e9
+    out["fused_rollout"] = {"us_per_step": t_fused / K * 1e6, "env_steps_per_s": n * K / t_fused,
+                            "roofline": {"bound": "valu", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": None if tf is None else tf / peak,
+                                         "flop_per_env_step": flop,
+                                         "hbm": {"achieved": fgbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fgbs / HBM_PEAK_GBS,
+                                                 "bytes_per_env_step": FUSED_BYTES[kind]}}}
     if cpu_seconds > 0:
         from oracle import quad3d as q3
 

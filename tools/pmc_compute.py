@@ -30,10 +30,11 @@ csv.field_size_limit(1 << 30)
 GROUP_A = "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 GROUP_B = "SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE"
 GROUP_C = "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU"
+GROUP_D = "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVES SQ_INSTS_VALU"
 K_FUSED = 32       # steps per fused launch in the probe
 N = 65536
-KERNELS = ("step_kernel<0", "step_kernel<1", "rollout_kernel<0", "rollout_kernel<1", "rollout_policy_kernel<0",
-           "rollout_policy_kernel<1", "ppo_")
+KERNELS = ("q3_step_kernel<", "q3_rollout_kernel<", "step_kernel<0", "step_kernel<1", "rollout_kernel<0", "rollout_kernel<1",
+           "rollout_policy_kernel<0", "rollout_policy_kernel<1", "ppo_")
 
 
 def probe():
@@ -62,6 +63,20 @@ def probe():
         for r in range(3):
             res = env.rollout_policy_device(pol, K_FUSED, torch.zeros(4), noise_seed=0, first_step=r * K_FUSED,
                                             out=None if res is None else res[:6])
+        torch.cuda.synchronize()
+        env.close()
+    # predecessor envs (include/quad3d.h): hover (f64) and gates (f32)
+    from optimal_quad_control_rl_amd.quad3d import Quadcopter3DVec, Quadcopter3DVecGates
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bench_quad3d import Q3_TRACK
+    for kind in ("hover", "gates"):
+        env = Quadcopter3DVec(N) if kind == "hover" else Quadcopter3DVecGates(N, *Q3_TRACK)
+        acts = torch.rand((K_FUSED, N, 4), device=dev) * 2 - 1
+        env.reset_device()
+        for k in range(8):
+            env.step_device(acts[k])
+        for _ in range(3):
+            env.rollout_device(acts)
         torch.cuda.synchronize()
         env.close()
     # PPO minibatch update (17-float INDI observation, 16 384-row minibatches)
@@ -111,7 +126,7 @@ def summarise(paths, out_path):
         waves = m.get("SQ_WAVES", 0.0)
         d = {}
         if waves:
-            steps = K_FUSED if name.startswith("rollout") else 1
+            steps = K_FUSED if "rollout" in name else 1
             valu = m.get("SQ_INSTS_VALU", 0.0) - m.get("SQ_INSTS_MFMA", 0.0)
             d["waves"] = waves
             d["valu_insts_per_wave_step"] = valu / waves / steps
@@ -131,6 +146,10 @@ def summarise(paths, out_path):
                 # fraction of the wave's lifetime spent at the f32 vector issue floor / on the matrix core
                 d["valu_floor_frac_of_wave"] = d["valu_issue_floor_cycles_per_wave_step"] / d["wave_cycles_per_wave_step"]
                 d["mfma_busy_frac_of_wave"] = d["mfma_busy_cycles_per_wave_step"] / d["wave_cycles_per_wave_step"]
+            if "SQ_INSTS_VALU_FMA_F64" in m:
+                d["f64_vector_flop_per_env_step"] = 64.0 * (m.get("SQ_INSTS_VALU_ADD_F64", 0) + m.get("SQ_INSTS_VALU_MUL_F64", 0)
+                                                            + m.get("SQ_INSTS_VALU_TRANS_F64", 0)
+                                                            + 2.0 * m.get("SQ_INSTS_VALU_FMA_F64", 0)) / (waves * 64.0) / steps
             if "SQ_INSTS_VALU_FMA_F32" in m:
                 envs = waves * 64.0
                 vec = 64.0 * (m.get("SQ_INSTS_VALU_ADD_F32", 0) + m.get("SQ_INSTS_VALU_MUL_F32", 0) + m.get("SQ_INSTS_VALU_TRANS_F32", 0)
@@ -155,5 +174,6 @@ if __name__ == "__main__":
         print(GROUP_A)
         print(GROUP_B)
         print(GROUP_C)
+        print(GROUP_D)
     else:
         summarise(sys.argv[2:-1], sys.argv[-1])
