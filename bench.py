@@ -234,7 +234,7 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
                 "launch_us": fused_kernel_ms * 1e3, "us_per_step": fused_kernel_ms * 1e3 / K,
                 "bytes_per_launch": fused_bytes * K, "bytes_per_env_step": FUSED_BYTES_PER_ENV_STEP[variant](ga),
                 "note": "algorithmic bytes of THIS kernel: the env state stays in registers for the K steps, so a step moves its action in "
-                        "and obs / reward / done / trunc out (PMC-measured traffic agrees within 3 %); the SURVEY 8(d) per-step figure "
+                        "and obs / reward / done / trunc out (PMC-measured traffic agrees within 3 percent); the SURVEY 8(d) per-step figure "
                         "(%d B, state read + written every step) describes the per-step kernel and is used only there"
                         % BYTES_PER_ENV_STEP[variant](ga),
                 "valu": {"bound": "valu", "achieved": tf, "peak": VALU_F32_PEAK_TF, "unit": "TFLOP/s",
