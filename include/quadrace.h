@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define QR_ABI_VERSION 1
+#define QR_ABI_VERSION 2
 
 enum {
     QR_OK = 0,
@@ -104,6 +104,14 @@ int qr_set_pause(qr_env* env, int32_t pause);
 /* env.pause_if_collision after construction (qr_config.pause_if_collision sets the initial value) */
 int qr_set_pause_if_collision(qr_env* env, int32_t on);
 
+/* Terminal observations (what SB3 bootstraps time-limit truncations from, `infos[i]["terminal_observation"]`, R:589-594).
+ * With a device buffer registered, every env that finishes an episode at a step writes the gate-frame observation of its
+ * FINAL state -- taken before the auto-reset -- to row [env] (qr_step: buffer [N][obs_len]) or row [k][env] (qr_step_many,
+ * qr_step_launches, qr_rollout_policy: buffer [K][N][obs_len], k = step within the call).  Rows of envs that did not
+ * finish are not touched.  NULL (default) switches it off.  (The reference itself hands SB3 the post-reset row, a
+ * consequence of filling `infos` after reset_(): see DESIGN.md.) */
+int qr_set_terminal_obs(qr_env* env, float* term_obs_dev);
+
 /* Philox4x32-10 key for the in-kernel reset RNG; also zeroes the per-env episode counters. */
 int qr_seed(qr_env* env, uint64_t seed);
 
@@ -133,6 +141,11 @@ int qr_step_launches(qr_env* env, int32_t num_steps, const float* actions_dev, f
 
 /* update_states(): recompute the observation from the current state. */
 int qr_observe(qr_env* env, float* obs_out_dev, void* stream);
+
+/* Diagnostic: out_dev [N][7] = (vbx, vby, vbz, thrust, Mx, My, Mz) -- body velocity (get_body_velocity, R:155) and the
+ * residual thrust / moment MLP outputs (thrust_moment_model_world_states, R:254-262) for the CURRENT state of every env,
+ * computed by the device functions the step kernels inline.  E2E with residual weights only. */
+int qr_probe_residual(qr_env* env, float* out_dev, void* stream);
 
 /* Row-major copies of the internal state (device pointers; any may be NULL).
  * dist is ignored for INDI. target/steps are int32. episode = per-env reset counter (RNG stream position). */
@@ -196,31 +209,52 @@ int qr_ppo_num_params(const qr_ppo* ppo);
 /* builds the f16 operand images from the parameters: call once before the first qr_ppo_minibatch and after any
  * change of theta made outside this library */
 int qr_ppo_pack(qr_ppo* ppo, const float* theta_dev, void* stream);
-/* gradient only (no clipping, no optimiser step): grad_out_dev [num_params]; stats_dev (may be NULL) float[4] is
- * ACCUMULATED into: sum of per-sample surrogate losses, sum of squared value errors, sum of approx-KL terms, number
- * of clipped samples */
+/* gradient only (no clipping, no optimiser step): grad_out_dev [num_params + 4] -- the gradient followed by this
+ * minibatch's statistics {sum of per-sample surrogate losses, sum of squared value errors, sum of approx-KL terms, number
+ * of clipped samples}; stats_dev (may be NULL) float[4] is ACCUMULATED into with the same four sums */
 int qr_ppo_grad(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const float* act_dev,
                 const float* old_logp_dev, const float* adv_dev, const float* ret_dev, const int32_t* idx_dev, int32_t B,
                 float clip, float vf_coef, float ent_coef, float* grad_out_dev, float* stats_dev, void* stream);
-/* one complete minibatch update of theta (and the Adam moments); adam_step = 1, 2, ... counts updates */
+/* one complete minibatch update of theta (and the Adam moments); adam_step = 1, 2, ... counts updates.  Three launches:
+ * forward/backward (phase A), weight gradients (phase B), and ONE kernel that reduces the gradient, takes its global norm
+ * across a grid-wide barrier, clips, applies Adam and re-packs the f16 operand images.  A non-finite gradient norm makes
+ * the whole update a no-op (counted, see qr_ppo_status).  stats_dev (may be NULL) float[4] is accumulated into. */
 int qr_ppo_minibatch(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* adam_v_dev, const float* obs_dev,
                      const float* act_dev, const float* old_logp_dev, const float* adv_dev, const float* ret_dev,
                      const int32_t* idx_dev, int32_t B, float clip, float vf_coef, float ent_coef, float max_grad_norm,
                      float lr, float beta1, float beta2, float eps, int32_t adam_step, float* stats_dev, void* stream);
+/* Announces an epoch: idx_dev [num_minibatches * B] is the permutation whose consecutive slices of B rows will be passed,
+ * in order, to qr_ppo_minibatch / qr_ppo_grad.  One launch computes the advantage mean / std sums of every minibatch
+ * (otherwise each minibatch call spends a launch on its own).  Optional. */
+int qr_ppo_epoch_begin(qr_ppo* ppo, const float* adv_dev, const int32_t* idx_dev, int32_t B, int32_t num_minibatches,
+                       void* stream);
+/* SB3's `target_kl` early stop, decided on the device: before an optimiser step is taken the update kernel compares the
+ * minibatch's mean approx-KL with 1.5 * target_kl; if it is larger the step is NOT taken and a sticky stop flag makes every
+ * later qr_ppo_minibatch / qr_ppo_apply launch a no-op, until qr_ppo_control(..., clear != 0) (call it at the start of
+ * each PPO.train()).  target_kl <= 0 disables the check.  No host synchronisation is involved. */
+int qr_ppo_control(qr_ppo* ppo, float target_kl, int32_t clear, void* stream);
+/* blocks; out4 = {stopped (0/1), optimiser steps taken since the last clear, updates skipped for a non-finite gradient
+ * norm, grid-barrier timeouts (must be 0)} */
+int qr_ppo_status(qr_ppo* ppo, int32_t* out4, void* stream);
 
 /* forward pass of one network with the current operand images (net 0: action means; net 1: value in column 0): out_dev [n][4] */
 int qr_ppo_forward(qr_ppo* ppo, int32_t net, int32_t n, const float* obs_dev, float* out_dev, void* stream);
-/* GAE(lambda) over a rollout buffer [T][N] (SB3 RolloutBuffer.compute_returns_and_advantage; done = 0 / 1 floats, truncations
- * count as terminations) and, when ep_*_dev are given, the running episode return / length / gate count per env with the
- * sums over finished episodes ACCUMULATED into fin_dev[4] = {sum return, sum length, sum gates, episodes} (VecMonitor, R:769) */
+/* GAE(lambda) over a rollout buffer [T][N] (SB3 RolloutBuffer.compute_returns_and_advantage; done = 0 / 1 floats).
+ * term_val_dev (may be NULL) [T][N] = V(terminal observation) at the steps that ended by the time limit and 0 elsewhere:
+ * gamma * term_val is added to those rewards, which is how SB3's collect_rollouts bootstraps truncated episodes (R:589-594
+ * hands it `terminal_observation` / `TimeLimit.truncated`); without it truncations count as terminations.  When ep_*_dev are
+ * given, the running episode return / length / gate count per env are updated (from the raw rewards) and the sums over finished
+ * episodes ACCUMULATED into fin_dev[4] = {sum return, sum length, sum gates, episodes} (VecMonitor, R:769) */
 int qr_ppo_gae(qr_ppo* ppo, int32_t T, int32_t N, const float* rew_dev, const float* done_dev, const float* val_dev,
-               const float* last_val_dev, float gamma, float lam, float* adv_out_dev, float* ret_out_dev, float* ep_ret_dev,
-               float* ep_len_dev, float* ep_gates_dev, float* fin_dev, void* stream);
+               const float* last_val_dev, const float* term_val_dev, float gamma, float lam, float* adv_out_dev,
+               float* ret_out_dev, float* ep_ret_dev, float* ep_len_dev, float* ep_gates_dev, float* fin_dev, void* stream);
 /* data-parallel training (one process per GPU): each rank computes qr_ppo_grad on its own rows, the caller averages the
- * gradients across ranks (a single all-reduce of num_params floats -- ~250 KB -- over RCCL), then every rank applies the
- * identical update: global-norm clip, Adam, operand re-pack.  grad_dev is consumed (cleared). */
-int qr_ppo_apply(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* adam_v_dev, float* grad_dev, float max_grad_norm,
-                 float lr, float beta1, float beta2, float eps, int32_t adam_step, void* stream);
+ * [num_params + 4] vector across ranks (a single all-reduce of ~250 KB over RCCL: gradient AND minibatch statistics), then
+ * every rank applies the identical update: global-norm clip, Adam, operand re-pack -- and takes the identical target-KL
+ * decision, because the KL sum travelled with the gradient.  B = rows per rank of this minibatch.  stats_dev as above. */
+int qr_ppo_apply(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* adam_v_dev, float* grad_dev, int32_t B,
+                 float max_grad_norm, float lr, float beta1, float beta2, float eps, int32_t adam_step, float* stats_dev,
+                 void* stream);
 
 #ifdef __cplusplus
 }

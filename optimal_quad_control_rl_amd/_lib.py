@@ -38,12 +38,14 @@ SIGNATURES = {
     "qr_set_limits": (C.c_int, [_vp, C.c_int32, C.c_float]),
     "qr_set_pause": (C.c_int, [_vp, C.c_int32]),
     "qr_set_pause_if_collision": (C.c_int, [_vp, C.c_int32]),
+    "qr_set_terminal_obs": (C.c_int, [_vp, _vp]),
     "qr_seed": (C.c_int, [_vp, C.c_uint64]),
     "qr_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "qr_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qr_step_many": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qr_step_launches": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qr_observe": (C.c_int, [_vp, _vp, _vp]),
+    "qr_probe_residual": (C.c_int, [_vp, _vp, _vp]),
     "qr_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qr_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qr_last_step_many_ms": (C.c_int, [_vp, _f32p]),
@@ -62,8 +64,11 @@ SIGNATURES = {
     "qr_ppo_grad": (C.c_int, [_vp] * 8 + [C.c_int32, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp]),
     "qr_ppo_minibatch": (C.c_int, [_vp] * 10 + [C.c_int32] + [C.c_float] * 8 + [C.c_int32, _vp, _vp]),
     "qr_ppo_forward": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
-    "qr_ppo_gae": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float, C.c_float] + [_vp] * 7),
-    "qr_ppo_apply": (C.c_int, [_vp] * 5 + [C.c_float] * 5 + [C.c_int32, _vp]),
+    "qr_ppo_gae": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float] + [_vp] * 7),
+    "qr_ppo_apply": (C.c_int, [_vp] * 5 + [C.c_int32] + [C.c_float] * 5 + [C.c_int32, _vp, _vp]),
+    "qr_ppo_epoch_begin": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
+    "qr_ppo_control": (C.c_int, [_vp, C.c_float, C.c_int32, _vp]),
+    "qr_ppo_status": (C.c_int, [_vp, C.POINTER(C.c_int32), _vp]),
     # include/quad3d.h (predecessor environments of "3D quad.ipynb")
     "q3_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(_vp)]),
     "q3_destroy": (C.c_int, [_vp]),
@@ -107,7 +112,7 @@ def load(build_if_missing=True):
     for name, (rt, at) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError here = ABI drift between header and library
         fn.restype, fn.argtypes = rt, at
-    if L.qr_abi_version() != 1:
+    if L.qr_abi_version() != 2:
         raise RuntimeError("libquadrace ABI version mismatch")
     _lib = L
     return L

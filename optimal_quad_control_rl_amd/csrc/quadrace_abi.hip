@@ -27,6 +27,7 @@ int policy_device(const qr_policy* p);
 hipError_t launch_reset(int variant, const Params& P, const uint8_t* mask, float* obs, hipStream_t st);
 hipError_t launch_observe(int variant, const Params& P, float* obs, hipStream_t st);
 hipError_t launch_clear_episode(const Params& P, hipStream_t st);
+hipError_t launch_residual_probe(const Params& P, float* out, hipStream_t st);
 hipError_t launch_get_state(int variant, const Params& P, float* world, float* dist, int32_t* target, int32_t* steps,
                             uint32_t* episode, hipStream_t st);
 hipError_t launch_set_state(int variant, const Params& P, const float* world, const float* dist,
@@ -357,6 +358,12 @@ int qr_set_pause_if_collision(qr_env* e, int32_t on) {
     return QR_OK;
 }
 
+int qr_set_terminal_obs(qr_env* e, float* term_obs_dev) {
+    if (!e) return fail(QR_E_INVALID, "qr_set_terminal_obs: null env");
+    e->P.term_obs = term_obs_dev;
+    return QR_OK;
+}
+
 int qr_seed(qr_env* e, uint64_t seed) {
     if (!e) return fail(QR_E_INVALID, "qr_seed: null env");
     QR_HIP(hipSetDevice(e->cfg.device));
@@ -416,10 +423,13 @@ int qr_step_launches(qr_env* e, int32_t K, const float* actions_dev, float* obs_
         hipGraph_t graph = nullptr;
         QR_HIP(hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
         hipError_t err = hipSuccess;
-        for (int k = 0; k < K && err == hipSuccess; ++k)
-            err = qr::launch_step(e->cfg.variant, e->P, actions_dev + (size_t)k * n * 4, obs_out_dev + (size_t)k * n * e->L,
+        for (int k = 0; k < K && err == hipSuccess; ++k) {
+            qr::Params Pk = e->P;
+            if (Pk.term_obs) Pk.term_obs += (size_t)k * n * e->L;   // terminal-observation rows [k][env]
+            err = qr::launch_step(e->cfg.variant, Pk, actions_dev + (size_t)k * n * 4, obs_out_dev + (size_t)k * n * e->L,
                                   rew_out_dev + (size_t)k * n, done_out_dev + (size_t)k * n,
                                   trunc_out_dev ? trunc_out_dev + (size_t)k * n : nullptr, e->capture_stream);
+        }
         const hipError_t end = hipStreamEndCapture(e->capture_stream, &graph);
         if (err != hipSuccess || end != hipSuccess) {
             if (graph) (void)hipGraphDestroy(graph);
@@ -485,6 +495,15 @@ int qr_observe(qr_env* e, float* obs_out_dev, void* stream) {
     if (int rc = check_ready(e)) return rc;
     if (!obs_out_dev) return fail(QR_E_INVALID, "qr_observe: null output");
     QR_HIP(qr::launch_observe(e->cfg.variant, e->P, obs_out_dev, (hipStream_t)stream));
+    return QR_OK;
+}
+
+int qr_probe_residual(qr_env* e, float* out_dev, void* stream) {
+    if (int rc = bind_device(e)) return rc;
+    if (!out_dev) return fail(QR_E_INVALID, "qr_probe_residual: null output");
+    if (e->cfg.variant != QR_VARIANT_E2E || !(e->P.flags & qr::kFlagResidual))
+        return fail(QR_E_STATE, "qr_probe_residual: needs an E2E env with residual weights");
+    QR_HIP(qr::launch_residual_probe(e->P, out_dev, (hipStream_t)stream));
     return QR_OK;
 }
 

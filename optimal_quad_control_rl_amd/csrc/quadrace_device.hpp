@@ -65,6 +65,8 @@ struct Params {
     float dt;
     uint32_t seed_lo, seed_hi, gid_lo, gid_hi;  // Philox key, global id of env 0
     float obs_lo[4], obs_inv[4];  // observation scaling of (Mx,My,Mz,Fz): lo and 1/(hi-lo) after the R:419-441 fix-up
+    float* term_obs;    // optional (qr_set_terminal_obs): rows [N][obs_len] (per-step kernel) / [K][N][obs_len] (K-step kernels)
+                        // receiving the PRE-reset observation of every env that finished at that step
 #ifdef QR_PHASE_TIMING
     unsigned long long* ticks;  // [n_waves][16] shader-clock stamps (profiling build only, tools/phase_timing.py)
     int tick_on;
@@ -571,11 +573,14 @@ __device__ __forceinline__ void observe(const Params& P, const float* __restrict
 // One env step (step_wait, R:501-595 / I:303-385).  Returns reward; sets done / trunc flags.
 // On auto-reset `did_reset` is set so the caller persists the new disturbances.  Must be called by all 64 lanes.
 // -------------------------------------------------------------------------------------------------
-template <int V>
+// `before_reset(done)` is invoked (all lanes) after the state update and before the auto-reset -- the caller's hook
+// for the terminal observation SB3 bootstraps time-limit truncations from (R:589-594).
+template <int V, class BeforeReset>
 __device__ __forceinline__ float step_env(const Params& P, const float* __restrict__ gates,
                                           const float* __restrict__ rtab, float* __restrict__ tile, const MlpRegs& mlp,
                                           int lane, bool active, Env<V>& e, const float u[4], uint32_t gid_lo,
-                                          uint32_t gid_hi, bool& done, bool& trunc, bool& did_reset) {
+                                          uint32_t gid_hi, bool& done, bool& trunc, bool& did_reset,
+                                          BeforeReset&& before_reset) {
     constexpr int S = Env<V>::S;
     const Rot R = make_rot(e.s[6], e.s[7], e.s[8]);
     QR_TICK(P, 3);
@@ -641,6 +646,7 @@ __device__ __forceinline__ float step_env(const Params& P, const float* __restri
 #pragma unroll
         for (int k = 0; k < S; ++k) e.s[k] = nw[k];
         did_reset = done;
+        before_reset(done);
         reset_done_lanes<V>(P, rtab, tile, lane, done && active, e, gid_lo, gid_hi);  // shadow lanes are not reset
     }
     return reward;

@@ -116,6 +116,18 @@ __device__ __forceinline__ void store_obs_coalesced(float* __restrict__ tile, fl
     __builtin_amdgcn_wave_barrier();
 }
 
+// Terminal observation (optional, Params::term_obs): the gate-frame observation of the final state of an episode, written
+// before the auto-reset replaces that state.  Finished envs are rare (~1 % of the lanes per step), so the divergent
+// observe + row store costs next to nothing; rows of envs that did not finish are left untouched.
+template <int V, int GA>
+__device__ __forceinline__ void store_terminal_obs(const Params& P, const float* __restrict__ gates, const Env<V>& e,
+                                                   size_t row_base, int i, bool write) {
+    if (P.term_obs == nullptr || !write) return;
+    float to[obs_len<V, GA>()];
+    observe<V, GA>(P, gates, e, to);
+    store_obs<V, GA>(P.term_obs + row_base * obs_len<V, GA>(), i, to);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Fused step: residual MLP -> EoM -> Euler -> reward/termination -> auto-reset -> gate-frame observation
 // ---------------------------------------------------------------------------------------------------
@@ -166,8 +178,8 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
     const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
     bool done, trunc, did_reset;
-    const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc,
-                                     did_reset);
+    const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc, did_reset,
+                                     [&](bool fin) { store_terminal_obs<V, GA>(P, gates, e, 0, i, fin && active); });
     if (active) {
         stream_store(rew_out + i, reward);
         stream_store(done_out + i, (uint8_t)(done ? 1 : 0));
@@ -258,7 +270,9 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
             const float u[4] = {act.x, act.y, act.z, act.w};
             bool done, trunc, did_reset;
             const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc,
-                                             did_reset);
+                                             did_reset, [&](bool fin) {
+                                                 store_terminal_obs<V, GA>(P, gates, e, (size_t)k * n, i, fin && active);
+                                             });
             any_reset |= did_reset;
             if (active) {
                 stream_store(rew_out + (size_t)k * n + i, reward);
@@ -367,7 +381,9 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
                             fminf(fmaxf(a[2], -1.0f), 1.0f), fminf(fmaxf(a[3], -1.0f), 1.0f)};
         bool done, trunc, did_reset;
         const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc,
-                                         did_reset);
+                                         did_reset, [&](bool fin) {
+                                             store_terminal_obs<V, GA>(P, gates, e, (size_t)k * n, i, fin && active);
+                                         });
         any_reset |= did_reset;
         if (active) {
             stream_store(rew_out + (size_t)k * n + i, reward);
@@ -484,6 +500,30 @@ set_state_kernel(Params P, const float* __restrict__ world, const float* __restr
     P.ts[i] = pack_ts<V>(e);
 }
 
+// qr_probe_residual: body velocity (R:103) and the residual thrust / moment MLP outputs (R:254-262) of the CURRENT state
+// of every env, row [vbx vby vbz thrust Mx My Mz] -- the same device functions the step kernels inline, exposed so that
+// parity tests can pin them directly against the reference's fixture rows instead of through finite differences.
+__global__ void __launch_bounds__(kBlock) residual_probe_kernel(Params P, float* __restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool active = i < P.n;   // MFMA / permlane are wave-wide: tail lanes shadow env 0
+    Env<kE2E> e;
+    load_env<kE2E>(P, active ? i : 0, e);
+    MlpRegs mlp;
+    mlp_load_regs(P.tables, lane, mlp);
+    const Rot R = make_rot(e.s[6], e.s[7], e.s[8]);
+    float vb[3];
+    vb[0] = fmaf(e.s[3], R.r00, fmaf(e.s[4], R.r10, e.s[5] * R.r20));
+    vb[1] = fmaf(e.s[3], R.r01, fmaf(e.s[4], R.r11, e.s[5] * R.r21));
+    vb[2] = fmaf(e.s[3], R.r02, fmaf(e.s[4], R.r12, e.s[5] * R.r22));
+    const float x[10] = {e.s[12], e.s[13], e.s[14], e.s[15], vb[0], vb[1], vb[2], e.s[9], e.s[10], e.s[11]};
+    float thrust, moment[3];
+    residual_mlp(mlp, lane, x, thrust, moment);
+    if (!active) return;
+    float* o = out + (size_t)i * 7;
+    o[0] = vb[0]; o[1] = vb[1]; o[2] = vb[2]; o[3] = thrust; o[4] = moment[0]; o[5] = moment[1]; o[6] = moment[2];
+}
+
 // qr_seed: restart every env's reset stream (episode counter = 0)
 __global__ void __launch_bounds__(kBlock) clear_episode_kernel(Params P) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -579,6 +619,11 @@ hipError_t launch_reset(int variant, const Params& P, const uint8_t* mask, float
 hipError_t launch_observe(int variant, const Params& P, float* obs, hipStream_t st) {
     if (variant == kE2E) { QR_DISPATCH_GA(kE2E, observe_kernel, P, obs) }
     else { QR_DISPATCH_GA(kINDI, observe_kernel, P, obs) }
+    return hipGetLastError();
+}
+
+hipError_t launch_residual_probe(const Params& P, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(residual_probe_kernel, grid_for(P.n), dim3(kBlock), 0, st, P, out);
     return hipGetLastError();
 }
 

@@ -4,9 +4,10 @@
 // (policy mean / value), a state-independent log-std, clipped surrogate + vf_coef * MSE value loss, per-minibatch
 // advantage normalisation, global grad-norm clipping, Adam.  With the collect phase fused into one kernel
 // (qr_rollout_policy) torch's minibatch update was > 95 % of training time: ~100 small launches around
-// 16 k x 120 x 120 GEMMs.  Here one minibatch is six launches:
+// 16 k x 120 x 120 GEMMs.  Here one minibatch is three launches (phase A, phase B, apply) plus one adv_stats launch per EPOCH:
 //
-//   adv_stats   sum / sum of squares of the minibatch's advantages (SB3 normalises per minibatch; phase A finishes the maths)
+//   adv_stats   sum / sum of squares of the advantages of EVERY minibatch of an epoch in one launch (qr_ppo_epoch_begin;
+//               SB3 normalises per minibatch; phase A finishes the maths)
 //   phase A     per wave = one 32-sample tile of one net (8-wave workgroups): forward (f16 MFMA chain of quadrace_policy.hpp), per-sample loss
 //               gradients, backward through the transposed weight images -- activations h_l and deltas d_l never leave
 //               registers in the "lane = sample" form.  Each of them is also emitted in the transposed operand form
@@ -16,9 +17,12 @@
 //   phase B     dW_l = d_l^T x h_(l-1): one wave per 2x2 block of 32x32 weight tiles and chunk of the sample groups,
 //               v_mfma_f32_32x32x16_f16 with k = sample, plain stores to partial[chunk][param].  Biases ride along as the
 //               constant-1 unit of every layer.
-//   norm        sums the chunk partials and the per-wave sums into the flat gradient, accumulates its squared norm
-//   adam        clip scale from the norm, torch.optim.Adam arithmetic on the flat parameter vector
-//   pack        f32 parameters -> f16 forward and transposed operand images for the next minibatch
+//   apply       ONE kernel: sums the chunk partials and the per-wave sums into the gradient, accumulates its squared norm,
+//               crosses a grid-wide barrier (62 co-resident workgroups), then clip scale, torch.optim.Adam arithmetic, and each
+//               thread scatters its new parameter as f16 into the forward / transposed operand images of the next minibatch;
+//               SB3's target-KL early stop is decided here, on the device, before the step is taken
+//   (pack       the gather form of the same image layout: initial images / after external changes of theta;
+//    reduce     gradient + minibatch statistics only, for the data-parallel path: qr_ppo_grad -> all-reduce -> qr_ppo_apply)
 //
 // Operand layouts are those of quadrace_policy.hpp (verified on MI355X with tools/ubench/mfma_layout.hip).
 #include <hip/hip_runtime.h>
@@ -118,9 +122,8 @@ __global__ void __launch_bounds__(256) ppo_pack_kernel(const float* __restrict__
     images[(size_t)net * D::kImage + e] = v;
 }
 
-// ---- adv_stats: sum and sum of squares of adv[idx[0..B)] into acc[0], acc[1] (phase A turns them into mean / rstd) -------
-// acc (double[4]) = {sum adv, sum adv^2, sum grad^2, -}: each accumulator is cleared by the kernel that runs before its
-// next use (adv_stats clears acc[2]; the norm kernel clears acc[0..1]), so a minibatch needs no memset.
+// ---- adv_stats: sum and sum of squares of the advantages of minibatch mb = blockIdx.y, rows idx[mb * B + 0..B), into
+// table[mb][0..1] (the table is zeroed by a memset before the launch; phase A turns the sums into mean / rstd) ----------
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -146,17 +149,29 @@ __device__ __forceinline__ void block_sum2_f64(double& a, double& b) {
 
 // (same-address f64 atomics serialise at ~15 ns each: one pair per 1024-thread block, not one per wave)
 __global__ void __launch_bounds__(1024) ppo_adv_stats_kernel(const float* __restrict__ adv, const int* __restrict__ idx, int B,
-                                                             double* __restrict__ acc) {
+                                                             double* __restrict__ table) {
     const int i = blockIdx.x * 1024 + threadIdx.x;
-    if (i == 0) acc[2] = 0.0;
-    const double x = i < B ? (double)adv[idx[i]] : 0.0;
+    const double x = i < B ? (double)adv[idx[(size_t)blockIdx.y * B + i]] : 0.0;
     double s1 = x, s2 = x * x;
     block_sum2_f64<1024>(s1, s2);
     if (threadIdx.x == 0) {
-        unsafeAtomicAdd(acc + 0, s1);
-        unsafeAtomicAdd(acc + 1, s2);
+        unsafeAtomicAdd(table + 2 * blockIdx.y + 0, s1);
+        unsafeAtomicAdd(table + 2 * blockIdx.y + 1, s2);
     }
 }
+
+// Device-resident control block of one qr_ppo handle
+struct PpoCtrl {
+    double sumsq[2];              // squared gradient norm of the current update, double-buffered by barrier generation parity
+    unsigned long long arrive;    // grid barrier of ppo_apply_kernel: arrivals (monotonic)
+    unsigned long long depart;    //                                   departures (monotonic)
+    unsigned long long gen;       // completed barrier generations (= apply launches that were not skipped)
+    int stop;                     // sticky: a minibatch exceeded 1.5 x target_kl (SB3's early stop); cleared by qr_ppo_control
+    int applied;                  // optimiser steps taken since the last qr_ppo_control
+    int skipped_nonfinite;        // updates dropped because the gradient norm was not finite
+    int barrier_timeouts;         // must stay 0
+    float mb_stats[4];            // the current minibatch's sums: surrogate loss, squared value error, approx KL, clipped count
+};
 
 // ---- phase A ------------------------------------------------------------------------------------------------------
 struct PpoBatch {
@@ -169,6 +184,7 @@ struct PpoBatch {
     int B, G;               // G = B / 64 groups
     float clip, vf_coef, ent_coef;
     const double* acc;       // [sum adv, sum adv^2] of this minibatch (ppo_adv_stats_kernel)
+    const int* stop;         // PpoCtrl::stop: set by an earlier launch when the target-KL early stop hit -> nothing left to do
     const float* theta;      // flat parameters (log_std is read from here)
     const half8* images;     // [2][kImage]
     half8* tbuf;             // [2][kSlots][G][4][64]
@@ -308,6 +324,7 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half8* W = reinterpret_cast<half8*>(smem);
     const int net = blockIdx.y;
+    if (*a.stop) return;  // uniform over the grid
     PPO_TICK(a, 0);
     {   // operand images -> LDS, 8 independent 16-byte loads in flight per thread (one load per round trip took 22 k cycles)
         const float4* src = reinterpret_cast<const float4*>(a.images + (size_t)net * D::kImage);
@@ -511,8 +528,10 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
 // (Measured: f32 atomics from ~3000 waves cost 17 us per minibatch, as much as the loads and MFMAs themselves.)
 template <int L>
 __global__ void __launch_bounds__(64) ppo_phase_b_kernel(const half8* __restrict__ tbuf, float* __restrict__ partial, int num_params,
-                                                         int G, int groups_per_chunk, int num_chunks, float scale) {
+                                                         int G, int groups_per_chunk, int num_chunks, float scale,
+                                                         const int* __restrict__ stop) {
     using D = PpoDims<L>;
+    if (*stop) return;  // target-KL early stop hit in an earlier launch
     const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
     // XCD-aware mapping: workgroups go round-robin to the 8 XCDs (each with its own L2), so workgroup id % 8 selects the XCD.
     // All tile blocks of one sample chunk share their operands -> they get the same id % 8 and meet in one L2
@@ -597,27 +616,43 @@ __global__ void __launch_bounds__(64) ppo_phase_b_kernel(const half8* __restrict
         }
 }
 
-// ---- global gradient norm -> clip scale; Adam ----------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) ppo_norm_kernel(float* __restrict__ grad, const float* __restrict__ partial, int chunks, int n,
-                                                        const float* __restrict__ wave_out, int G, float ent_coef,
-                                                        float* __restrict__ stats, double* __restrict__ acc) {
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    if (i == 0) acc[0] = acc[1] = 0.0;  // the advantage sums of this minibatch have been consumed by phase A
-    // the tail block also reduces the per-wave sums of phase A: waves 0..3 -> d loss / d log_std[k], waves 4..7 -> statistics
-    __shared__ float wave_red[8];
+// ---- gradient reduction, global norm, clip, Adam, operand re-pack: ONE kernel ----------------------------------------------
+struct ApplyArgs {
+    float *theta, *m, *v;     // parameters and Adam moments (flat, n floats)
+    const float* ext_grad;    // data-parallel path: [n + 4] externally averaged gradient + minibatch statistics; else nullptr
+    float* grad_out;          // optional [n + 4]: the reduced gradient + minibatch statistics (qr_ppo_grad); else nullptr
+    const float* partial;     // [chunks][n] sample-chunk partials of phase B
+    int chunks, n;
+    const float* wave_out;    // per-wave sums of phase A, Gw = waves per net
+    int Gw;
+    float ent_coef;
+    float* stats;             // optional [4], accumulated
+    PpoCtrl* ctrl;
+    half8* images;            // [2][kImage] operand images (re-packed after the step)
+    float max_norm, lr, beta1, beta2, eps, bc1, bc2_sqrt;
+    float kl_limit;           // 1.5 * target_kl * B (threshold on the minibatch's KL SUM); <= 0: no early stop
+    int take_step;            // 0: reduce only (qr_ppo_grad)
+};
+
+// gradient element i and, in the block(s) that own the log_std entries, the per-wave sums of phase A:
+// red[0..3] = d loss / d log_std[k] (x 1/B), red[4..7] = sum surrogate, sum squared value error, sum approx kl, clipped count
+__device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, float* red /* shared [8] */) {
+    const int n = a.n;
+    if (a.ext_grad) {
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x < 4) red[4 + threadIdx.x] = a.ext_grad[n + threadIdx.x];
+        __syncthreads();
+        return i < n ? a.ext_grad[i] : 0.0f;
+    }
     if (((int)blockIdx.x + 1) * 1024 > n - 4) {  // the block(s) holding the log_std entries (the last one, or the last two)
         const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
         if (w < 8) {
             // statistics: 4 surrogate (policy waves, slot 4), 5 squared value error (value waves, slot 4), 6 approx kl, 7 clipped
             const int slot = w < 4 ? w : (w == 4 || w == 5 ? 4 : (w == 6 ? 5 : 6));
-            const float* wv = wave_out + (w == 5 ? (size_t)G * 8 : 0) + slot;
+            const float* wv = a.wave_out + (w == 5 ? (size_t)a.Gw * 8 : 0) + slot;
             float t = 0.0f;
-            for (int q = lane; q < G; q += 64) t += wv[(size_t)q * 8];
+            for (int q = lane; q < a.Gw; q += 64) t += wv[(size_t)q * 8];
             t = wave_sum(t);
-            if (lane == 0) {
-                wave_red[w] = t;
-                if (w >= 4 && stats && blockIdx.x == gridDim.x - 1) stats[w - 4] += t;  // single writer
-            }
+            if (lane == 0) red[w] = t;
         }
         __syncthreads();
     }
@@ -625,43 +660,144 @@ __global__ void __launch_bounds__(1024) ppo_norm_kernel(float* __restrict__ grad
     if (i < n - 4) {  // weights and biases: sum the sample-chunk partials of phase B
         float gs[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // independent loads in flight
         int cix = 0;
-        for (; cix + 8 <= chunks; cix += 8) {
+        for (; cix + 8 <= a.chunks; cix += 8) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) gs[q] += partial[(size_t)(cix + q) * n + i];
+            for (int q = 0; q < 8; ++q) gs[q] += a.partial[(size_t)(cix + q) * n + i];
         }
-        for (; cix < chunks; ++cix) gs[0] += partial[(size_t)cix * n + i];
+        for (; cix < a.chunks; ++cix) gs[0] += a.partial[(size_t)cix * n + i];
         g = ((gs[0] + gs[1]) + (gs[2] + gs[3])) + ((gs[4] + gs[5]) + (gs[6] + gs[7]));
     } else if (i < n) {  // log_std; entropy = sum(log_std) + const
-        g = wave_red[i - (n - 4)] - ent_coef;
+        g = red[i - (n - 4)] - a.ent_coef;
     }
-    if (i < n) grad[i] = g;
-    double sq = (double)g * g, unused = 0.0;
-    block_sum2_f64<1024>(sq, unused);
-    if (threadIdx.x == 0) unsafeAtomicAdd(acc + 2, sq);
+    return g;
 }
 
-__global__ void __launch_bounds__(256) ppo_adam_kernel(float* __restrict__ theta, float* __restrict__ m, float* __restrict__ v,
-                                                       float* __restrict__ grad, int n, const double* __restrict__ acc,
-                                                       float max_norm, float lr, float beta1, float beta2, float eps, float bc1,
-                                                       float bc2_sqrt) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float norm = (float)sqrt(acc[2]);
-    const float clip = fminf(1.0f, max_norm / (norm + 1e-6f));  // torch.nn.utils.clip_grad_norm_
-    float g = grad[i] * clip;
-    if (!(fabsf(g) <= 3.0e38f)) g = 0.0f;  // a non-finite gradient never reaches the parameters
-    const float mi = beta1 * m[i] + (1.0f - beta1) * g;
-    const float vi = beta2 * v[i] + (1.0f - beta2) * g * g;
-    m[i] = mi;
-    v[i] = vi;
-    theta[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);  // torch.optim.Adam
-    grad[i] = 0.0f;
+// f16 operand-image positions of parameter `local` (index inside one net's block of the flat vector): the inverse of
+// ppo_pack_kernel's gather.  Every weight sits once in the forward image and (layers 2-4) once in the transposed image.
+template <int L>
+__device__ __forceinline__ void pack_scatter(_Float16* __restrict__ img, int O, int local, float val) {
+    using P = PolicyDims<L>;
+    using D = PpoDims<L>;
+    const NetOff o = net_off(L, O);
+    const _Float16 hv = (_Float16)val;
+    // (row, hidden k-slot) of a 128-wide layer image starting at half8 offset `off`: see ppo_pack_kernel
+    auto hidden_pos = [](int off, int row, int hid, bool single_tile) -> size_t {
+        const int t = single_tile ? 0 : (row >> 5), c = row & 31, q = hid >> 5, u = hid & 31;
+        const int h = (u >> 2) & 1, r = (u & 3) + 4 * (u >> 3);      // u = rho(r, h)
+        const int sp = 2 * q + (r >> 3), j = r & 7;
+        return ((size_t)(off + t * 512 + sp * 64 + 32 * h + c)) * 8 + j;
+    };
+    auto layer1_pos = [](int row, int k) -> size_t {
+        const int t = row >> 5, c = row & 31, sidx = k >> 4, h = (k >> 3) & 1, j = k & 7;
+        return ((size_t)((t * P::kSteps1 + sidx) * 64 + 32 * h + c)) * 8 + j;
+    };
+    if (local < o.b1) {                       // w1[row][k]
+        img[layer1_pos(local / L, local % L)] = hv;
+    } else if (local < o.w2) {                // b1[row] = input L (the constant 1)
+        img[layer1_pos(local - o.b1, L)] = hv;
+    } else if (local < o.b2) {                // w2[out][in]
+        const int out = (local - o.w2) / kH, in = (local - o.w2) % kH;
+        img[hidden_pos(P::kOff2, out, in, false)] = hv;
+        img[hidden_pos(D::kOffT2, in, out, false)] = hv;
+    } else if (local < o.w3) {
+        img[hidden_pos(P::kOff2, local - o.b2, kPolBiasUnit, false)] = hv;
+    } else if (local < o.b3) {
+        const int out = (local - o.w3) / kH, in = (local - o.w3) % kH;
+        img[hidden_pos(P::kOff3, out, in, false)] = hv;
+        img[hidden_pos(D::kOffT3, in, out, false)] = hv;
+    } else if (local < o.w4) {
+        img[hidden_pos(P::kOff3, local - o.b3, kPolBiasUnit, false)] = hv;
+    } else if (local < o.b4) {                // w4[oo][i]: output tile rows 0..O-1; W4^T: row = hidden unit i, k-slot (h, j) = oo
+        const int oo = (local - o.w4) / kH, i = (local - o.w4) % kH;
+        img[hidden_pos(P::kOff4, oo, i, true)] = hv;
+        img[((size_t)(D::kOffT4 + (i >> 5) * 64 + 32 * (oo >> 3) + (i & 31))) * 8 + (oo & 7)] = hv;
+    } else {                                  // b4[oo]
+        img[hidden_pos(P::kOff4, local - o.b4, kPolBiasUnit, true)] = hv;
+    }
+}
+
+template <int L>
+__global__ void __launch_bounds__(1024) ppo_apply_kernel(ApplyArgs a) {
+    PpoCtrl* c = a.ctrl;
+    if (a.take_step && c->stop) return;  // set by an EARLIER launch: uniform over the grid (SB3: no update after the early stop)
+    const unsigned long long gen = c->gen;
+    const int n = a.n;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const bool last_block = blockIdx.x == gridDim.x - 1;
+    __shared__ float red[8];
+    __shared__ double norm_sq_s;
+    __shared__ float kl_s;
+    const float g = reduce_grad_element(a, i, red);
+    if (a.grad_out) {
+        if (i < n) a.grad_out[i] = g;
+        if (last_block && threadIdx.x < 4) a.grad_out[n + threadIdx.x] = red[4 + threadIdx.x];
+    }
+    if (!a.take_step) {
+        if (last_block && threadIdx.x < 4 && a.stats) a.stats[threadIdx.x] += red[4 + threadIdx.x];
+        return;
+    }
+    // ---- squared norm, then a grid-wide barrier: every workgroup of this launch is resident (62 x 1024 threads on 256 CUs)
+    double sq = (double)g * g, unused = 0.0;
+    block_sum2_f64<1024>(sq, unused);
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(&c->sumsq[gen & 1], sq);
+        if (last_block) {
+            for (int k = 0; k < 4; ++k) __hip_atomic_store(&c->mb_stats[k], red[4 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c->sumsq[(gen + 1) & 1] = 0.0;   // the other parity slot is idle during this launch: clear it for the next one
+        }
+        __hip_atomic_fetch_add(&c->arrive, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = (gen + 1) * gridDim.x;
+        int spins = 0;
+        while (__hip_atomic_load(&c->arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 22)) {  // never observed; a bounded wait cannot hang the GPU
+                atomicAdd(&c->barrier_timeouts, 1);
+                break;
+            }
+        }
+        norm_sq_s = __hip_atomic_load(&c->sumsq[gen & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        kl_s = __hip_atomic_load(&c->mb_stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const double norm_sq = norm_sq_s;
+    const bool stop_now = a.kl_limit > 0.0f && kl_s > a.kl_limit;   // SB3: checked BEFORE the optimiser step of this minibatch
+    const bool finite = norm_sq <= 1.0e300;                          // false for inf and NaN
+    if (!stop_now && finite && i < n) {
+        const float norm = (float)sqrt(norm_sq);
+        const float clip = fminf(1.0f, a.max_norm / (norm + 1e-6f));  // torch.nn.utils.clip_grad_norm_
+        const float gc = g * clip;
+        const float mi = a.beta1 * a.m[i] + (1.0f - a.beta1) * gc;
+        const float vi = a.beta2 * a.v[i] + (1.0f - a.beta2) * gc * gc;
+        a.m[i] = mi;
+        a.v[i] = vi;
+        const float th = a.theta[i] - (a.lr / a.bc1) * mi / (sqrtf(vi) / a.bc2_sqrt + a.eps);  // torch.optim.Adam
+        a.theta[i] = th;
+        // operand images of the next minibatch: this parameter's f16 copies (log_std has none)
+        const int n4 = net_off(L, 4).total, n1 = net_off(L, 1).total;
+        if (i < n4) pack_scatter<L>(reinterpret_cast<_Float16*>(a.images), 4, i, th);
+        else if (i < n4 + n1) pack_scatter<L>(reinterpret_cast<_Float16*>(a.images + PpoDims<L>::kImage), 1, i - n4, th);
+    }
+    if (last_block && threadIdx.x == 0) {
+        if (a.stats)
+            for (int k = 0; k < 4; ++k) a.stats[k] += red[4 + k];
+        if (stop_now) c->stop = 1;
+        else if (finite) c->applied += 1;
+        else c->skipped_nonfinite += 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // the last workgroup to leave closes the generation (visible to the next launch)
+        const unsigned long long d = __hip_atomic_fetch_add(&c->depart, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (d + 1 == (gen + 1) * gridDim.x) c->gen = gen + 1;
+    }
 }
 
 // ---- GAE(lambda) and episode statistics over a rollout buffer [T][N] (what SB3's RolloutBuffer.compute_returns_and_advantage
-// and VecMonitor do on the host): one lane = one env.  done is 0 / 1 as float; time-limit truncations count as terminations.
+// and VecMonitor do on the host): one lane = one env.  done is 0 / 1 as float.  term_val (optional) = V(terminal observation)
+// at the steps that ended by the time limit, 0 elsewhere: SB3's collect_rollouts adds gamma * V(terminal_obs) to the reward
+// of a truncated step before the buffer sees it (the episode still ends there: no bootstrap through the reset).
 __global__ void __launch_bounds__(256) ppo_gae_kernel(int T, int N, const float* __restrict__ rew, const float* __restrict__ done,
-                                                      const float* __restrict__ val, const float* __restrict__ last_val, float gamma,
+                                                      const float* __restrict__ val, const float* __restrict__ last_val,
+                                                      const float* __restrict__ term_val, float gamma,
                                                       float lam, float* __restrict__ adv, float* __restrict__ ret,
                                                       float* __restrict__ ep_ret, float* __restrict__ ep_len,
                                                       float* __restrict__ ep_gates, float* __restrict__ fin) {
@@ -672,7 +808,8 @@ __global__ void __launch_bounds__(256) ppo_gae_kernel(int T, int N, const float*
         for (int t = T - 1; t >= 0; --t) {
             const size_t e = (size_t)t * N + i;
             const float nonterminal = 1.0f - done[e], v = val[e];
-            const float delta = rew[e] + gamma * next_val * nonterminal - v;
+            const float r = term_val ? fmaf(gamma, term_val[e], rew[e]) : rew[e];
+            const float delta = r + gamma * next_val * nonterminal - v;
             last = delta + gamma * lam * nonterminal * last;
             adv[e] = last;
             ret[e] = last + v;
@@ -718,13 +855,19 @@ struct qr_ppo {
     int image_half8 = 0, slots = 0, max_chunks = 32;  // chunks = split of the minibatch's sample groups in phase B
     qr::half8* d_images = nullptr;
     qr::half8* d_tbuf = nullptr;
-    float* d_grad = nullptr;
     float* d_partial = nullptr;  // [max_chunks][num_params] phase-B outputs
     float* d_wave = nullptr;     // [2][2 x max groups][8] per-wave sums of phase A
 #ifdef QR_PHASE_TIMING
     unsigned long long* ticks = nullptr;
 #endif
-    double* d_acc = nullptr;     // {sum adv, sum adv^2, sum grad^2, -}, see ppo_adv_stats_kernel
+    qr::PpoCtrl* d_ctrl = nullptr;
+    // advantage sums per minibatch: entries 0..kMaxEpochMinibatches-1 are filled for a whole epoch by qr_ppo_epoch_begin,
+    // the last entry serves a minibatch that was not announced that way
+    static constexpr int kMaxEpochMinibatches = 4096;
+    double* d_mbstats = nullptr;   // [kMaxEpochMinibatches + 1][2]
+    const int32_t* epoch_idx = nullptr;
+    int epoch_B = 0, epoch_count = 0, epoch_cursor = 0;
+    float target_kl = 0.0f;        // <= 0: no early stop
 };
 
 namespace qr {
@@ -751,7 +894,25 @@ struct PpoOps {
         PPO_HIP(hipGetLastError());
         return QR_OK;
     }
-    static int grad(qr_ppo* p, qr::PpoBatch b, hipStream_t st) {
+    // advantage statistics of this minibatch: the epoch table when the rows were announced by qr_ppo_epoch_begin, else one launch
+    static int adv_stats(qr_ppo* p, qr::PpoBatch& b, hipStream_t st) {
+        // the table is consumed strictly in order (entry k serves the call whose rows are idx_all + k * B); anything else
+        // disarms it, so a recycled buffer address can never pick up the sums of an older permutation
+        if (p->epoch_idx && b.B == p->epoch_B && p->epoch_cursor < p->epoch_count &&
+            b.idx == p->epoch_idx + (size_t)p->epoch_cursor * b.B) {
+            b.acc = p->d_mbstats + 2 * p->epoch_cursor;
+            if (++p->epoch_cursor == p->epoch_count) p->epoch_idx = nullptr;
+            return QR_OK;
+        }
+        p->epoch_idx = nullptr;
+        double* slot = p->d_mbstats + 2 * qr_ppo::kMaxEpochMinibatches;
+        PPO_HIP(hipMemsetAsync(slot, 0, 2 * sizeof(double), st));
+        hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((b.B + 1023) / 1024, 1), dim3(1024), 0, st, b.adv, b.idx, b.B, slot);
+        b.acc = slot;
+        return QR_OK;
+    }
+    // phase A + phase B: per-sample-chunk partial gradients in d_partial, per-wave sums in d_wave; returns the chunk count
+    static int grad(qr_ppo* p, qr::PpoBatch b, hipStream_t st, int* chunks_out) {
         const size_t lds = (size_t)D::kImage * 16 + 7 * qr::kStashRows * sizeof(float);  // operand images + per-sample stash
         static bool configured = false;
         if (!configured) {
@@ -761,23 +922,31 @@ struct PpoOps {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured = true;
         }
+        if (int rc = adv_stats(p, b, st)) return rc;
         // split the minibatch's sample groups into chunks: 2 * kBlocksPerNet x chunks waves in phase B
         int chunks = p->max_chunks;
         if (chunks > b.G) chunks = b.G;
         if (chunks < 1) chunks = 1;
         const int per = (b.G + chunks - 1) / chunks;
         chunks = (b.G + per - 1) / per;
-        hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((b.B + 1023) / 1024), dim3(1024), 0, st, b.adv, b.idx, b.B, p->d_acc);
         // one workgroup per CU (LDS): 4-wave workgroups (2 groups) while that still fits the 256 CUs in one round, else 8 waves
         if (b.G <= 256)
             hipLaunchKernelGGL((qr::ppo_phase_a_kernel<L, 256>), dim3((b.G + 1) / 2, 2), dim3(256), lds, st, b);
         else
             hipLaunchKernelGGL((qr::ppo_phase_a_kernel<L, 512>), dim3((b.G + 3) / 4, 2), dim3(512), lds, st, b);
         hipLaunchKernelGGL(qr::ppo_phase_b_kernel<L>, dim3(2 * D::kBlocksPerNet * chunks), dim3(64), 0, st, p->d_tbuf, p->d_partial,
-                           p->num_params, b.G, per, chunks, 1.0f / (float)b.B);
-        // chunk reduction + gradient norm (also leaves the complete gradient in d_grad)
-        hipLaunchKernelGGL(qr::ppo_norm_kernel, dim3((p->num_params + 1023) / 1024), dim3(1024), 0, st, p->d_grad, p->d_partial, chunks,
-                           p->num_params, p->d_wave, 2 * b.G, b.ent_coef, b.stats, p->d_acc);
+                           p->num_params, b.G, per, chunks, 1.0f / (float)b.B, &p->d_ctrl->stop);
+        PPO_HIP(hipGetLastError());
+        *chunks_out = chunks;
+        return QR_OK;
+    }
+    static int apply(qr_ppo* p, qr::ApplyArgs a, hipStream_t st) {
+        a.ctrl = p->d_ctrl;
+        a.images = p->d_images;
+        a.n = p->num_params;
+        a.partial = p->d_partial;
+        a.wave_out = p->d_wave;
+        hipLaunchKernelGGL(qr::ppo_apply_kernel<L>, dim3((p->num_params + 1023) / 1024), dim3(1024), 0, st, a);
         PPO_HIP(hipGetLastError());
         return QR_OK;
     }
@@ -808,16 +977,23 @@ int fill_batch(qr_ppo* p, qr::PpoBatch& b, const float* theta, const float* obs,
     b.obs = obs; b.act = act; b.old_logp = old_logp; b.adv = adv; b.ret = ret; b.idx = idx;
     b.B = B; b.G = B / 64;
     b.clip = clip; b.vf_coef = vf_coef; b.ent_coef = ent_coef;
-    b.acc = p->d_acc;
+    b.acc = nullptr;
     b.theta = theta;
     b.images = p->d_images;
     b.tbuf = p->d_tbuf;
     b.wave_out = p->d_wave;
     b.stats = stats;
+    b.stop = &p->d_ctrl->stop;
 #ifdef QR_PHASE_TIMING
     b.ticks = p->ticks;
 #endif
     return QR_OK;
+}
+
+void adam_constants(qr::ApplyArgs& a, float max_grad_norm, float lr, float beta1, float beta2, float eps, int adam_step) {
+    a.max_norm = max_grad_norm; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.bc1 = 1.0f - powf(beta1, (float)adam_step);
+    a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)adam_step));
 }
 
 }  // namespace
@@ -846,14 +1022,15 @@ int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo
     p->num_params = qr::ppo_num_params(obs_len);
     PPO_HIP(hipSetDevice(device));
     const size_t tbytes = (size_t)2 * p->slots * (max_minibatch / 64) * 256 * 16;
+    const size_t mbbytes = (size_t)(qr_ppo::kMaxEpochMinibatches + 1) * 2 * sizeof(double);
     hipError_t e = hipMalloc((void**)&p->d_images, (size_t)2 * p->image_half8 * 16);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_tbuf, tbytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_grad, (size_t)p->num_params * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_partial, (size_t)p->max_chunks * p->num_params * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_wave, (size_t)2 * 2 * (max_minibatch / 64) * 8 * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_acc, 4 * sizeof(double));
-    if (e == hipSuccess) e = hipMemset(p->d_grad, 0, (size_t)p->num_params * 4);
-    if (e == hipSuccess) e = hipMemset(p->d_acc, 0, 4 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_ctrl, sizeof(qr::PpoCtrl));
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_mbstats, mbbytes);
+    if (e == hipSuccess) e = hipMemset(p->d_ctrl, 0, sizeof(qr::PpoCtrl));
+    if (e == hipSuccess) e = hipMemset(p->d_mbstats, 0, mbbytes);
     if (e != hipSuccess) {
         qr_ppo_destroy(p);
         return ppofail(QR_E_HIP, std::string("qr_ppo_create: ") + hipGetErrorString(e));
@@ -868,10 +1045,10 @@ int qr_ppo_destroy(qr_ppo* p) {
     (void)hipDeviceSynchronize();
     (void)hipFree(p->d_images);
     (void)hipFree(p->d_tbuf);
-    (void)hipFree(p->d_grad);
     (void)hipFree(p->d_partial);
     (void)hipFree(p->d_wave);
-    (void)hipFree(p->d_acc);
+    (void)hipFree(p->d_ctrl);
+    (void)hipFree(p->d_mbstats);
     delete p;
     return QR_OK;
 }
@@ -888,6 +1065,41 @@ int qr_ppo_pack(qr_ppo* p, const float* theta_dev, void* stream) {
     return dispatch_L(p->L, [&](auto Lc) { return PpoOps<decltype(Lc)::value>::pack(p, theta_dev, (hipStream_t)stream); });
 }
 
+int qr_ppo_control(qr_ppo* p, float target_kl, int32_t clear, void* stream) {
+    if (!p) return ppofail(QR_E_INVALID, "qr_ppo_control: null handle");
+    PPO_HIP(hipSetDevice(p->device));
+    p->target_kl = target_kl;
+    if (clear) {  // stop flag and counters (the barrier counters that follow them in PpoCtrl keep running)
+        PPO_HIP(hipMemsetAsync(&p->d_ctrl->stop, 0, 4 * sizeof(int), (hipStream_t)stream));
+    }
+    return QR_OK;
+}
+
+int qr_ppo_status(qr_ppo* p, int32_t* out4, void* stream) {
+    if (!p || !out4) return ppofail(QR_E_INVALID, "qr_ppo_status: null argument");
+    PPO_HIP(hipSetDevice(p->device));
+    PPO_HIP(hipMemcpyAsync(out4, &p->d_ctrl->stop, 4 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    PPO_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return QR_OK;
+}
+
+int qr_ppo_epoch_begin(qr_ppo* p, const float* adv_dev, const int32_t* idx_dev, int32_t B, int32_t num_minibatches, void* stream) {
+    if (!p || !adv_dev || !idx_dev) return ppofail(QR_E_INVALID, "qr_ppo_epoch_begin: null argument");
+    if (B < 64 || B % 64 != 0 || B > p->max_B || num_minibatches < 1 || num_minibatches > qr_ppo::kMaxEpochMinibatches)
+        return ppofail(QR_E_INVALID, "qr_ppo_epoch_begin: bad minibatch size / count");
+    PPO_HIP(hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    PPO_HIP(hipMemsetAsync(p->d_mbstats, 0, (size_t)num_minibatches * 2 * sizeof(double), st));
+    hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((B + 1023) / 1024, num_minibatches), dim3(1024), 0, st, adv_dev, idx_dev, B,
+                       p->d_mbstats);
+    PPO_HIP(hipGetLastError());
+    p->epoch_idx = idx_dev;
+    p->epoch_B = B;
+    p->epoch_count = num_minibatches;
+    p->epoch_cursor = 0;
+    return QR_OK;
+}
+
 int qr_ppo_grad(qr_ppo* p, const float* theta_dev, const float* obs_dev, const float* act_dev, const float* old_logp_dev,
                 const float* adv_dev, const float* ret_dev, const int32_t* idx_dev, int32_t B, float clip, float vf_coef,
                 float ent_coef, float* grad_out_dev, float* stats_dev, void* stream) {
@@ -897,16 +1109,20 @@ int qr_ppo_grad(qr_ppo* p, const float* theta_dev, const float* obs_dev, const f
     if (!grad_out_dev) return ppofail(QR_E_INVALID, "qr_ppo_grad: null grad_out");
     PPO_HIP(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
-    PPO_HIP(hipMemsetAsync(p->d_acc, 0, 4 * sizeof(double), st));  // (d_grad is written in full by the norm kernel)
-    if (int rc = dispatch_L(p->L, [&](auto Lc) {
-            constexpr int L = decltype(Lc)::value;
-            if (int r = PpoOps<L>::pack(p, theta_dev, st)) return r;
-            return PpoOps<L>::grad(p, b, st);
-        }))
-        return rc;
-    PPO_HIP(hipMemcpyAsync(grad_out_dev, p->d_grad, (size_t)p->num_params * 4, hipMemcpyDeviceToDevice, st));
-    PPO_HIP(hipMemsetAsync(p->d_acc, 0, 4 * sizeof(double), st));
-    return QR_OK;
+    return dispatch_L(p->L, [&](auto Lc) {
+        constexpr int L = decltype(Lc)::value;
+        if (int r = PpoOps<L>::pack(p, theta_dev, st)) return r;
+        int chunks = 0;
+        if (int r = PpoOps<L>::grad(p, b, st, &chunks)) return r;
+        qr::ApplyArgs a{};
+        a.grad_out = grad_out_dev;
+        a.chunks = chunks;
+        a.Gw = 2 * b.G;
+        a.ent_coef = ent_coef;
+        a.stats = stats_dev;
+        a.take_step = 0;
+        return PpoOps<L>::apply(p, a, st);
+    });
 }
 
 int qr_ppo_minibatch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_dev, const float* obs_dev, const float* act_dev,
@@ -919,37 +1135,43 @@ int qr_ppo_minibatch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam
     if (!adam_m_dev || !adam_v_dev || adam_step < 1) return ppofail(QR_E_INVALID, "qr_ppo_minibatch: bad Adam state");
     PPO_HIP(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
-    const float bc1 = 1.0f - powf(beta1, (float)adam_step);
-    const float bc2s = sqrtf(1.0f - powf(beta2, (float)adam_step));
     return dispatch_L(p->L, [&](auto Lc) {
         constexpr int L = decltype(Lc)::value;
-        if (int r = PpoOps<L>::grad(p, b, st)) return r;  // images were packed by the previous call (or qr_ppo_pack)
-        const int pb = (p->num_params + 255) / 256;
-        hipLaunchKernelGGL(qr::ppo_adam_kernel, dim3(pb), dim3(256), 0, st, theta_dev, adam_m_dev, adam_v_dev, p->d_grad,
-                           p->num_params, p->d_acc, max_grad_norm, lr, beta1, beta2, eps, bc1, bc2s);
-        PPO_HIP(hipGetLastError());
-        return PpoOps<L>::pack(p, theta_dev, st);
+        int chunks = 0;
+        if (int r = PpoOps<L>::grad(p, b, st, &chunks)) return r;  // images were packed by the previous call (or qr_ppo_pack)
+        qr::ApplyArgs a{};
+        a.theta = theta_dev; a.m = adam_m_dev; a.v = adam_v_dev;
+        a.chunks = chunks;
+        a.Gw = 2 * b.G;
+        a.ent_coef = ent_coef;
+        a.stats = stats_dev;
+        a.kl_limit = p->target_kl > 0.0f ? 1.5f * p->target_kl * (float)B : 0.0f;
+        a.take_step = 1;
+        adam_constants(a, max_grad_norm, lr, beta1, beta2, eps, adam_step);
+        return PpoOps<L>::apply(p, a, st);
     });
 }
 
-// Data-parallel training: every rank calls qr_ppo_grad on its shard of the minibatch, the caller averages the gradients
-// (one all-reduce of num_params floats over RCCL), then every rank applies the same update with qr_ppo_apply.
-int qr_ppo_apply(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_dev, float* grad_dev, float max_grad_norm, float lr,
-                 float beta1, float beta2, float eps, int32_t adam_step, void* stream) {
-    if (!p || !theta_dev || !adam_m_dev || !adam_v_dev || !grad_dev || adam_step < 1) return ppofail(QR_E_INVALID, "qr_ppo_apply: bad argument");
+// Data-parallel training: every rank calls qr_ppo_grad on its shard of the minibatch, the caller averages the [n + 4] vector
+// (gradient + minibatch statistics: one all-reduce over RCCL), then every rank applies the same update with qr_ppo_apply --
+// including the same target-KL decision, because the KL sum travels with the gradient.
+int qr_ppo_apply(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_dev, float* grad_dev, int32_t B, float max_grad_norm,
+                 float lr, float beta1, float beta2, float eps, int32_t adam_step, float* stats_dev, void* stream) {
+    if (!p || !theta_dev || !adam_m_dev || !adam_v_dev || !grad_dev || adam_step < 1 || B < 1)
+        return ppofail(QR_E_INVALID, "qr_ppo_apply: bad argument");
     PPO_HIP(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
-    const float bc1 = 1.0f - powf(beta1, (float)adam_step);
-    const float bc2s = sqrtf(1.0f - powf(beta2, (float)adam_step));
-    PPO_HIP(hipMemsetAsync(p->d_acc, 0, 4 * sizeof(double), st));
-    hipLaunchKernelGGL(qr::ppo_sqnorm_kernel, dim3((p->num_params + 1023) / 1024), dim3(1024), 0, st, grad_dev, p->num_params, p->d_acc);
-    hipLaunchKernelGGL(qr::ppo_adam_kernel, dim3((p->num_params + 255) / 256), dim3(256), 0, st, theta_dev, adam_m_dev, adam_v_dev,
-                       grad_dev, p->num_params, p->d_acc, max_grad_norm, lr, beta1, beta2, eps, bc1, bc2s);
-    PPO_HIP(hipGetLastError());
-    const int rc = dispatch_L(p->L, [&](auto Lc) { return PpoOps<decltype(Lc)::value>::pack(p, theta_dev, st); });
-    if (rc != QR_OK) return rc;
-    PPO_HIP(hipMemsetAsync(p->d_acc, 0, 4 * sizeof(double), st));
-    return QR_OK;
+    return dispatch_L(p->L, [&](auto Lc) {
+        constexpr int L = decltype(Lc)::value;
+        qr::ApplyArgs a{};
+        a.theta = theta_dev; a.m = adam_m_dev; a.v = adam_v_dev;
+        a.ext_grad = grad_dev;
+        a.stats = stats_dev;
+        a.kl_limit = p->target_kl > 0.0f ? 1.5f * p->target_kl * (float)B : 0.0f;
+        a.take_step = 1;
+        adam_constants(a, max_grad_norm, lr, beta1, beta2, eps, adam_step);
+        return PpoOps<L>::apply(p, a, st);
+    });
 }
 
 // Forward pass of one of the two networks with the operand images of the last pack (0 = policy means, 1 = value in column 0):
@@ -964,14 +1186,14 @@ int qr_ppo_forward(qr_ppo* p, int32_t net, int32_t n, const float* obs_dev, floa
 
 // GAE(lambda) advantages / returns of a rollout [T][N] and (optionally) episode statistics; see ppo_gae_kernel.
 int qr_ppo_gae(qr_ppo* p, int32_t T, int32_t N, const float* rew_dev, const float* done_dev, const float* val_dev,
-               const float* last_val_dev, float gamma, float lam, float* adv_out_dev, float* ret_out_dev, float* ep_ret_dev,
-               float* ep_len_dev, float* ep_gates_dev, float* fin_dev, void* stream) {
+               const float* last_val_dev, const float* term_val_dev, float gamma, float lam, float* adv_out_dev, float* ret_out_dev,
+               float* ep_ret_dev, float* ep_len_dev, float* ep_gates_dev, float* fin_dev, void* stream) {
     if (!p || !rew_dev || !done_dev || !val_dev || !last_val_dev || !adv_out_dev || !ret_out_dev || T < 1 || N < 1)
         return ppofail(QR_E_INVALID, "qr_ppo_gae: bad argument");
     if (ep_ret_dev && (!ep_len_dev || !ep_gates_dev)) return ppofail(QR_E_INVALID, "qr_ppo_gae: episode state needs all three arrays");
     PPO_HIP(hipSetDevice(p->device));
     hipLaunchKernelGGL(qr::ppo_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, T, N, rew_dev, done_dev, val_dev,
-                       last_val_dev, gamma, lam, adv_out_dev, ret_out_dev, ep_ret_dev, ep_len_dev, ep_gates_dev, fin_dev);
+                       last_val_dev, term_val_dev, gamma, lam, adv_out_dev, ret_out_dev, ep_ret_dev, ep_len_dev, ep_gates_dev, fin_dev);
     PPO_HIP(hipGetLastError());
     return QR_OK;
 }

@@ -9,8 +9,15 @@ SB3 is not a dependency here and its NumPy rollout buffer would put a host round
 compact torch implementation of the same algorithm that consumes the env's device tensors directly
 (`step_device`), so observations, actions, rewards and the rollout buffer never leave HBM.  With tens of thousands
 of envs the rollout is short and the minibatches large (`n_steps`, `batch_size`, `n_epochs` are arguments; the
-reference's values suit its 100 envs).  Time-limit truncations are treated like terminations (the reference's own
-bootstrap uses a post-reset observation, see vec_env._make_infos).
+reference's values suit its 100 envs).
+
+Time-limit truncations follow SB3's rule (`collect_rollouts`): the reward of a step that ended by the time limit gets
+gamma * V(terminal observation) added, the episode still ends there.  The env kernels hand out the TRUE terminal
+observation (final state before the auto-reset, `set_terminal_obs_buffer`); the reference fills
+`infos[i]["terminal_observation"]` after `reset_()` (R:589-594), so its SB3 run bootstraps from the first observation of
+the next episode -- that quirk is not reproduced (`truncation_bootstrap=False` gives the round-1 behaviour: truncation =
+termination).  `target_kl` early stopping is SB3's: checked per minibatch before the optimiser step; with the matrix-core
+updater the decision is taken on the device (no host round trip) and, data-parallel, on the all-reduced KL.
 """
 import math
 import time
@@ -140,7 +147,7 @@ class MfmaPpoUpdater:
     def grad(self, obs, act, old_lp, adv, ret, idx, clip=0.2, vf_coef=0.5, ent_coef=0.0, stats=False):
         """Flat gradient of the PPO loss on the rows `idx` (no clipping, no optimiser step)."""
         self._check(obs, act, old_lp, adv, ret, idx)
-        g = torch.empty_like(self.theta)
+        g = torch.empty(self.theta.numel() + 4, dtype=torch.float32, device=self.device)  # gradient + minibatch statistics
         self._lib.check(self._L.qr_ppo_grad(self._h, self._p(self.theta), self._p(obs), self._p(act), self._p(old_lp), self._p(adv),
                                             self._p(ret), self._p(idx), int(idx.numel()), clip, vf_coef, ent_coef, self._p(g),
                                             self._p(self.stats) if stats else None, self._stream()))
@@ -169,32 +176,53 @@ class MfmaPpoUpdater:
         self._lib.check(self._L.qr_ppo_forward(self._h, int(net), int(obs.shape[0]), self._p(obs), self._p(out), self._stream()))
         return out if net == 0 else out[:, 0]
 
-    def gae(self, rew, done, val, last_val, gamma, lam, ep_state=None, fin=None):
-        """GAE(lambda) over a rollout [T, N] in one kernel -> (advantages, returns); `ep_state` = (ep_ret, ep_len, ep_gates)
-        running per-env episode statistics (updated in place), sums over finished episodes accumulate into `fin` [4]."""
+    def gae(self, rew, done, val, last_val, gamma, lam, ep_state=None, fin=None, term_val=None):
+        """GAE(lambda) over a rollout [T, N] in one kernel -> (advantages, returns); `term_val` [T, N] = V(terminal obs) at
+        time-limit truncations (0 elsewhere; SB3's bootstrap); `ep_state` = (ep_ret, ep_len, ep_gates) running per-env episode
+        statistics (updated in place), sums over finished episodes accumulate into `fin` [4]."""
         T, N = rew.shape
-        for t in (rew, done, val, last_val):
+        for t in (rew, done, val, last_val) + ((term_val,) if term_val is not None else ()):
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
         adv, ret = torch.empty_like(rew), torch.empty_like(rew)
         er, el, eg = ep_state if ep_state is not None else (None, None, None)
-        self._lib.check(self._L.qr_ppo_gae(self._h, T, N, self._p(rew), self._p(done), self._p(val), self._p(last_val), gamma, lam,
-                                           self._p(adv), self._p(ret), self._p(er), self._p(el), self._p(eg), self._p(fin),
-                                           self._stream()))
+        self._lib.check(self._L.qr_ppo_gae(self._h, T, N, self._p(rew), self._p(done), self._p(val), self._p(last_val),
+                                           self._p(term_val), gamma, lam, self._p(adv), self._p(ret), self._p(er), self._p(el),
+                                           self._p(eg), self._p(fin), self._stream()))
         return adv, ret
 
-    def apply(self, grad, lr, max_grad_norm=0.5):
-        """Clip `grad` (flat, consumed) to the global norm and take one Adam step -- the second half of a data-parallel
-        update: `g = up.grad(...); dist.all_reduce(g); g /= world; up.apply(g, lr)`."""
-        assert grad.is_cuda and grad.dtype == torch.float32 and grad.is_contiguous() and grad.numel() == self.theta.numel()
+    def control(self, target_kl=None, clear=True):
+        """Arms SB3's target-KL early stop (None / <= 0: off) and, with `clear`, resets the sticky stop flag and the
+        update counters -- call at the start of every train()."""
+        self._lib.check(self._L.qr_ppo_control(self._h, float(target_kl or 0.0), int(bool(clear)), self._stream()))
+
+    def status(self):
+        """(stopped, optimiser steps taken, updates skipped for a non-finite gradient, barrier timeouts); synchronises."""
+        out = (self._C.c_int32 * 4)()
+        self._lib.check(self._L.qr_ppo_status(self._h, out, self._stream()))
+        return bool(out[0]), int(out[1]), int(out[2]), int(out[3])
+
+    def begin_epoch(self, adv, perm, B):
+        """One launch for the advantage mean / std sums of every minibatch perm[k B:(k + 1) B] of the epoch."""
+        assert perm.is_cuda and perm.dtype == torch.int32 and perm.is_contiguous() and perm.numel() % B == 0
+        self._lib.check(self._L.qr_ppo_epoch_begin(self._h, self._p(adv), self._p(perm), int(B), perm.numel() // int(B),
+                                                   self._stream()))
+
+    def apply(self, grad, lr, B, max_grad_norm=0.5, stats=True):
+        """Clip `grad` ([n + 4]: flat gradient + minibatch statistics, as returned by grad()) to the global norm and take one
+        Adam step -- the second half of a data-parallel update: `g = up.grad(...); dist.all_reduce(g); g /= world;
+        up.apply(g, lr, B)`.  The target-KL decision uses the (averaged) KL sum carried in g."""
+        assert grad.is_cuda and grad.dtype == torch.float32 and grad.is_contiguous() and grad.numel() == self.theta.numel() + 4
         self.step += 1
-        self._lib.check(self._L.qr_ppo_apply(self._h, self._p(self.theta), self._p(self.m), self._p(self.v), self._p(grad),
-                                             max_grad_norm, lr, self.betas[0], self.betas[1], self.eps, self.step, self._stream()))
+        self._lib.check(self._L.qr_ppo_apply(self._h, self._p(self.theta), self._p(self.m), self._p(self.v), self._p(grad), int(B),
+                                             max_grad_norm, lr, self.betas[0], self.betas[1], self.eps, self.step,
+                                             self._p(self.stats) if stats else None, self._stream()))
 
     def minibatch(self, obs, act, old_lp, adv, ret, idx, lr, clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5):
         if self.data_parallel():
-            # data parallel: every rank holds the same parameters and its own envs; average the 63 k-float gradient
-            g = self.grad(obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef, stats=True)
-            return self.apply(average_across_ranks(g), lr, max_grad_norm)
+            # data parallel: every rank holds the same parameters and its own envs; average the gradient (and the minibatch
+            # statistics that ride behind it: every rank then takes the same target-KL decision)
+            g = self.grad(obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef, stats=False)
+            return self.apply(average_across_ranks(g), lr, int(idx.numel()), max_grad_norm)
         self.step += 1
         self._lib.check(self._L.qr_ppo_minibatch(self._h, self._p(self.theta), self._p(self.m), self._p(self.v), self._p(obs),
                                                  self._p(act), self._p(old_lp), self._p(adv), self._p(ret), self._p(idx),
@@ -206,7 +234,7 @@ class PPO:
     def __init__(self, env, n_steps=32, batch_size=None, n_epochs=5, gamma=0.999, gae_lambda=0.95, clip_range=0.2,
                  learning_rate=3e-4, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, net_arch=(120, 120, 120),
                  log_std_init=0.0, seed=0, target_kl=None, lr_final_frac=1.0, total_timesteps_hint=None,
-                 fused_collect=False, native_update=False):
+                 fused_collect=False, native_update=False, truncation_bootstrap=True):
         self.env = env
         self.n_envs, self.dev = env.num_envs, env.device
         self.n_steps, self.n_epochs = n_steps, n_epochs
@@ -226,6 +254,10 @@ class PPO:
         self.buf_val = torch.empty((T, N), **f32)
         self.buf_rew = torch.empty((T, N), **f32)
         self.buf_done = torch.empty((T, N), **f32)
+        # SB3's time-limit bootstrap: V(terminal observation) at truncated steps (0 elsewhere), added to the reward x gamma
+        self.truncation_bootstrap = bool(truncation_bootstrap)
+        self.buf_term_val = torch.zeros((T, N), **f32) if self.truncation_bootstrap else None
+        self._term_obs = None
         self._done_u8 = torch.empty((T, N), dtype=torch.uint8, device=self.dev)
         self._trunc_u8 = torch.empty((T, N), dtype=torch.uint8, device=self.dev)
         self.num_timesteps = 0
@@ -253,6 +285,9 @@ class PPO:
 
             self._mfma = MfmaPolicy(obs_dim, self.dev.index)
             self._last_obs = None
+        if self.truncation_bootstrap:  # the kernels write the pre-reset observation of finished envs here
+            self._term_obs = torch.zeros((T, N, obs_dim) if fused_collect else (N, obs_dim), **f32)
+            env.set_terminal_obs_buffer(self._term_obs)
 
     @torch.no_grad()
     def _episode_stats(self, rew, done):
@@ -282,13 +317,25 @@ class PPO:
         self.buf_done.copy_(done)
         T, N = self.n_steps, self.n_envs
         self.num_timesteps += T * N
+        value = (lambda o: self._updater.forward(1, o.contiguous()).contiguous()) if self._updater is not None else self.policy.value
+        if self.truncation_bootstrap:
+            # rows that ended by the time limit (rare: at most one per env per max_steps): V of their terminal observation
+            self.buf_term_val.zero_()
+            rows = trunc.view(-1).nonzero().squeeze(1)
+            self.stats["truncations"] = int(rows.numel())
+            if rows.numel():
+                self.buf_term_val.view(-1)[rows] = value(self._term_obs.view(T * N, -1)[rows])
         if self._updater is not None:   # values on the matrix cores too; GAE and episode statistics follow in train()
-            self.buf_val.copy_(self._updater.forward(1, self.buf_obs.view(T * N, -1)).view(T, N))
-            self.last_val = self._updater.forward(1, last_obs.contiguous()).contiguous()
+            self.buf_val.copy_(value(self.buf_obs.view(T * N, -1)).view(T, N))
+            self.last_val = value(last_obs)
             self._stats_pending = True
             return
-        self.buf_val.copy_(self.policy.value(self.buf_obs.view(T * N, -1)).view(T, N))
-        self.last_val = self.policy.value(last_obs)
+        self.buf_val.copy_(value(self.buf_obs.view(T * N, -1)).view(T, N))
+        self.last_val = value(last_obs)
+        # the torch update evaluates log-probs with the f32 network: store the OLD log-probs from the same network, not the
+        # f16 matrix-core ones of the rollout kernel, so that the ratio is exactly 1 at the first minibatch
+        lp, _ = self.policy.log_prob_entropy(self.buf_obs.view(T * N, -1), self.buf_act.view(T * N, 4))
+        self.buf_lp.copy_(lp.view(T, N))
         self._episode_stats(self.buf_rew, self.buf_done)
 
     @torch.no_grad()
@@ -302,10 +349,12 @@ class PPO:
             self.buf_act[t].copy_(actions)
             self.buf_lp[t].copy_(lp)
             self.buf_val[t].copy_(val)
-            obs, rew, done, _ = self.env.step_device(actions.clamp(-1.0, 1.0).contiguous())  # SB3 clips to the Box
+            obs, rew, done, trunc = self.env.step_device(actions.clamp(-1.0, 1.0).contiguous())  # SB3 clips to the Box
             d = done.to(torch.float32)
             self.buf_rew[t].copy_(rew)
             self.buf_done[t].copy_(d)
+            if self.truncation_bootstrap:  # rows of envs that did not finish hold stale data: masked by trunc
+                self.buf_term_val[t].copy_(torch.where(trunc.bool(), torch.nan_to_num(self.policy.value(self._term_obs)), 0.0))
             self.ep_ret += rew
             self.ep_len += 1.0
             self.ep_gates += (rew > 5.0).to(torch.float32)  # gate reward 10 - 10*d2g (R:537)
@@ -334,7 +383,8 @@ class PPO:
         next_val = self.last_val
         for t in reversed(range(T)):
             nonterminal = 1.0 - self.buf_done[t]
-            delta = self.buf_rew[t] + self.gamma * next_val * nonterminal - self.buf_val[t]
+            rew = self.buf_rew[t] if self.buf_term_val is None else self.buf_rew[t] + self.gamma * self.buf_term_val[t]
+            delta = rew + self.gamma * next_val * nonterminal - self.buf_val[t]
             last = delta + self.gamma * self.lam * nonterminal * last
             adv[t] = last
             next_val = self.buf_val[t]
@@ -355,12 +405,15 @@ class PPO:
             self.buf_rew[bad] = 0.0
             self.buf_val[bad] = 0.0
             self.last_val = torch.nan_to_num(self.last_val)
+            if self.buf_term_val is not None:
+                self.buf_term_val.nan_to_num_()
 
     def _gae_native(self):
         fin = torch.zeros(4, dtype=torch.float32, device=self.dev)
         pending = getattr(self, "_stats_pending", False)
         adv, ret = self._updater.gae(self.buf_rew, self.buf_done, self.buf_val, self.last_val, self.gamma, self.lam,
-                                     (self.ep_ret, self.ep_len, self.ep_gates) if pending else None, fin if pending else None)
+                                     (self.ep_ret, self.ep_len, self.ep_gates) if pending else None, fin if pending else None,
+                                     term_val=self.buf_term_val)
         if pending:
             self._stats_pending = False
             f = fin.tolist() + [float(self.buf_rew.mean())]
@@ -421,25 +474,30 @@ class PPO:
     def _train_native(self, obs, act, old_lp, adv, ret, B):
         up = self._updater
         lr = self.opt.param_groups[0]["lr"]
-        n_updates = 0
+        kl_stop = self.target_kl is not None and self.target_kl < 1e8
+        # SB3's target_kl rule runs on the device: before each optimiser step the update kernel compares the minibatch's
+        # mean approx-KL (data-parallel: the all-reduced one) with 1.5 target_kl; a hit skips that step and turns every
+        # later launch of this train() into a no-op -- no host synchronisation inside the loop, identical on every rank
+        up.control(self.target_kl if kl_stop else None, clear=True)
         up.stats.zero_()
+        launched = 0
         for _ in range(self.n_epochs):
             perm = torch.randperm(B, device=self.dev).to(torch.int32)
-            if self.target_kl is not None and self.target_kl < 1e8:
-                up.stats.zero_()
+            up.begin_epoch(adv, perm, self.batch_size)
             for s in range(0, B, self.batch_size):
                 up.minibatch(obs, act, old_lp, adv, ret, perm[s:s + self.batch_size], lr, self.clip, self.vf_coef, self.ent_coef,
                              self.max_grad_norm)
-                n_updates += 1
-            if self.target_kl is not None and self.target_kl < 1e8:   # SB3 checks every minibatch; here once per epoch
-                if float(up.stats[2]) / B > 1.5 * self.target_kl:
-                    break
+                launched += 1
+        stopped, applied, skipped, timeouts = up.status()
+        assert timeouts == 0, "grid barrier of the update kernel timed out"
         st = up.stats.tolist()
-        seen = max(1, n_updates * self.batch_size) if not (self.target_kl is not None and self.target_kl < 1e8) else B
+        seen = max(1, (applied + skipped + (1 if stopped else 0)) * self.batch_size)
         self.stats["loss"] = (st[0] + self.vf_coef * st[1]) / seen
         self.stats["approx_kl"] = st[2] / seen
         self.stats["clip_fraction"] = st[3] / seen
-        self.stats["updates"] = self.stats.get("updates", 0) + n_updates
+        self.stats["updates"] = self.stats.get("updates", 0) + applied
+        self.stats["early_stop"] = bool(stopped)
+        self.stats["skipped_nonfinite"] = self.stats.get("skipped_nonfinite", 0) + skipped
         self.stats["std"] = float(self.policy.log_std.detach().exp().mean())
 
     def learn(self, total_timesteps, log_every=10, callback=None):

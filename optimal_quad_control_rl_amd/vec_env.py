@@ -457,6 +457,25 @@ class Quadcopter3DGates(_Base):
         return {**state_dict, **action_dict}
 
     # ------------------------------------------------------------------ device fast path (no host sync)
+    def set_terminal_obs_buffer(self, buf):
+        """Register (or, with None, remove) a float32 CUDA tensor that receives the TRUE terminal observation -- the
+        gate-frame observation of an episode's final state, taken before the auto-reset -- of every env that finishes
+        at a step: shape [N, L] for step_device, [K, N, L] for rollout_device / step_sequence_device /
+        rollout_policy_device (row [k, env]).  Rows of envs that did not finish are left untouched.  This is what SB3
+        bootstraps time-limit truncations from; the reference itself fills `terminal_observation` after reset_()
+        (R:589-594), i.e. with the first observation of the NEXT episode."""
+        if buf is not None:
+            assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous() and buf.shape[-1] == self.state_len
+            assert buf.shape[-2] == self.num_envs
+        self._term_obs_buf = buf   # keep it alive while the library holds the pointer
+        _lib.check(self._L.qr_set_terminal_obs(self._h, _ptr(buf)))
+
+    def probe_residual(self):
+        """[N, 7] device tensor (vb[3], residual thrust, residual moment[3]) of the current states (E2E + residual only)."""
+        out = torch.empty((self.num_envs, 7), dtype=torch.float32, device=self.device)
+        _lib.check(self._L.qr_probe_residual(self._h, _ptr(out), self._stream()))
+        return out
+
     def reset_device(self):
         _lib.check(self._L.qr_reset(self._h, None, _ptr(self._obs), self._stream()))
         return self._obs

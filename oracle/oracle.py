@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libquadrace_oracle.so")
+# QR_ORACLE_LIB selects another build of the same sources (the sanitizer build of `make -C oracle asan-test`)
+_LIB_PATH = os.environ.get("QR_ORACLE_LIB") or os.path.join(_HERE, "libquadrace_oracle.so")
 _REF_LIB_PATH = os.path.join(_HERE, "_ref", "libref_residual.so")
 
 E2E, INDI = 0, 1
@@ -25,7 +26,7 @@ def build(force=False):
     """Compile the oracle (and oracle/_ref when /root/reference is mounted)."""
     srcs = [os.path.join(_HERE, f) for f in ("quadrace_oracle.c", "quad3d_oracle.c")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "libquadrace_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, os.path.basename(_LIB_PATH)], stdout=subprocess.DEVNULL)
     if force or not os.path.exists(_REF_LIB_PATH):
         subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
@@ -46,6 +47,7 @@ def lib():
         L.qro_set_disturbance.argtypes = [C.c_void_p, _f32p, C.c_float]
         L.qro_set_limits.argtypes = [C.c_void_p, C.c_int, C.c_float]
         L.qro_set_pause.argtypes = [C.c_void_p, C.c_int]
+        L.qro_set_terminal_obs.argtypes = [C.c_void_p, _f32p]
         L.qro_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.qro_seed.argtypes = [C.c_void_p, C.c_uint64]
         L.qro_reset.argtypes = [C.c_void_p, _u8p, _f32p]
@@ -192,6 +194,13 @@ class OracleEnv:
 
     def set_pause(self, pause):
         self.L.qro_set_pause(self.h, int(bool(pause)))
+
+    def set_terminal_obs(self, buf):
+        """buf: float32 [num_envs, obs_len] array (kept alive here) receiving the pre-reset observation of every env that
+        finishes at a step (twin of qr_set_terminal_obs), or None."""
+        self._term_obs = None if buf is None else buf
+        assert buf is None or (buf.dtype == np.float32 and buf.flags["C_CONTIGUOUS"])
+        self.L.qro_set_terminal_obs(self.h, None if buf is None else _p(buf))
 
     def set_threads(self, threads):
         """cpu_baseline only: spread the independent envs over OpenMP threads (results are unchanged)."""

@@ -45,6 +45,7 @@ typedef struct qro_env {
     float mlp[740];
     uint64_t seed, env_id_base;
     float *world, *dist, *obs;
+    float* term_obs; /* optional caller buffer [n][obs_len]: pre-reset observation of envs that finish at a step */
     int32_t *target, *steps;
     uint32_t* episode;
     int threads; /* cpu_baseline only: OpenMP threads over the (independent) envs; 1 = scalar loop */
@@ -380,6 +381,7 @@ void qro_set_disturbance(qro_env* e, const float* ranges, float scale) {
 }
 void qro_set_limits(qro_env* e, int max_steps, float dt) { e->max_steps = max_steps; e->dt = dt; }
 void qro_set_pause(qro_env* e, int pause) { e->pause = pause; }
+void qro_set_terminal_obs(qro_env* e, float* buf) { e->term_obs = buf; } /* twin of qr_set_terminal_obs (qr_step rows) */
 int qro_set_threads(qro_env* e, int threads) {
 #ifdef _OPENMP
     e->threads = threads < 1 ? 1 : threads;
@@ -477,6 +479,7 @@ void qro_step(qro_env* e, const float* actions, float* obs_out, float* rew_out, 
             if (!done) memcpy(w, nw, sizeof(float) * S);
         } else {                                                   /* R:581-585 */
             memcpy(w, nw, sizeof(float) * S);
+            if (done && e->term_obs) observe_one(e, i, e->term_obs + (size_t)i * e->obs_len); /* true terminal observation */
             if (done) reset_one(e, i);
         }
         if (rew_out) rew_out[i] = reward;

@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_header_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/*.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert _lib.load().qr_abi_version() == 1
+    assert _lib.load().qr_abi_version() == 2
 
 
 def test_no_cpu_fallback():

@@ -109,8 +109,9 @@ def test_gradient_matches_autograd(L, B, clip):
             # same operands: only the f16 rounding of the deltas remains (a 64-sample sum of +-deltas can cancel)
             assert err16 < (6e-3 if B >= 256 else 3e-2), (name, err16, report)
         assert err < 1e-1 and cos > 0.995, (name, err, cos, report)
-    assert off == g.numel()
+    assert off + 4 == g.numel()                              # the minibatch statistics ride behind the gradient
     st = up.stats.cpu().numpy()
+    assert np.allclose(g[off:].cpu().numpy(), st, rtol=1e-6, atol=1e-6)
     assert abs(st[0] / B - float(pg)) < 5e-3 * max(1.0, abs(float(pg)))
     assert abs(st[1] / B - float(vl)) < 5e-3 * max(1.0, abs(float(vl)))
     clipped = float(((ratio - 1).abs() > clip).float().sum())
@@ -186,7 +187,7 @@ def test_grad_then_apply_equals_minibatch():
         idx = perm[k * B:(k + 1) * B].contiguous()
         up_a.minibatch(obs, act, old_lp, adv, ret, idx, lr=3e-4)
         g = up_b.grad(obs, act, old_lp, adv, ret, idx)
-        up_b.apply(g, lr=3e-4)
+        up_b.apply(g, lr=3e-4, B=B)
     assert up_a.step == up_b.step == 3
     assert torch.allclose(up_a.theta, up_b.theta, rtol=0, atol=2e-7), float((up_a.theta - up_b.theta).abs().max())
     assert torch.allclose(up_a.m, up_b.m, rtol=1e-5, atol=1e-9)
@@ -215,7 +216,7 @@ def test_gae_and_value_forward_match_torch():
             return torch.zeros((self.num_envs, self.state_len), device=self.device)
 
     T, N = 32, 4096
-    ref = PPO(FakeEnv(), n_steps=T, batch_size=N * T // 4, gamma=0.99)
+    ref = PPO(FakeEnv(), n_steps=T, batch_size=N * T // 4, gamma=0.99, truncation_bootstrap=False)
     pol, _, up, obs, *_ = _setup(17, 8192, seed=3, max_minibatch=4096)
     g = torch.Generator(device=obs.device).manual_seed(5)
     rew = torch.randn((T, N), device=obs.device, generator=g) * 0.3
@@ -239,3 +240,107 @@ def test_gae_and_value_forward_match_torch():
     v, m = up.forward(1, obs), up.forward(0, obs)
     assert (v - v_ref).abs().max() < 2e-2 * max(1.0, float(v_ref.abs().max()))
     assert (m - m_ref).abs().max() < 2e-2 * max(1.0, float(m_ref.abs().max()))
+
+
+def test_gae_with_truncation_bootstrap_matches_sb3_rule():
+    """SB3 restated in torch: `collect_rollouts` adds gamma * V(terminal_observation) to the reward of every step that ended
+    by the time limit (infos["TimeLimit.truncated"]) BEFORE the buffer stores it; `compute_returns_and_advantage` then treats
+    every done as the end of the episode (next_non_terminal = 1 - episode_start).  qr_ppo_gae takes V(terminal obs) as
+    term_val [T, N] (0 where the step was not truncated) and must give the same advantages / returns; the episode returns of
+    the on-device VecMonitor stay those of the RAW rewards."""
+    pol, _, up, obs, *_ = _setup(17, 4096, seed=9, max_minibatch=4096)
+    dev = obs.device
+    T, N, gamma, lam = 48, 2048, 0.999, 0.95
+    g = torch.Generator(device=dev).manual_seed(17)
+    rew = torch.randn((T, N), device=dev, generator=g) * 0.3
+    done = (torch.rand((T, N), device=dev, generator=g) < 0.05)
+    trunc = done & (torch.rand((T, N), device=dev, generator=g) < 0.5)            # half of the episode ends are time limits
+    val = torch.randn((T, N), device=dev, generator=g) * 5.0
+    last_val = torch.randn(N, device=dev, generator=g) * 5.0
+    term_v = torch.randn((T, N), device=dev, generator=g) * 5.0                  # V(terminal_observation) of each row
+    term_val = torch.where(trunc, term_v, torch.zeros_like(term_v)).contiguous()
+    # --- SB3
+    rewards = rew.clone()
+    rewards[trunc] += gamma * term_v[trunc]                                       # collect_rollouts
+    adv_ref = torch.zeros_like(rew)
+    last_gae = torch.zeros(N, device=dev)
+    for t in reversed(range(T)):                                                  # compute_returns_and_advantage
+        if t == T - 1:
+            next_non_terminal, next_values = 1.0 - done[t].float(), last_val      # SB3 passes `dones` of the last step
+        else:
+            next_non_terminal, next_values = 1.0 - done[t].float(), val[t + 1]    # episode_starts[t + 1] == dones[t]
+        delta = rewards[t] + gamma * next_values * next_non_terminal - val[t]
+        last_gae = delta + gamma * lam * next_non_terminal * last_gae
+        adv_ref[t] = last_gae
+    ret_ref = adv_ref + val
+    er, el, eg = (torch.zeros(N, device=dev) for _ in range(3))
+    fin = torch.zeros(4, device=dev)
+    adv, ret = up.gae(rew.contiguous(), done.float().contiguous(), val.contiguous(), last_val.contiguous(), gamma, lam, (er, el, eg), fin,
+                      term_val=term_val)
+    assert torch.allclose(adv, adv_ref, rtol=1e-5, atol=2e-4), float((adv - adv_ref).abs().max())
+    assert torch.allclose(ret, ret_ref, rtol=1e-5, atol=2e-4)
+    # without term_val a truncation is a termination: the advantages at truncated rows differ by gamma * V(terminal obs)
+    adv0, _ = up.gae(rew.contiguous(), done.float().contiguous(), val.contiguous(), last_val.contiguous(), gamma, lam)
+    assert torch.allclose((adv - adv0)[trunc], gamma * term_v[trunc], rtol=1e-4, atol=1e-3)
+    # VecMonitor sums use the raw rewards
+    ep = torch.zeros(N, device=dev); tot = 0.0
+    for t in range(T):
+        ep += rew[t]; tot += float((ep * done[t].float()).sum()); ep *= 1.0 - done[t].float()
+    assert abs(float(fin[0]) - tot) < 1e-2 * max(1.0, abs(tot)) and float(fin[3]) == float(done.sum())
+
+
+def test_target_kl_early_stop_runs_on_the_device():
+    """SB3's rule: approx_kl of a minibatch > 1.5 target_kl -> that optimiser step is not taken and training of this
+    rollout stops.  Here the update kernel takes the decision; later launches are no-ops until control(clear=True)."""
+    L, rows, B = 17, 8192, 2048
+    pol, ref, up, obs, act, old_lp, adv, ret = _setup(L, rows, seed=33)
+    perm = torch.randperm(rows, device=obs.device).to(torch.int32)
+    up.control(None, clear=True)
+    up.begin_epoch(adv, perm, B)
+    for k in range(2):
+        up.minibatch(obs, act, old_lp, adv, ret, perm[k * B:(k + 1) * B], lr=3e-4)
+    assert up.status() == (False, 2, 0, 0)
+    theta2 = up.theta.clone()
+    # the synthetic old log-probs are 0.15-sigma off: approx KL ~ 1e-2 per sample >> 1.5e-6
+    with torch.no_grad():
+        lp, _ = pol.log_prob_entropy(obs, act)
+        kl = float(((lp - old_lp).exp() - 1 - (lp - old_lp)).mean())
+    assert kl > 1e-3
+    up.control(1e-6, clear=True)
+    up.stats.zero_()
+    up.minibatch(obs, act, old_lp, adv, ret, perm[2 * B:3 * B], lr=3e-4)      # exceeds the limit: no step, stop flag set
+    up.minibatch(obs, act, old_lp, adv, ret, perm[3 * B:4 * B], lr=3e-4)      # skipped entirely
+    assert up.status() == (True, 0, 0, 0)
+    assert torch.equal(up.theta, theta2)
+    assert abs(float(up.stats[2]) / B - kl) < 0.3 * kl                         # the breaking minibatch's KL was recorded (once)
+    up.control(10.0 * kl, clear=True)                                           # generous limit: training resumes
+    up.minibatch(obs, act, old_lp, adv, ret, perm[2 * B:3 * B], lr=3e-4)
+    assert up.status() == (False, 1, 0, 0) and not torch.equal(up.theta, theta2)
+
+
+def test_epoch_table_equals_per_minibatch_statistics_and_nonfinite_guard():
+    L, rows, B = 17, 8192, 2048
+    pol_a, _, up_a, obs, act, old_lp, adv, ret = _setup(L, rows, seed=41)
+    pol_b, _, up_b, *_ = _setup(L, rows, seed=41)
+    perm = torch.randperm(rows, device=obs.device).to(torch.int32)
+    up_a.begin_epoch(adv, perm, B)                      # one launch for the four minibatches' advantage sums
+    for k in range(4):
+        up_a.minibatch(obs, act, old_lp, adv, ret, perm[k * B:(k + 1) * B], lr=3e-4)
+        up_b.minibatch(obs, act, old_lp, adv, ret, perm[k * B:(k + 1) * B].clone(), lr=3e-4)   # not announced: own launch
+    assert torch.allclose(up_a.theta, up_b.theta, rtol=0, atol=2e-7)
+    # image re-pack inside the update kernel == the gather pack of the same parameters
+    v_scatter = up_a.forward(1, obs[:2048].contiguous()).clone()
+    up_a.pack()
+    assert torch.equal(v_scatter, up_a.forward(1, obs[:2048].contiguous()))
+    m_scatter = up_b.forward(0, obs[:2048].contiguous()).clone()
+    up_b.pack()
+    assert torch.equal(m_scatter, up_b.forward(0, obs[:2048].contiguous()))
+    # a non-finite gradient leaves parameters and Adam moments untouched and is counted
+    before, m_before = up_a.theta.clone(), up_a.m.clone()
+    bad_adv = adv.clone(); bad_adv[perm[0].long()] = float("nan")
+    up_a.control(None, clear=True)
+    up_a.minibatch(obs, act, old_lp, bad_adv, ret, perm[:B], lr=3e-4)
+    assert up_a.status() == (False, 0, 1, 0)
+    assert torch.equal(up_a.theta, before) and torch.equal(up_a.m, m_before)
+    up_a.minibatch(obs, act, old_lp, adv, ret, perm[:B], lr=3e-4)               # and training continues afterwards
+    assert up_a.status()[1] == 1 and torch.isfinite(up_a.theta).all()

@@ -1,0 +1,223 @@
+"""GPU: round-2 parity hardening -- full-size lock-step through auto-resets, the residual
+MLP / body velocity pinned DIRECTLY against the reference's fixture rows, true terminal observations, the 8-shard
+partition of BASELINE config 4 on one GPU, and the complete config-5 training loop at 65 536 envs."""
+import numpy as np
+import pytest
+import torch
+
+import parity as P
+
+pytestmark = pytest.mark.gpu
+
+E2E, INDI = 0, 1
+
+
+@pytest.fixture(scope="module")
+def PA():
+    assert torch.cuda.is_available()
+    from product_adapter import ProductAdapter
+
+    return ProductAdapter
+
+
+@pytest.fixture(scope="module")
+def OA():
+    from oracle_adapter import OracleAdapter
+
+    return OracleAdapter
+
+
+def _pair(PA, OA, variant, n, tname, ga, blob, seed=11, env_id_base=0):
+    trk = P.tracks()[tname]
+    kw = dict(gates_ahead=ga, residual=blob if variant == E2E else None,
+              dist_ranges=P.TRAIN_DIST_RANGES if variant == E2E else None, seed=seed, env_id_base=env_id_base)
+    return PA(variant, n, trk, **kw), OA(variant, n, trk, **kw)
+
+
+def test_residual_and_body_velocity_match_reference_rows_directly(PA, residual_blob):
+    """F1 (reference: get_body_velocity R:155, thrust_moment_model_world_states R:254-262 on 257 states): the device
+    functions the step kernels inline, read back through qr_probe_residual -- no finite differences."""
+    d = P.load("f1_residual")
+    s = d["states"]
+    n = s.shape[0]
+    a = PA(E2E, n, P.tracks()["zigzag"], gates_ahead=0, residual=residual_blob)
+    a.set_state(s, np.zeros((n, 6), np.float32), np.zeros(n, np.int32), np.zeros(n, np.int32))
+    out = a.env.probe_residual().cpu().numpy().astype(np.float64)
+    ref = np.concatenate([d["vb"], d["thrust"].reshape(n, 1), d["moment"]], axis=1).astype(np.float64)
+    err = np.abs(out - ref) / np.maximum(1.0, np.abs(ref))
+    assert err[:, :3].max() < 1e-5, err[:, :3].max()        # body velocity
+    assert err[:, 3].max() < 1e-5, err[:, 3].max()          # residual thrust (values up to ~40)
+    assert err[:, 4:].max() < 1e-5, err[:, 4:].max()        # residual moments
+    # the notebook's own printed known answer (R:184+), state = [0..15]
+    assert abs(out[0, 3] - 36.098232) < 2e-4
+    np.testing.assert_allclose(out[0, 4:], [0.2847767, -0.22512697, -0.05896095], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("variant", [E2E, INDI])
+def test_full_size_lockstep_through_resets_vs_oracle(PA, OA, variant, residual_blob):
+    """BASELINE size N = 65 536, 64 teacher-forced steps through auto-resets (max_steps = 40 truncates every env once;
+    random actions crash many more): dones / targets / step counts exact, freshly reset lanes bit-exact, integrated lanes
+    within the one-step tolerance."""
+    n, K = 65536, 64
+    g, o = _pair(PA, OA, variant, n, "zigzag" if variant == E2E else "square", 1, residual_blob, seed=21)
+    o.env.set_threads(16)
+    g.env.max_steps = 40
+    o.env.set_limits(40, 0.01)
+    g.reset(); o.reset()
+    rng = np.random.default_rng(31)
+    tot_done, worst_state, worst_obs = 0, 0.0, 0.0
+    for k in range(K):
+        wo, do, to, so = o.get_state()
+        g.set_state(wo, do if variant == E2E else None, to, so)
+        g.env.set_state_tensors(episode=o.env.episode.astype(np.int64))
+        a = rng.uniform(-1, 1, size=(n, 4)).astype(np.float32)
+        if k % 2:
+            a = (0.124 + 0.3 * a).astype(np.float32) if variant == E2E else (0.2 * a + [0, 0, 0, 0.22]).astype(np.float32)
+        og, rg, dng, trg = g.step(a)
+        oo, ro, dno, tro = o.step(a)
+        mism = dng != dno
+        assert mism.sum() <= 4, f"step {k}: {mism.sum()} done mismatches"   # knife-edge threshold cases only
+        ok = ~mism
+        wg, dg, tg, sg = g.get_state()
+        wo2, do2, to2, so2 = o.get_state()
+        np.testing.assert_array_equal(tg[ok], to2[ok])
+        np.testing.assert_array_equal(sg[ok], so2[ok])
+        np.testing.assert_array_equal(trg, tro)
+        assert np.abs(rg[ok] - ro[ok]).max() < P.TOL_STEP_REWARD
+        done, live = dno & ok, ~dno & ok
+        np.testing.assert_array_equal(wg[done], wo2[done])                  # freshly reset lanes: bit exact
+        if variant == E2E:
+            np.testing.assert_array_equal(dg[done], do2[done])
+        worst_state = max(worst_state, float(P.rel_err(wg[live], wo2[live]).max()))
+        worst_obs = max(worst_obs, float(P.obs_err(og[ok], oo[ok], wo2[ok]).max()))
+        tot_done += int(dno.sum())
+    assert worst_state < P.TOL_STEP_STATE and worst_obs < P.TOL_STEP_OBS, (worst_state, worst_obs)
+    assert tot_done >= n
+
+
+@pytest.mark.parametrize("variant", [E2E, INDI])
+def test_terminal_observation_vs_oracle_and_across_kernels(PA, OA, variant, residual_blob):
+    """qr_set_terminal_obs: every env that finishes writes the observation of its FINAL state (before the auto-reset).
+    (a) per-step kernel vs the oracle twin; (b) the fused rollout kernel and the captured per-step launches write the same
+    rows [k][env] bit for bit; rows of unfinished envs stay untouched."""
+    n, K = 4096, 48
+    g, o = _pair(PA, OA, variant, n, "square", 2, residual_blob, seed=5)
+    L = g.env.state_len
+    g.env.max_steps = 30
+    o.env.set_limits(30, 0.01)
+    g.reset(); o.reset()
+    tbuf = torch.full((n, L), -7.0, device=g.env.device)
+    g.env.set_terminal_obs_buffer(tbuf)
+    obuf = np.full((n, L), -7.0, np.float32)
+    o.env.set_terminal_obs(obuf)
+    rng = np.random.default_rng(77)
+    seen = 0
+    for k in range(K):
+        wo, do, to, so = o.get_state()
+        g.set_state(wo, do if variant == E2E else None, to, so)
+        g.env.set_state_tensors(episode=o.env.episode.astype(np.int64))
+        tbuf.fill_(-7.0); obuf[:] = -7.0
+        a = rng.uniform(-1, 1, size=(n, 4)).astype(np.float32)
+        _, _, dng, _ = g.step(a)
+        _, _, dno, _ = o.step(a)
+        t = tbuf.cpu().numpy()
+        both = dng & dno
+        assert (t[~dng] == -7.0).all() and (obuf[~dno] == -7.0).all()       # untouched rows
+        if both.any():
+            wfin = None
+            err = P.obs_err(t[both], obuf[both])
+            assert err.max() < P.TOL_STEP_OBS, err.max()
+            seen += int(both.sum())
+    assert seen >= n   # every env was truncated at least once
+    g.env.set_terminal_obs_buffer(None)
+    # (b) K-step kernels: same rows from the fused kernel and from the per-step launches
+    from optimal_quad_control_rl_amd import Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES
+
+    cls = Quadcopter3DGates if variant == E2E else Quadcopter3DGatesINDI
+    outs = []
+    acts = torch.rand((K, n, 4), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 2 - 1
+    for mode in ("fused", "launches"):
+        e = cls(n, *P.tracks()["square"], gates_ahead=2, seed=9, infos_mode="none")
+        if variant == E2E:
+            e.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+        e.max_steps = 30
+        e.reset_device()
+        tb = torch.full((K, n, L), -7.0, device=e.device)
+        e.set_terminal_obs_buffer(tb)
+        if mode == "fused":
+            res = e.rollout_device(acts)
+        else:
+            res = (torch.empty((K, n, L), device=e.device), torch.empty((K, n), device=e.device),
+                   torch.empty((K, n), dtype=torch.uint8, device=e.device), torch.empty((K, n), dtype=torch.uint8, device=e.device))
+            e.step_sequence_device(acts, res)
+        torch.cuda.synchronize()
+        outs.append((tb.clone(), res[2].clone()))
+        e.close()
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
+    done = outs[0][1].bool()
+    assert done.sum() >= n and (outs[0][0][~done] == -7.0).all() and (outs[0][0][done] != -7.0).any(dim=-1).all()
+
+
+def test_eight_shards_of_32768_equal_one_262144_env_handle():
+    """BASELINE config 4 (262 144 envs = 8 x 32 768) on ONE GPU: eight handles with env_id_base = r * 32 768, stepped one
+    after the other, produce bit for bit the rows [r * 32 768, (r + 1) * 32 768) of a single 262 144-env handle -- reset,
+    20 fused steps with auto-resets, final state."""
+    from optimal_quad_control_rl_amd import Quadcopter3DGates, TRAIN_DISTURBANCE_RANGES, zigzag_track
+
+    n, R, K = 32768, 8, 20
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(123)
+    acts = torch.rand((K, n * R, 4), device=dev, generator=gen) * 2 - 1
+
+    def make(num, base):
+        e = Quadcopter3DGates(num, *zigzag_track(), gates_ahead=1, seed=17, env_id_base=base, infos_mode="none")
+        e.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+        e.max_steps = 12   # truncations inside the window on top of the crashes
+        return e
+
+    big = make(n * R, 0)
+    obs0 = big.reset_device().clone()
+    ob, rb, db, tb = big.rollout_device(acts)
+    wb = big.get_state_tensors()[0]
+    assert int(db.sum()) > n * R   # more than one reset per env on average
+    for r in range(R):
+        sl = slice(r * n, (r + 1) * n)
+        e = make(n, r * n)
+        assert torch.equal(e.reset_device(), obs0[sl])
+        o, rw, d, t = e.rollout_device(acts[:, sl].contiguous())
+        assert torch.equal(o, ob[:, sl]) and torch.equal(rw, rb[:, sl]) and torch.equal(d, db[:, sl]) and torch.equal(t, tb[:, sl])
+        assert torch.equal(e.get_state_tensors()[0], wb[sl])
+        e.close()
+    big.close()
+
+
+@pytest.mark.parametrize("variant", ["indi", "e2e"])
+def test_config5_training_loop_at_full_size(variant):
+    """BASELINE config 5 as a whole loop at 65 536 envs: three iterations of closed-loop collection in one kernel
+    (qr_rollout_policy) + value forward + GAE with the time-limit bootstrap + 2 epochs x 32 matrix-core minibatch updates,
+    the reference's gamma = 0.999 (R:784-795)."""
+    from optimal_quad_control_rl_amd import (Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES, square_track)
+    from optimal_quad_control_rl_amd.ppo import PPO
+
+    n, T = 65536, 32
+    if variant == "indi":
+        env = Quadcopter3DGatesINDI(n, *square_track(), gates_ahead=1, seed=1, infos_mode="none")
+    else:
+        env = Quadcopter3DGates(n, *square_track(), gates_ahead=1, seed=1, infos_mode="none")
+        env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+    env.max_steps = 48    # time-limit truncations inside the three rollouts
+    ppo = PPO(env, n_steps=T, batch_size=n * T // 32, n_epochs=2, gamma=0.999, fused_collect=True, native_update=True, seed=0,
+              target_kl=None)
+    theta0 = ppo._updater.theta.clone()
+    for it in range(3):
+        ppo.collect()
+        if it >= 1:
+            assert ppo.stats["truncations"] > 0 and float(ppo.buf_term_val.abs().sum()) > 0
+            tr = ppo._trunc_u8.bool()
+            assert (ppo.buf_term_val[~tr] == 0).all()
+        ppo.train()
+        assert ppo.stats["updates"] == 64 * (it + 1) and not ppo.stats["early_stop"] and ppo.stats["skipped_nonfinite"] == 0
+    assert ppo.num_timesteps == 3 * n * T
+    assert torch.isfinite(ppo._updater.theta).all() and not torch.equal(ppo._updater.theta, theta0)
+    assert np.isfinite(ppo.stats["loss"]) and ppo.stats["approx_kl"] >= 0 and ppo.stats["episodes"] > 0
+    env.close()
