@@ -341,12 +341,20 @@ __device__ __forceinline__ float relu_dot16(const float* w, const f32x16& acc) {
 }
 
 // max(x, 0) as ONE v_max_f32.  fmaxf() costs two: LLVM first canonicalises an operand it cannot prove quiet
-// (v_max_f32 x, x, x) -- matrix-core results never are signalling NaNs, and v_max_f32 itself returns the non-NaN
-// operand, so relu0(NaN) = 0 = fmaxf(NaN, 0): identical results, 128 fewer VALU instructions per env step.
-__device__ __forceinline__ float relu0(float x) {
+// (v_max_f32 x, x, x) -- matrix-core results never are signalling NaNs, and v_max_f32 itself returns the non-NaN operand,
+// so relu0(NaN) = 0 = fmaxf(NaN, 0): identical results, 128 fewer VALU instructions per env step.  Inline asm also keeps
+// the operation where the source puts it (between the MFMAs of the next accumulator, see residual_mlp).
+// MFMA -> VALU read hazards: the wait states after a matrix instruction are inserted by the compiler's hazard recogniser,
+// which does not look inside inline asm.  `ready` is the result of acc_ready(): a compiler-visible VALU read of the same
+// accumulator (so the wait states are inserted before IT), and passing it in orders every relu0 of that accumulator behind it.
+__device__ __forceinline__ float relu0(float x, uint32_t ready) {
     float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x), "s"(ready));
     return r;
+}
+template <class Acc>
+__device__ __forceinline__ uint32_t acc_ready(const Acc& acc) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(acc[0]));
 }
 
 // dot(w[0..15], relu(acc[0..15])) over this lane's 16 hidden rows as four independent chains, cut into 4-row chunks
@@ -355,11 +363,11 @@ struct DotAcc {
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     __device__ __forceinline__ float sum() const { return (s0 + s1) + (s2 + s3); }
 };
-__device__ __forceinline__ void dot_chunk(const float* w, const f32x16& acc, int r, DotAcc& d) {
-    d.s0 = fmaf(w[r + 0], relu0(acc[r + 0]), d.s0);
-    d.s1 = fmaf(w[r + 1], relu0(acc[r + 1]), d.s1);
-    d.s2 = fmaf(w[r + 2], relu0(acc[r + 2]), d.s2);
-    d.s3 = fmaf(w[r + 3], relu0(acc[r + 3]), d.s3);
+__device__ __forceinline__ void dot_chunk(const float* w, const f32x16& acc, int r, DotAcc& d, uint32_t ready) {
+    d.s0 = fmaf(w[r + 0], relu0(acc[r + 0], ready), d.s0);
+    d.s1 = fmaf(w[r + 1], relu0(acc[r + 1], ready), d.s1);
+    d.s2 = fmaf(w[r + 2], relu0(acc[r + 2], ready), d.s2);
+    d.s3 = fmaf(w[r + 3], relu0(acc[r + 3], ready), d.s3);
 }
 
 __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const float x[10], float& thrust,
@@ -387,32 +395,33 @@ __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const f
 #define QR_PIN() __builtin_amdgcn_sched_barrier(0)
     QR_MFMA(hT0, m.a[0], b01[0]); QR_MFMA(hT0, m.a[1], b23[0]); QR_MFMA(hT0, m.a[2], b45[0]); QR_MFMA(hT0, m.a[3], b6one[0]);
     QR_PIN();
-    QR_MFMA(hM0, m.a[4], b01[0]); QR_PIN();
-    QR_MFMA(hM0, m.a[5], b23[0]); dot_chunk(m.w2 + 0, hT0, 0, dT0); QR_PIN();
-    QR_MFMA(hM0, m.a[6], b45[0]); dot_chunk(m.w2 + 0, hT0, 4, dT0); QR_PIN();
-    QR_MFMA(hM0, m.a[7], b67[0]); dot_chunk(m.w2 + 0, hT0, 8, dT0); QR_PIN();
-    QR_MFMA(hM0, m.a[8], b89[0]); dot_chunk(m.w2 + 0, hT0, 12, dT0); QR_PIN();
+    QR_MFMA(hM0, m.a[4], b01[0]); const uint32_t rT0 = acc_ready(hT0); QR_PIN();
+    QR_MFMA(hM0, m.a[5], b23[0]); dot_chunk(m.w2 + 0, hT0, 0, dT0, rT0); QR_PIN();
+    QR_MFMA(hM0, m.a[6], b45[0]); dot_chunk(m.w2 + 0, hT0, 4, dT0, rT0); QR_PIN();
+    QR_MFMA(hM0, m.a[7], b67[0]); dot_chunk(m.w2 + 0, hT0, 8, dT0, rT0); QR_PIN();
+    QR_MFMA(hM0, m.a[8], b89[0]); dot_chunk(m.w2 + 0, hT0, 12, dT0, rT0); QR_PIN();
     QR_MFMA(hM0, m.a[9], bias_sel); QR_PIN();
-    QR_MFMA(hT1, m.a[0], b01[1]); QR_PIN();
+    QR_MFMA(hT1, m.a[0], b01[1]); const uint32_t rM0 = acc_ready(hM0); QR_PIN();
 #pragma unroll
     for (int g = 0; g < 3; ++g) {  // MFMA g + 1 of thrust tile 1 hosts moment-0 output g (4 chunks = 32 VALU)
         if (g == 0) QR_MFMA(hT1, m.a[1], b23[1]);
         if (g == 1) QR_MFMA(hT1, m.a[2], b45[1]);
         if (g == 2) QR_MFMA(hT1, m.a[3], b6one[1]);
 #pragma unroll
-        for (int r = 0; r < 16; r += 4) dot_chunk(m.w2 + 16 + 16 * g, hM0, r, dM0[g]);
+        for (int r = 0; r < 16; r += 4) dot_chunk(m.w2 + 16 + 16 * g, hM0, r, dM0[g], rM0);
         QR_PIN();
     }
-    QR_MFMA(hM1, m.a[4], b01[1]); QR_PIN();
-    QR_MFMA(hM1, m.a[5], b23[1]); dot_chunk(m.w2 + 0, hT1, 0, dT1); QR_PIN();
-    QR_MFMA(hM1, m.a[6], b45[1]); dot_chunk(m.w2 + 0, hT1, 4, dT1); QR_PIN();
-    QR_MFMA(hM1, m.a[7], b67[1]); dot_chunk(m.w2 + 0, hT1, 8, dT1); QR_PIN();
-    QR_MFMA(hM1, m.a[8], b89[1]); dot_chunk(m.w2 + 0, hT1, 12, dT1); QR_PIN();
+    QR_MFMA(hM1, m.a[4], b01[1]); const uint32_t rT1 = acc_ready(hT1); QR_PIN();
+    QR_MFMA(hM1, m.a[5], b23[1]); dot_chunk(m.w2 + 0, hT1, 0, dT1, rT1); QR_PIN();
+    QR_MFMA(hM1, m.a[6], b45[1]); dot_chunk(m.w2 + 0, hT1, 4, dT1, rT1); QR_PIN();
+    QR_MFMA(hM1, m.a[7], b67[1]); dot_chunk(m.w2 + 0, hT1, 8, dT1, rT1); QR_PIN();
+    QR_MFMA(hM1, m.a[8], b89[1]); dot_chunk(m.w2 + 0, hT1, 12, dT1, rT1); QR_PIN();
     QR_MFMA(hM1, m.a[9], bias_sel); QR_PIN();
+    const uint32_t rM1 = acc_ready(hM1);
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; r += 4) dot_chunk(m.w2 + 16 + 16 * g, hM1, r, dM1[g]);
+        for (int r = 0; r < 16; r += 4) dot_chunk(m.w2 + 16 + 16 * g, hM1, r, dM1[g], rM1);
 #undef QR_MFMA
 #undef QR_PIN
     float part[2][4];

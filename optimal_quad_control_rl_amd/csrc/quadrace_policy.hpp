@@ -73,49 +73,63 @@ __device__ __forceinline__ half8 sat_pack(const float* v) {
     return __builtin_elementwise_min(__builtin_elementwise_max(b, bot), top);
 }
 
+// relu + saturation + f16 pack of two accumulator values (v_cvt_pk_f16_f32, v_pk_max_f16 against 0, v_pk_min_f16 against
+// 65504 -- the instructions relu_pack() compiles to).  The max / min pair is inline asm so that the compiler keeps these
+// units where the source puts them: between the MFMAs of the next output tile (see policy_layer).
+typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t relu_pack2(float lo, float hi) {
+    // The conversion stays compiler-visible: it READS matrix-core results, and the wait states between an MFMA and a
+    // VALU read of its destination are inserted by the compiler's hazard recogniser, which does not look inside inline asm.
+    typedef _Float16 half2p __attribute__((ext_vector_type(2)));
+    const half2p c = {(_Float16)lo, (_Float16)hi};
+    uint32_t r = __builtin_bit_cast(uint32_t, c);
+    asm("v_pk_max_f16 %0, %0, 0\n\tv_pk_min_f16 %0, %0, %1" : "+v"(r) : "v"(0x7BFF7BFFu));   // 65504 in both halves
+    return r;
+}
+
 // One layer with KS K-steps per 32-row output tile: in[et][KS] -> out[et][8].  W = this layer's A operands in LDS.
-// Software-pipelined by output tile: the 2*KS MFMAs of tile t are issued interleaved with the ReLU/f16 pack of tile
-// t-1 (the wave issues in order, so VALU work only overlaps the matrix pipe when it sits BETWEEN the MFMAs in program
-// order; sched_group_barrier pins that interleave: 2 MFMA, then up to 8 VALU, repeat).
+//
+// A wave issues in order and an MFMA issued while the matrix core is busy stalls the wave, so everything else must sit
+// BETWEEN the MFMAs in program order to overlap with them.  The schedule is therefore written out and pinned with
+// sched_barrier (left to itself the scheduler emitted "ds_read, s_waitcnt lgkmcnt(0), MFMA, MFMA" per K-step -- the LDS
+// latency exposed 32 times per layer -- and one lump of 48 pack instructions per tile behind the MFMAs):
+//   K-step g of output tile t:   ds_read of tile t+1's operand g   (a whole tile ahead of its use)
+//                                2 MFMAs (env tiles 0 and 1) on tile t's operand g
+//                                1/KS of the ReLU + f16 pack of tile t-1 (its accumulators finished a tile ago)
 template <int KS>
 __device__ __forceinline__ void policy_layer(const half8* __restrict__ W, int lane, const half8 (&in)[2][KS],
                                              half8 (&out)[2][8]) {
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     f32x16p acc[2][2];  // [tile parity][env tile]
     half8 a[2][KS];     // [tile parity][K-step]: A operands, fetched one tile ahead of their MFMAs
+    u32x4p o32[2][8];   // the packed outputs, dword by dword
 #pragma unroll
     for (int s = 0; s < KS; ++s) a[0][s] = W[s * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t <= 4; ++t) {
-        if (t < 3) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) a[(t + 1) & 1][s] = W[((t + 1) * KS + s) * 64 + lane];
-        }
-        if (t < 4) {
-            acc[t & 1][0] = zero;
-            acc[t & 1][1] = zero;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                acc[t & 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t & 1][s], in[0][s], acc[t & 1][0], 0, 0, 0);
-                acc[t & 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t & 1][s], in[1][s], acc[t & 1][1], 0, 0, 0);
+        for (int g = 0; g < KS; ++g) {
+            if (t < 3) a[(t + 1) & 1][g] = W[((t + 1) * KS + g) * 64 + lane];
+            if (t < 4) {
+                acc[t & 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t & 1][g], in[0][g], g == 0 ? zero : acc[t & 1][0], 0, 0, 0);
+                acc[t & 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t & 1][g], in[1][g], g == 0 ? zero : acc[t & 1][1], 0, 0, 0);
             }
-        }
-        if (t > 0) {
-            const int p = (t - 1) & 1;
-            out[0][2 * (t - 1)] = relu_pack(acc[p][0], 0);
-            out[0][2 * (t - 1) + 1] = relu_pack(acc[p][0], 1);
-            out[1][2 * (t - 1)] = relu_pack(acc[p][1], 0);
-            out[1][2 * (t - 1) + 1] = relu_pack(acc[p][1], 1);
-        }
-        if (t < 4) {
+            if (t > 0) {  // dwords [16 g / KS, 16 (g + 1) / KS) of the previous tile: d = 8 et + 4 s + dd
+                const int p = (t - 1) & 1;
 #pragma unroll
-            for (int g = 0; g < KS; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                    // 2 MFMA
-                if (t < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // 1 LDS read of the next tile's A
-                if (t > 0) __builtin_amdgcn_sched_group_barrier(0x002, 64 / KS, 0);   // a share of the previous tile's pack
+                for (int d = (16 * g) / KS; d < (16 * (g + 1)) / KS; ++d) {
+                    const int et = d >> 3, sh = (d >> 2) & 1, dd = d & 3;
+                    o32[et][2 * (t - 1) + sh][dd] = relu_pack2(acc[p][et][8 * sh + 2 * dd], acc[p][et][8 * sh + 2 * dd + 1]);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[et][k] = __builtin_bit_cast(half8, o32[et][k]);
 }
 
 // Full policy forward for the wave's 64 envs.  o[L] = this lane's observation (lane = env); mean[4] = action means

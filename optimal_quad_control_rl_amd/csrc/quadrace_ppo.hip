@@ -162,10 +162,12 @@ __global__ void __launch_bounds__(1024) ppo_adv_stats_kernel(const float* __rest
 
 // Device-resident control block of one qr_ppo handle
 struct PpoCtrl {
-    double sumsq[2];              // squared gradient norm of the current update, double-buffered by barrier generation parity
-    unsigned long long arrive;    // grid barrier of ppo_apply_kernel: arrivals (monotonic)
-    unsigned long long depart;    //                                   departures (monotonic)
-    unsigned long long gen;       // completed barrier generations (= apply launches that were not skipped)
+    double sumsq[2][512];         // per-workgroup squared-gradient sums of the current update (one slot per workgroup: no
+                                  // same-address f64 atomics), double-buffered by barrier generation parity
+    unsigned int flags[512];      // grid barrier of ppo_apply_kernel: flags[b] = generation workgroup b has arrived in (plain
+                                  // stores: same-address read-modify-write atomics from 247 workgroups serialise at ~100 ns each)
+    unsigned int go;              // generation released by workgroup 0 once every flag shows it
+    unsigned int gen;             // completed barrier generations (= apply launches that were not skipped)
     int stop;                     // sticky: a minibatch exceeded 1.5 x target_kl (SB3's early stop); cleared by qr_ppo_control
     int applied;                  // optimiser steps taken since the last qr_ppo_control
     int skipped_nonfinite;        // updates dropped because the gradient norm was not finite
@@ -206,6 +208,13 @@ struct PpoBatch {
 #else
 #define PPO_TICK(a, slot) do { } while (0)
 #endif
+
+// The transposed operands are written once and read once, by phase B: streaming ("nt") stores keep ~54 MB of dirty lines out
+// of the end-of-kernel L2 write-back (same reasoning as the env kernels' outputs, tools/ubench/launch_floor.hip).
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_store_h8(half8* p, const half8 v) {
+    __builtin_nontemporal_store(__builtin_bit_cast(f32x4p, v), reinterpret_cast<f32x4p*>(p));
+}
 
 __device__ __forceinline__ half8 plain_pack(const f32x16p& acc, int s) {
     half8 b;
@@ -297,8 +306,8 @@ __device__ __forceinline__ void tstore_hidden(const half8 (&X)[8], half8* __rest
         f32x16p acc = zero;
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut], id[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut + 1], id[1], acc, 0, 0, 0);
-        dst[ut * slot_stride + (2 * st) * 64 + lane] = plain_pack(acc, 0);
-        dst[ut * slot_stride + (2 * st + 1) * 64 + lane] = plain_pack(acc, 1);
+        stream_store_h8(dst + ut * slot_stride + (2 * st) * 64 + lane, plain_pack(acc, 0));
+        stream_store_h8(dst + ut * slot_stride + (2 * st + 1) * 64 + lane, plain_pack(acc, 1));
     }
 }
 
@@ -326,6 +335,37 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
     const int net = blockIdx.y;
     if (*a.stop) return;  // uniform over the grid
     PPO_TICK(a, 0);
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    // wave-uniform indices in scalar registers: the 25+ scratch-slot addresses become scalar bases + one lane offset
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x * kGroupsPerBlockA + (wave >> 1);   // sample group of this wave
+    const int et = wave & 1;                       // its 32-sample tile: samples 32 et + c (both lane halves: k-slots by h)
+    const bool live = g < a.G;                     // whole wave
+    // Every global LOAD of this wave is issued here, BEFORE the operand images are staged: the row index, the gathered
+    // observation row and the per-sample scalars are two dependent HBM round trips that now fly under the ~7 k cycles of
+    // image staging instead of after them; and loads and stores share one in-order counter, so a load issued after the
+    // transposed-operand stores would wait for all of them to drain.
+    const int b = a.idx[(live ? g : a.G - 1) * 64 + 32 * et + c];
+    float xin[KS1][8];
+    {
+        const float* row = a.obs + (size_t)b * L;
+#pragma unroll
+        for (int s = 0; s < KS1; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * s + 8 * h + j;
+                xin[s][j] = row[k < L ? k : L - 1];
+            }
+    }
+    const float4 act_v = net == 0 ? reinterpret_cast<const float4*>(a.act)[b] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float old_logp_in = a.old_logp[b], adv_in = a.adv[b], ret_in = a.ret[b];
+    const double acc_s1 = a.acc[0], acc_s2 = a.acc[1];
+    float log_std_v[4];
+    {
+        const float* log_std = a.theta + net_off(L, 4).total + net_off(L, 1).total;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) log_std_v[k] = log_std[k];
+    }
     {   // operand images -> LDS, 8 independent 16-byte loads in flight per thread (one load per round trip took 22 k cycles)
         const float4* src = reinterpret_cast<const float4*>(a.images + (size_t)net * D::kImage);
         float4* dst = reinterpret_cast<float4*>(W);
@@ -345,55 +385,35 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
         }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    // wave-uniform indices in scalar registers: the 25+ scratch-slot addresses become scalar bases + one lane offset
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = blockIdx.x * kGroupsPerBlockA + (wave >> 1);   // sample group of this wave
-    const int et = wave & 1;                       // its 32-sample tile: samples 32 et + c (both lane halves: k-slots by h)
-    if (g >= a.G) return;  // whole wave
+    if (!live) return;  // whole wave
     PPO_TICK(a, 1);
-    const int b = a.idx[g * 64 + 32 * et + c];
-    // every global LOAD of this wave is issued here: loads and stores share one in-order counter, so a load issued after the
-    // transposed-operand stores would wait for all of them to drain.  The per-sample scalars are parked in the LDS left
-    // over beside the operand images until the loss needs them (LDS traffic is counted separately).
+    // the per-sample scalars are parked in the LDS left over beside the operand images until the loss needs them
     float* stash = reinterpret_cast<float*>(W + D::kImage) + wave * 32 + c;
     if (h == 0) {
-        const float4 act_v = net == 0 ? reinterpret_cast<const float4*>(a.act)[b] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         stash[0 * kStashRows] = act_v.x;
         stash[1 * kStashRows] = act_v.y;
         stash[2 * kStashRows] = act_v.z;
         stash[3 * kStashRows] = act_v.w;
-        stash[4 * kStashRows] = a.old_logp[b];
-        stash[5 * kStashRows] = a.adv[b];
-        stash[6 * kStashRows] = a.ret[b];
+        stash[4 * kStashRows] = old_logp_in;
+        stash[5 * kStashRows] = adv_in;
+        stash[6 * kStashRows] = ret_in;
     }
     float wsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // per-wave sums: d log_std[4] / B, loss statistics
-    const double acc_s1 = a.acc[0], acc_s2 = a.acc[1];
-    float log_std_v[4];
-    {
-        const float* log_std = a.theta + net_off(L, 4).total + net_off(L, 1).total;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) log_std_v[k] = log_std[k];
-    }
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const size_t slot_stride = (size_t)a.G * 256;
     half8* tb = a.tbuf + ((size_t)net * D::kSlots * a.G + g) * 256;  // slot 0, this group, kk = 0 (scalar); + lane at each use
 
     // ---- layer-1 operand: lane (c, h) holds inputs k = 16 s + 8 h + j of sample c; input L = constant 1
     half8 in[KS1];
-    {
-        const float* row = a.obs + (size_t)b * L;
 #pragma unroll
-        for (int s = 0; s < KS1; ++s) {
-            float v[8];
+    for (int s = 0; s < KS1; ++s) {
+        float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 16 * s + 8 * h + j;
-                const float x = row[k < L ? k : L - 1];
-                v[j] = k < L ? x : (k == L ? 1.0f : 0.0f);
-            }
-            in[s] = sat_pack(v);  // observations can be large or NaN: keep f16 finite
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * s + 8 * h + j;
+            v[j] = k < L ? xin[s][j] : (k == L ? 1.0f : 0.0f);
         }
+        in[s] = sat_pack(v);  // observations can be large or NaN: keep f16 finite
     }
     const bool valid = h == 0;  // lanes 0..31 carry the tile's per-sample scalars (mean / value / loss gradients)
     {
@@ -409,8 +429,8 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
                 for (int j = 0; j < 8; ++j) id[j] = (16 * s + 8 * h + j == 32 * ut + c) ? (_Float16)1.0f : (_Float16)0.0f;
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(in[s], id, acc, 0, 0, 0);
             }
-            tb[(D::kSlotX0 + ut) * slot_stride + (2 * et) * 64 + lane] = plain_pack(acc, 0);
-            tb[(D::kSlotX0 + ut) * slot_stride + (2 * et + 1) * 64 + lane] = plain_pack(acc, 1);
+            stream_store_h8(tb + (D::kSlotX0 + ut) * slot_stride + (2 * et) * 64 + lane, plain_pack(acc, 0));
+            stream_store_h8(tb + (D::kSlotX0 + ut) * slot_stride + (2 * et + 1) * 64 + lane, plain_pack(acc, 1));
         }
         // ---- forward
         uint32_t m1[2], m2[2], m3[2];
@@ -493,8 +513,8 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
 #pragma unroll
             for (int j = 0; j < 8; ++j) id[j] = (8 * h + j == c) ? (_Float16)1.0f : (_Float16)0.0f;
             const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(d4, id, zero, 0, 0, 0);
-            tb[D::kSlotD4 * slot_stride + (2 * et) * 64 + lane] = plain_pack(acc, 0);
-            tb[D::kSlotD4 * slot_stride + (2 * et + 1) * 64 + lane] = plain_pack(acc, 1);
+            stream_store_h8(tb + D::kSlotD4 * slot_stride + (2 * et) * 64 + lane, plain_pack(acc, 0));
+            stream_store_h8(tb + D::kSlotD4 * slot_stride + (2 * et + 1) * 64 + lane, plain_pack(acc, 1));
         }
         // ---- backward: d3 = (W4^T d4) * relu'(z3);  d2 = (W3^T d3) * relu'(z2);  d1 = (W2^T d2) * relu'(z1)
 #pragma unroll
@@ -636,6 +656,9 @@ struct ApplyArgs {
 
 // gradient element i and, in the block(s) that own the log_std entries, the per-wave sums of phase A:
 // red[0..3] = d loss / d log_std[k] (x 1/B), red[4..7] = sum surrogate, sum squared value error, sum approx kl, clipped count
+constexpr int kApplyThreads = 256;   // 247 workgroups: the 8 MB of chunk partials are pulled by (almost) every CU
+                                     // (62 x 1024 threads took 13.5 us for this kernel, bound by 62 CUs' load issue)
+
 __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, float* red /* shared [8] */) {
     const int n = a.n;
     if (a.ext_grad) {
@@ -643,9 +666,9 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
         __syncthreads();
         return i < n ? a.ext_grad[i] : 0.0f;
     }
-    if (((int)blockIdx.x + 1) * 1024 > n - 4) {  // the block(s) holding the log_std entries (the last one, or the last two)
-        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        if (w < 8) {
+    if (((int)blockIdx.x + 1) * kApplyThreads > n - 4) {  // the block(s) holding the log_std entries (the last one or two)
+        const int lane = threadIdx.x & 63;
+        for (int w = threadIdx.x >> 6; w < 8; w += kApplyThreads / 64) {
             // statistics: 4 surrogate (policy waves, slot 4), 5 squared value error (value waves, slot 4), 6 approx kl, 7 clipped
             const int slot = w < 4 ? w : (w == 4 || w == 5 ? 4 : (w == 6 ? 5 : 6));
             const float* wv = a.wave_out + (w == 5 ? (size_t)a.Gw * 8 : 0) + slot;
@@ -658,14 +681,18 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
     }
     float g = 0.0f;
     if (i < n - 4) {  // weights and biases: sum the sample-chunk partials of phase B
-        float gs[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // independent loads in flight
-        int cix = 0;
-        for (; cix + 8 <= a.chunks; cix += 8) {
+        // all (<= 32) chunk loads are issued before the first add: one memory round trip instead of four
+        // (the partials were written by the previous kernel, so they come from HBM / the memory-side cache)
+        constexpr int kMaxChunks = 32;
+        float gs[kMaxChunks];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) gs[q] += a.partial[(size_t)(cix + q) * n + i];
-        }
-        for (; cix < a.chunks; ++cix) gs[0] += a.partial[(size_t)cix * n + i];
-        g = ((gs[0] + gs[1]) + (gs[2] + gs[3])) + ((gs[4] + gs[5]) + (gs[6] + gs[7]));
+        for (int q = 0; q < kMaxChunks; ++q) gs[q] = q < a.chunks ? a.partial[(size_t)q * n + i] : 0.0f;
+#pragma unroll
+        for (int w = kMaxChunks / 2; w >= 1; w >>= 1)
+#pragma unroll
+            for (int q = 0; q < w; ++q) gs[q] += gs[q + w];
+        g = gs[0];
+        for (int cix = kMaxChunks; cix < a.chunks; ++cix) g += a.partial[(size_t)cix * n + i];
     } else if (i < n) {  // log_std; entropy = sum(log_std) + const
         g = red[i - (n - 4)] - a.ent_coef;
     }
@@ -717,12 +744,12 @@ __device__ __forceinline__ void pack_scatter(_Float16* __restrict__ img, int O, 
 }
 
 template <int L>
-__global__ void __launch_bounds__(1024) ppo_apply_kernel(ApplyArgs a) {
+__global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
     PpoCtrl* c = a.ctrl;
     if (a.take_step && c->stop) return;  // set by an EARLIER launch: uniform over the grid (SB3: no update after the early stop)
-    const unsigned long long gen = c->gen;
+    const unsigned int gen = c->gen;
     const int n = a.n;
-    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int i = blockIdx.x * kApplyThreads + threadIdx.x;
     const bool last_block = blockIdx.x == gridDim.x - 1;
     __shared__ float red[8];
     __shared__ double norm_sq_s;
@@ -736,28 +763,53 @@ __global__ void __launch_bounds__(1024) ppo_apply_kernel(ApplyArgs a) {
         if (last_block && threadIdx.x < 4 && a.stats) a.stats[threadIdx.x] += red[4 + threadIdx.x];
         return;
     }
-    // ---- squared norm, then a grid-wide barrier: every workgroup of this launch is resident (62 x 1024 threads on 256 CUs)
+    // ---- squared norm, then a grid-wide barrier: every workgroup of this launch is resident (247 x 256 threads on 256 CUs)
     double sq = (double)g * g, unused = 0.0;
-    block_sum2_f64<1024>(sq, unused);
+    block_sum2_f64<kApplyThreads>(sq, unused);
     if (threadIdx.x == 0) {
-        unsafeAtomicAdd(&c->sumsq[gen & 1], sq);
-        if (last_block) {
+        __hip_atomic_store(&c->sumsq[gen & 1][blockIdx.x], sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last_block)
             for (int k = 0; k < 4; ++k) __hip_atomic_store(&c->mb_stats[k], red[4 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c->sumsq[(gen + 1) & 1] = 0.0;   // the other parity slot is idle during this launch: clear it for the next one
+        __hip_atomic_store(&c->flags[blockIdx.x], gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // Barrier: workgroup 0's first wave polls all arrival flags (one coalesced load per 64 workgroups) and then releases
+    // `go`; everybody else polls that one word.  RELAXED polling (an agent-scope ACQUIRE load invalidates the XCD's L2 on every
+    // iteration and slowed the workgroups still summing partials), one acquire fence after the wait.  Bounded: cannot hang.
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        bool all = false;
+        for (int spins = 0; !all && spins < (1 << 20); ++spins) {
+            bool mine = true;
+            for (int q = threadIdx.x; q < (int)gridDim.x; q += 64)
+                mine = mine && __hip_atomic_load(&c->flags[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen + 1u;
+            all = __ballot(mine) == ~0ull;
+            if (!all) __builtin_amdgcn_s_sleep(2);
         }
-        __hip_atomic_fetch_add(&c->arrive, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long target = (gen + 1) * gridDim.x;
+        if (threadIdx.x == 0) {
+            if (!all) atomicAdd(&c->barrier_timeouts, 1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            c->gen = gen + 1u;   // every workgroup has read `gen` before it arrived; visible to the next launch
+            __hip_atomic_store(&c->go, gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (threadIdx.x == 0) {
         int spins = 0;
-        while (__hip_atomic_load(&c->arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1 << 22)) {  // never observed; a bounded wait cannot hang the GPU
+        while (__hip_atomic_load(&c->go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen + 1u) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1 << 20)) {  // never observed
                 atomicAdd(&c->barrier_timeouts, 1);
                 break;
             }
         }
-        norm_sq_s = __hip_atomic_load(&c->sumsq[gen & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         kl_s = __hip_atomic_load(&c->mb_stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();
+    // every workgroup adds the per-workgroup sums in the same order: one norm, bit-identical everywhere
+    double part = 0.0;
+    for (int q = threadIdx.x; q < (int)gridDim.x; q += kApplyThreads)
+        part += __hip_atomic_load(&c->sumsq[gen & 1][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    block_sum2_f64<kApplyThreads>(part, unused);
+    if (threadIdx.x == 0) norm_sq_s = part;
     __syncthreads();
     const double norm_sq = norm_sq_s;
     const bool stop_now = a.kl_limit > 0.0f && kl_s > a.kl_limit;   // SB3: checked BEFORE the optimiser step of this minibatch
@@ -783,11 +835,6 @@ __global__ void __launch_bounds__(1024) ppo_apply_kernel(ApplyArgs a) {
         if (stop_now) c->stop = 1;
         else if (finite) c->applied += 1;
         else c->skipped_nonfinite += 1;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {  // the last workgroup to leave closes the generation (visible to the next launch)
-        const unsigned long long d = __hip_atomic_fetch_add(&c->depart, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (d + 1 == (gen + 1) * gridDim.x) c->gen = gen + 1;
     }
 }
 
@@ -836,15 +883,6 @@ __global__ void __launch_bounds__(256) ppo_gae_kernel(int T, int N, const float*
             unsafeAtomicAdd(fin + 0, f0); unsafeAtomicAdd(fin + 1, f1); unsafeAtomicAdd(fin + 2, f2); unsafeAtomicAdd(fin + 3, f3);
         }
     }
-}
-
-// squared norm of an externally supplied gradient (data-parallel training: the all-reduced gradient comes back from the caller)
-__global__ void __launch_bounds__(1024) ppo_sqnorm_kernel(const float* __restrict__ grad, int n, double* __restrict__ acc) {
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    const double g = i < n ? (double)grad[i] : 0.0;
-    double sq = g * g, unused = 0.0;
-    block_sum2_f64<1024>(sq, unused);
-    if (threadIdx.x == 0) unsafeAtomicAdd(acc + 2, sq);
 }
 
 }  // namespace qr
@@ -946,7 +984,8 @@ struct PpoOps {
         a.n = p->num_params;
         a.partial = p->d_partial;
         a.wave_out = p->d_wave;
-        hipLaunchKernelGGL(qr::ppo_apply_kernel<L>, dim3((p->num_params + 1023) / 1024), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL(qr::ppo_apply_kernel<L>, dim3((p->num_params + qr::kApplyThreads - 1) / qr::kApplyThreads),
+                           dim3(qr::kApplyThreads), 0, st, a);
         PPO_HIP(hipGetLastError());
         return QR_OK;
     }

@@ -88,7 +88,8 @@ def test_full_size_lockstep_through_resets_vs_oracle(PA, OA, variant, residual_b
         np.testing.assert_array_equal(wg[done], wo2[done])                  # freshly reset lanes: bit exact
         if variant == E2E:
             np.testing.assert_array_equal(dg[done], do2[done])
-        worst_state = max(worst_state, float(P.rel_err(wg[live], wo2[live]).max()))
+        if live.any():   # (at the time-limit step of a crash-free batch every env is done at once)
+            worst_state = max(worst_state, float(P.rel_err(wg[live], wo2[live]).max()))
         worst_obs = max(worst_obs, float(P.obs_err(og[ok], oo[ok], wo2[ok]).max()))
         tot_done += int(dno.sum())
     assert worst_state < P.TOL_STEP_STATE and worst_obs < P.TOL_STEP_OBS, (worst_state, worst_obs)
@@ -179,7 +180,7 @@ def test_eight_shards_of_32768_equal_one_262144_env_handle():
     obs0 = big.reset_device().clone()
     ob, rb, db, tb = big.rollout_device(acts)
     wb = big.get_state_tensors()[0]
-    assert int(db.sum()) > n * R   # more than one reset per env on average
+    assert int(db.sum()) >= n * R   # every env is auto-reset at least once inside the window
     for r in range(R):
         sl = slice(r * n, (r + 1) * n)
         e = make(n, r * n)
@@ -221,3 +222,101 @@ def test_config5_training_loop_at_full_size(variant):
     assert torch.isfinite(ppo._updater.theta).all() and not torch.equal(ppo._updater.theta, theta0)
     assert np.isfinite(ppo.stats["loss"]) and ppo.stats["approx_kl"] >= 0 and ppo.stats["episodes"] > 0
     env.close()
+
+
+FAKE_SB3 = '''
+import warnings
+from abc import ABC, abstractmethod
+
+
+class VecEnv(ABC):
+    """The parts of stable_baselines3 2.1 `VecEnv` the reference class relies on (constructor contract incl. the
+    `get_attr("render_mode")` probe that R:603-604 answers with AttributeError, abstract method set, step())."""
+
+    def __init__(self, num_envs, observation_space, action_space):
+        self.num_envs = num_envs
+        self.observation_space = observation_space
+        self.action_space = action_space
+        self.reset_infos = [{} for _ in range(num_envs)]
+        self._seeds = [None for _ in range(num_envs)]
+        self._options = [{} for _ in range(num_envs)]
+        try:
+            render_modes = self.get_attr("render_mode")
+        except AttributeError:
+            warnings.warn("The `render_mode` attribute is not defined in your environment. It will be set to None.")
+            render_modes = [None for _ in range(num_envs)]
+        assert all(m == render_modes[0] for m in render_modes)
+        self.render_mode = render_modes[0]
+
+    @abstractmethod
+    def reset(self): ...
+    @abstractmethod
+    def step_async(self, actions): ...
+    @abstractmethod
+    def step_wait(self): ...
+    @abstractmethod
+    def close(self): ...
+    @abstractmethod
+    def get_attr(self, attr_name, indices=None): ...
+    @abstractmethod
+    def set_attr(self, attr_name, value, indices=None): ...
+    @abstractmethod
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs): ...
+    @abstractmethod
+    def env_is_wrapped(self, wrapper_class, indices=None): ...
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+'''
+
+SB3_CHILD = '''
+import sys, warnings, numpy as np
+sys.path.insert(0, %r)
+import stable_baselines3.common.vec_env as sb3v
+from optimal_quad_control_rl_amd import Quadcopter3DGates, zigzag_track
+from optimal_quad_control_rl_amd import vec_env as V
+assert V._SB3VecEnv is sb3v.VecEnv and issubclass(Quadcopter3DGates, sb3v.VecEnv)
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    env = Quadcopter3DGates(64, *zigzag_track(), gates_ahead=1)           # would raise TypeError if an abstract method were missing
+assert any("render_mode" in str(x.message) for x in w)                    # the R:603-604 path: get_attr raised AttributeError
+assert env.render_mode is None and len(env.reset_infos) == 64 and env.num_envs == 64
+obs = env.reset()
+assert obs.shape == (64, env.observation_space.shape[0]) and env.action_space.shape == (4,)
+o, r, d, infos = env.step(np.zeros((64, 4), np.float32))                  # the BASE class's step(): step_async + step_wait
+assert o.shape == obs.shape and r.shape == (64,) and d.dtype == bool and len(infos) == 64
+assert env.env_is_wrapped(object) == [False] * 64
+# attribute idioms of the reference-side harness (R:4499-4500): in-place edits reach the device
+env.world_states[3] = np.arange(16, dtype=np.float32)
+env.target_gates[:] = 2
+assert (env.world_states[3] == np.arange(16)).all() and (env.target_gates == 2).all()
+env.pause_if_collision = True                                             # plain attribute in the reference (R:293): assignable
+env.step_counts[:] = env.max_steps - 1
+ws = env.world_states.copy()
+o, r, d, _ = env.step(np.zeros((64, 4), np.float32))
+assert d.all() and (env.world_states == ws).all()                         # done envs frozen, not reset (R:573-578)
+env.pause_if_collision = False
+o, r, d, _ = env.step(np.zeros((64, 4), np.float32))
+assert d.all() and (env.step_counts == 0).all()                           # auto-reset again
+print("sb3 child ok")
+'''
+
+
+def test_derives_from_sb3_vecenv_when_present(tmp_path):
+    """The reference class IS an SB3 VecEnv (R:287).  SB3 is not installable here, so a stand-in package with SB3 2.1's
+    constructor contract is put on the path of a child process: the adapter must pick it up as its base class, satisfy the
+    abstract method set and survive the `get_attr("render_mode")` probe exactly like the reference does."""
+    import os
+    import subprocess
+    import sys
+
+    pkg = tmp_path / "stable_baselines3" / "common"
+    pkg.mkdir(parents=True)
+    (tmp_path / "stable_baselines3" / "__init__.py").write_text("")
+    (pkg / "__init__.py").write_text("")
+    (pkg / "vec_env.py").write_text(FAKE_SB3)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=str(tmp_path) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-c", SB3_CHILD % root], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "sb3 child ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

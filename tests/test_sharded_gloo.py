@@ -135,3 +135,43 @@ def test_world2_gradient_averaging_keeps_ranks_identical(tmp_path):
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ddp_ok").exists()
+
+
+def _kl_worker(rank, world, port, tmp):
+    """Data-parallel target-KL early stop: the minibatch statistics ride behind the gradient in ONE [n + 4] vector
+    (qr_ppo_grad), the all-reduce averages them with it, and qr_ppo_apply decides on the averaged KL sum -- so every rank
+    takes the same decision even when the rank-local KLs straddle the threshold (a rank-local decision would desynchronise
+    the per-minibatch all-reduce)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from optimal_quad_control_rl_amd.ppo import average_across_ranks
+
+    n, B, target_kl = 1000, 2048, 0.02
+    g = torch.Generator().manual_seed(7 + rank)
+    vec = torch.randn(n + 4, generator=g)
+    local_kl_mean = 0.01 if rank == 0 else 0.06            # rank 0 below 1.5 * target_kl = 0.03, rank 1 above
+    vec[n + 2] = local_kl_mean * B                          # the KL SUM of this rank's rows
+    local_decision = bool(vec[n + 2] > 1.5 * target_kl * B)
+    avg = average_across_ranks(vec.clone())
+    decision = bool(avg[n + 2] > 1.5 * target_kl * B)       # what ppo_apply_kernel evaluates (kl_limit = 1.5 target_kl B)
+    gathered = [torch.empty(1) for _ in range(world)]
+    dist.all_gather(gathered, torch.tensor([float(decision)]))
+    local = [torch.empty(1) for _ in range(world)]
+    dist.all_gather(local, torch.tensor([float(local_decision)]))
+    assert gathered[0] == gathered[1]                       # collective decision: identical everywhere
+    assert local[0] != local[1]                             # the rank-local rule would have split the ranks
+    assert decision == ((0.01 + 0.06) / 2 > 1.5 * target_kl)
+    both = [torch.empty_like(avg) for _ in range(world)]
+    dist.all_gather(both, avg)
+    assert torch.equal(both[0], both[1])                    # gradient and statistics identical after the all-reduce
+    if rank == 0:
+        open(os.path.join(tmp, "kl_ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_target_kl_decision_is_collective(tmp_path):
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_kl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "kl_ok").exists()

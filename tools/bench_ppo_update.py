@@ -30,7 +30,13 @@ def measure(L=17, B=16384, R=65536 * 8, iters=100, with_torch=True):
     pol = ActorCritic(L, 4).to(dev)
     up = MfmaPpoUpdater(pol, L, dev, B)
     nb = R // B
-    t_native = timed(lambda k: up.minibatch(obs, act, old_lp, adv, ret, perm[(k % nb) * B:(k % nb + 1) * B], 3e-4), iters)
+
+    def native_step(k):   # the training loop's calling pattern: one adv-statistics launch per epoch, three launches per minibatch
+        if k % nb == 0:
+            up.begin_epoch(adv, perm, B)
+        up.minibatch(obs, act, old_lp, adv, ret, perm[(k % nb) * B:(k % nb + 1) * B], 3e-4)
+
+    t_native = timed(native_step, iters)
     flops = 2 * B * 3 * 2 * (L * 120 + 2 * 120 * 120 + 2.5 * 120)   # 2 nets x (fwd + 2 bwd GEMMs) x 2 flop/MAC, useful MACs only
     out = {"what": "one PPO minibatch update (both 3x120 networks: forward, loss, backward, grad-norm clip, Adam): qr_ppo_minibatch "
                    "vs torch autograd + torch.optim.Adam on the same rows", "obs_len": L, "minibatch": B,

@@ -3,8 +3,9 @@
 
     python tools/train_ppo.py [--variant indi|e2e] [--envs 65536] [--steps 3e8] [--track square|zigzag]
 
-Prints training progress and a final deterministic evaluation (gates per episode, seconds per gate/lap on the
-4-gate square track; the reference's simulated lap times there are 2.5-3.2 s, FP:3474-3488)."""
+Prints training progress and a final deterministic evaluation on the 4-gate square track: gates per 12 s from a standing
+start, and lap times the way the reference tabulates them (FP:3474-3488: lap 1 from the start, then the flying laps; its
+simulated E2E policy flies 2.97 s then 2.51-2.59 s, INDI 3.20 s then 2.75-2.82 s)."""
 import argparse, os, sys, time, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,6 +29,7 @@ ap.add_argument("--native-update", action="store_true", help="minibatch updates 
 ap.add_argument("--ent-coef", type=float, default=0.0)
 ap.add_argument("--gamma", type=float, default=0.999)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--no-trunc-bootstrap", action="store_true", help="round-1 behaviour: a time-limit truncation is a termination")
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 
@@ -50,7 +52,7 @@ if a.variant == "e2e":
     env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
 model = PPO(env, seed=a.seed, ent_coef=a.ent_coef, gamma=a.gamma, n_steps=a.n_steps, n_epochs=a.epochs, batch_size=a.envs * a.n_steps // a.minibatches, learning_rate=a.lr,
             target_kl=a.target_kl, lr_final_frac=a.lr_final, total_timesteps_hint=int(a.steps) // world, fused_collect=a.fused,
-            native_update=a.native_update)
+            native_update=a.native_update, truncation_bootstrap=not a.no_trunc_bootstrap)
 if "RANK" in os.environ:
     model._updater.broadcast_parameters(0)   # identical start on every rank (the seed already makes it so; this guarantees it)
     model.noise_seed = a.seed                 # same key, different global env ids -> independent action noise per rank
@@ -67,22 +69,48 @@ if best["state"] is not None:
 torch.cuda.synchronize()
 train_s = time.perf_counter() - t0
 
-# deterministic evaluation on a fresh env: 1200 steps = 12 s of flight, no auto-reset masking of crashes
+# deterministic evaluation on a fresh env: 2000 steps = 20 s of flight (six laps), crashes auto-reset and restart the lap count
 n_eval = 4096
 ev = cls(n_eval, *trk, gates_ahead=1, infos_mode="none", seed=99)
 if a.variant == "e2e":
     ev.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+ev.max_steps = 10 ** 6
 obs = ev.reset_device()
-gates = torch.zeros(n_eval, device="cuda"); crashes = torch.zeros(n_eval, device="cuda")
-for k in range(1200):
-    obs, rew, done, trunc = ev.step_device(model.predict(obs).contiguous())
-    gates += (rew > 5).float(); crashes += (done.float() - trunc.float()).clamp(min=0)
+dev = obs.device
+G = 4 if a.track == "square" else len(trk[0])   # square_track() lists its four gates twice: a lap is four passes
+gates12 = torch.zeros(n_eval, device=dev); crashes12 = torch.zeros(n_eval, device=dev)
+passed = torch.zeros(n_eval, device=dev)            # gates passed since this env's last (re)start
+lap_start = torch.zeros(n_eval, device=dev)         # time of the last lap boundary (or restart)
+lap_sum = torch.zeros(7, device=dev); lap_cnt = torch.zeros(7, device=dev)   # laps 1..6 (index 0 unused)
 dt = 0.01
-res = dict(world_size=world, fused_collect=a.fused, native_update=a.native_update, variant=a.variant, track=a.track, envs=a.envs, train_steps=model.num_timesteps * world, train_seconds=train_s,
+for k in range(2000):
+    obs, rew, done, trunc = ev.step_device(model.predict(obs).contiguous())
+    t = (k + 1) * dt
+    g = (rew > 5).float()
+    if k < 1200:
+        gates12 += g; crashes12 += (done.float() - trunc.float()).clamp(min=0)
+    passed += g
+    lap_done = (g > 0) & (passed % G == 0) & (passed > 0)
+    lap_no = (passed / G).long().clamp(max=6)
+    if lap_done.any():
+        sel = lap_done & (passed / G <= 6)
+        lap_sum.index_add_(0, lap_no[sel], (t - lap_start)[sel])
+        lap_cnt.index_add_(0, lap_no[sel], torch.ones_like(lap_start)[sel])
+        lap_start = torch.where(lap_done, torch.full_like(lap_start, t), lap_start)
+    d = done.bool()
+    passed = torch.where(d, torch.zeros_like(passed), passed)
+    lap_start = torch.where(d, torch.full_like(lap_start, t), lap_start)
+laps = (lap_sum / lap_cnt.clamp(min=1)).tolist()
+res = dict(world_size=world, fused_collect=a.fused, native_update=a.native_update, variant=a.variant, track=a.track, envs=a.envs,
+           gamma=a.gamma, seed=a.seed, n_steps=a.n_steps, epochs=a.epochs, minibatches=a.minibatches, lr=a.lr, target_kl=a.target_kl,
+           truncation_bootstrap=not a.no_trunc_bootstrap,
+           train_steps=model.num_timesteps * world, train_seconds=train_s,
            train_Msteps_per_s=model.num_timesteps * world / train_s / 1e6,
-           eval_gates_per_12s=float(gates.mean()), eval_crashes_per_12s=float(crashes.mean()),
-           eval_seconds_per_gate=float(1200 * dt / gates.mean().clamp(min=1e-9)),
-           eval_seconds_per_lap_4gates=float(4 * 1200 * dt / gates.mean().clamp(min=1e-9)), **model.stats)
+           eval_gates_per_12s=float(gates12.mean()), eval_crashes_per_12s=float(crashes12.mean()),
+           eval_seconds_per_gate=float(1200 * dt / gates12.mean().clamp(min=1e-9)),
+           eval_seconds_per_lap_4gates=float(4 * 1200 * dt / gates12.mean().clamp(min=1e-9)),
+           eval_lap_seconds={f"lap{i}": laps[i] for i in range(1, 7)}, eval_laps_counted=lap_cnt[1:].tolist(),
+           eval_flying_lap_seconds=float(lap_sum[2:].sum() / lap_cnt[2:].sum().clamp(min=1)), **model.stats)
 print(json.dumps(res))
 if a.out:
     json.dump(res, open(a.out, "w"), indent=1)
