@@ -104,6 +104,19 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// one round of the same generator (for callers that spread the ten rounds over idle issue slots); round r = 0..9 uses the
+// key bumped r times, so ten calls with r = 0..9 equal philox4x32_10()
+__device__ __forceinline__ void philox4x32_round(uint32_t c[4], uint32_t k0, uint32_t k1, int r) {
+    k0 += 0x9E3779B9u * (uint32_t)r;
+    k1 += 0xBB67AE85u * (uint32_t)r;
+    const uint32_t lo0 = 0xD2511F53u * c[0], hi0 = __umulhi(0xD2511F53u, c[0]);
+    const uint32_t lo1 = 0xCD9E8D57u * c[2], hi1 = __umulhi(0xCD9E8D57u, c[2]);
+    c[0] = hi1 ^ c[1] ^ k0;
+    c[1] = lo1;
+    c[2] = hi0 ^ c[3] ^ k1;
+    c[3] = lo0;
+}
+
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }
 // Separately rounded operations (bit-identical to the CPU oracle).  NB: HIP's __fadd_rn/__fmul_rn are plain
 // operators that hipcc may still contract into an FMA, so contraction is switched off with the pragma.

@@ -344,29 +344,55 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
         P.tick_on = (k == K / 2);
 #endif
         QR_TICK(P, 8);
+        // Action noise eps ~ N(0, 1)^4 (Philox4x32-10 keyed by (noise seed, global env id, global step) + Box-Muller) does not
+        // depend on the policy output: its ~300 VALU instructions are cut into slices that policy_forward() places between
+        // the MFMAs of the second hidden layer, where the wave otherwise only waits for the matrix core.
         float mean[4];
-        policy_forward<L>(W, lane, o, mean);
+        float eps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        uint32_t pc[4];
+        float bm_u1a, bm_u2a, bm_u1b, bm_u2b, bm_ra, bm_rb, bm_sa, bm_ca, bm_sb, bm_cb;
+        // (drawn in deterministic mode too and then multiplied out: a branch would split the pinned MFMA schedule)
+        // Each slice first passes the values it reads through an empty volatile asm: that emits nothing, but it is ordered
+        // with the sched_barrier pins of policy_layer (both are side-effecting), which is what keeps the slice in ITS slot --
+        // plain arithmetic would all be hoisted in front of the layer.
+        auto pin_u = [](uint32_t& x) { asm volatile("" : "+v"(x)); };
+        auto pin_f = [](float& x) { asm volatile("" : "+v"(x)); };
+        auto noise_slice = [&](int slot) {
+            if (slot >= 1 && slot <= 11) { pin_u(pc[0]); pin_u(pc[1]); pin_u(pc[2]); pin_u(pc[3]); }
+            if (slot == 12) pin_f(bm_u1a);
+            if (slot == 13) pin_f(bm_u1b);
+            if (slot == 14) pin_f(bm_u2a);
+            if (slot == 15) pin_f(bm_u2b);
+            if (slot == 16) { pin_f(bm_ra); pin_f(bm_rb); pin_f(bm_sa); pin_f(bm_sb); }
+            if (slot == 0) {
+                const uint32_t s_lo = A.step_lo + (uint32_t)k;
+                pc[0] = gid_lo; pc[1] = gid_hi; pc[2] = s_lo; pc[3] = A.step_hi + (s_lo < A.step_lo ? 1u : 0u);
+            } else if (slot <= 10) {
+                philox4x32_round(pc, A.seed_lo, A.seed_hi, slot - 1);
+            } else if (slot == 11) {  // Box-Muller: two pairs of normals from four uniforms (u1 in (0,1], u2 in [0,1))
+                bm_u1a = (float)((pc[0] >> 8) + 1u) * 5.9604644775390625e-8f; bm_u2a = u01(pc[1]);
+                bm_u1b = (float)((pc[2] >> 8) + 1u) * 5.9604644775390625e-8f; bm_u2b = u01(pc[3]);
+            } else if (slot == 12) {
+                bm_ra = fast_sqrt(-2.0f * __logf(bm_u1a));
+            } else if (slot == 13) {
+                bm_rb = fast_sqrt(-2.0f * __logf(bm_u1b));
+            } else if (slot == 14) {
+                qr_sincos(6.283185307179586f * bm_u2a, bm_sa, bm_ca);
+            } else if (slot == 15) {
+                qr_sincos(6.283185307179586f * bm_u2b, bm_sb, bm_cb);
+            } else if (slot == 16) {
+                eps[0] = bm_ra * bm_ca; eps[1] = bm_ra * bm_sa; eps[2] = bm_rb * bm_cb; eps[3] = bm_rb * bm_sb;
+            }
+        };
+        policy_forward<L>(W, lane, o, mean, noise_slice);
         QR_TICK(P, 9);
         float a[4] = {mean[0], mean[1], mean[2], mean[3]};
         float logp = A.logp_const;
-        if (!A.deterministic) {
-            const uint32_t s_lo = A.step_lo + (uint32_t)k;
-            const uint32_t s_hi = A.step_hi + (s_lo < A.step_lo ? 1u : 0u);
-            uint32_t r[4];
-            philox4x32_10(gid_lo, gid_hi, s_lo, s_hi, A.seed_lo, A.seed_hi, r);
-            // Box-Muller: two pairs of normals from four uniforms (u1 in (0,1], u2 in [0,1))
-            const float u1a = (float)((r[0] >> 8) + 1u) * 5.9604644775390625e-8f, u2a = u01(r[1]);
-            const float u1b = (float)((r[2] >> 8) + 1u) * 5.9604644775390625e-8f, u2b = u01(r[3]);
-            const float ra = fast_sqrt(-2.0f * __logf(u1a)), rb = fast_sqrt(-2.0f * __logf(u1b));
-            float sa, ca, sb, cb;
-            qr_sincos(6.283185307179586f * u2a, sa, ca);
-            qr_sincos(6.283185307179586f * u2b, sb, cb);
-            const float eps[4] = {ra * ca, ra * sa, rb * cb, rb * sb};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                a[c] = fmaf(A.std[c], eps[c], mean[c]);
-                logp = fmaf(-0.5f * eps[c], eps[c], logp);
-            }
+        for (int c = 0; c < 4; ++c) {
+            const float e = A.deterministic ? 0.0f : eps[c];   // fmaf(std, 0, mean) = mean, fmaf(-0, 0, logp) = logp
+            a[c] = fmaf(A.std[c], e, mean[c]);
+            logp = fmaf(-0.5f * e, e, logp);
         }
         QR_TICK(P, 10);
         // rollout buffer row t: the observation the action was computed from, the unclipped action, its log-prob

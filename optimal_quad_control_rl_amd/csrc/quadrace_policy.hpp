@@ -96,9 +96,14 @@ __device__ __forceinline__ uint32_t relu_pack2(float lo, float hi) {
 //   K-step g of output tile t:   ds_read of tile t+1's operand g   (a whole tile ahead of its use)
 //                                2 MFMAs (env tiles 0 and 1) on tile t's operand g
 //                                1/KS of the ReLU + f16 pack of tile t-1 (its accumulators finished a tile ago)
-template <int KS>
+//                                `filler(slot)`: a slice of INDEPENDENT caller work (the closed-loop kernel draws its
+//                                action noise here) -- a K-step leaves ~25 of its 32 VALU issue slots unused
+struct NoFiller {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int KS, class Filler = NoFiller>
 __device__ __forceinline__ void policy_layer(const half8* __restrict__ W, int lane, const half8 (&in)[2][KS],
-                                             half8 (&out)[2][8]) {
+                                             half8 (&out)[2][8], Filler&& filler = Filler()) {
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     f32x16p acc[2][2];  // [tile parity][env tile]
     half8 a[2][KS];     // [tile parity][K-step]: A operands, fetched one tile ahead of their MFMAs
@@ -123,6 +128,7 @@ __device__ __forceinline__ void policy_layer(const half8* __restrict__ W, int la
                     o32[et][2 * (t - 1) + sh][dd] = relu_pack2(acc[p][et][8 * sh + 2 * dd], acc[p][et][8 * sh + 2 * dd + 1]);
                 }
             }
+            if (t < 4) filler(t * KS + g);   // slots 0 .. 4 KS - 1, one per MFMA pair
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -134,8 +140,10 @@ __device__ __forceinline__ void policy_layer(const half8* __restrict__ W, int la
 
 // Full policy forward for the wave's 64 envs.  o[L] = this lane's observation (lane = env); mean[4] = action means
 // of this lane's env.  Wlds = packed f16 weights in LDS (PolicyDims<L> layout).  Must be called by all 64 lanes.
-template <int L>
-__device__ __forceinline__ void policy_forward(const half8* __restrict__ Wlds, int lane, const float* o, float mean[4]) {
+// `filler(slot)`, slot = 0..31, is called once per K-step of the second hidden layer (see policy_layer).
+template <int L, class Filler = NoFiller>
+__device__ __forceinline__ void policy_forward(const half8* __restrict__ Wlds, int lane, const float* o, float mean[4],
+                                               Filler&& filler = Filler()) {
     using D = PolicyDims<L>;
     // ---- layer 1 B operands: input k = 16s + 8h + j; lanes 0..31 supply h = 0, lanes 32..63 h = 1 (of env l-32)
     half8 in1[2][D::kSteps1];
@@ -154,7 +162,7 @@ __device__ __forceinline__ void policy_forward(const half8* __restrict__ Wlds, i
     }
     half8 h1[2][8], h2[2][8];
     policy_layer<D::kSteps1>(Wlds, lane, in1, h1);
-    policy_layer<8>(Wlds + D::kOff2, lane, h1, h2);
+    policy_layer<8>(Wlds + D::kOff2, lane, h1, h2, filler);
     policy_layer<8>(Wlds + D::kOff3, lane, h2, h1);
     // ---- output layer: one 32-row tile, rows 0..3 = action means
     f32x16p acc0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
