@@ -213,7 +213,11 @@ struct PpoBatch {
 // of the end-of-kernel L2 write-back (same reasoning as the env kernels' outputs, tools/ubench/launch_floor.hip).
 typedef float f32x4p __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void stream_store_h8(half8* p, const half8 v) {
+#ifdef QR_PPO_PLAIN_SCRATCH_STORES
+    *p = v;
+#else
     __builtin_nontemporal_store(__builtin_bit_cast(f32x4p, v), reinterpret_cast<f32x4p*>(p));
+#endif
 }
 
 __device__ __forceinline__ half8 plain_pack(const f32x16p& acc, int s) {
@@ -227,19 +231,6 @@ __device__ __forceinline__ half8 plain_pack(const f32x16p& acc, int s) {
 // and bit 16 + sh for its high half.
 typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
 typedef unsigned short ushort2p __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t relu_bits(uint32_t word, const half8& relu_packed, int t, int s) {
-    const u32x4p p = __builtin_bit_cast(u32x4p, relu_packed);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        // relu output >= 0: its f16 bit pattern is non-zero iff the unit is active; min(bits, 1) per half -> 0 / 1
-        const uint32_t bits = p[d];
-        const ushort2p one = {1, 1};
-        const ushort2p halves = __builtin_bit_cast(ushort2p, bits);
-        const uint32_t on = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(halves, one));  // v_pk_min_u16
-        word |= on << (8 * (t & 1) + 4 * s + d);
-    }
-    return word;
-}
 __device__ __forceinline__ half8 mask_pack(const f32x16p& acc, uint32_t word, int t, int s) {
     float v[8];
 #pragma unroll
@@ -253,40 +244,82 @@ __device__ __forceinline__ half8 mask_pack(const f32x16p& acc, uint32_t word, in
     return __builtin_bit_cast(half8, p);
 }
 
+// One dword (two values) of a layer's epilogue, d = 0..15 within a pair of output tiles: tile-in-pair ti = d >> 3, pack
+// sh = (d >> 2) & 1, dword dd = d & 3 -> accumulator registers 8 sh + 2 dd (+1) of acc[ti].  Forward: relu + saturation +
+// f16 pack, and the unit-active bits into `word`; backward: saturation + pack, zeroed where the forward unit was inactive.
+// The f32 -> f16 conversion stays compiler-visible (it reads MFMA results: hazard wait states); the max / min pair is inline
+// asm so that the dword stays in the issue slot the source gives it (see mlp_layer).
+template <bool BWD>
+__device__ __forceinline__ uint32_t epilogue_dword(const f32x16p (&acc)[2], int d, uint32_t& word) {
+    const int ti = d >> 3, sh = (d >> 2) & 1, dd = d & 3;
+    const int shift = 8 * ti + 4 * sh + dd;
+    if (!BWD) {
+        const uint32_t r = relu_pack2(acc[ti][8 * sh + 2 * dd], acc[ti][8 * sh + 2 * dd + 1]);
+        const ushort2p one = {1, 1};
+        // relu output >= 0: its f16 bit pattern is non-zero iff the unit is active; min(bits, 1) per half -> 0 / 1
+        const uint32_t on = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2p, r), one));
+        word |= on << shift;
+        return r;
+    }
+    typedef _Float16 half2p __attribute__((ext_vector_type(2)));
+    const half2p c = {(_Float16)acc[ti][8 * sh + 2 * dd], (_Float16)acc[ti][8 * sh + 2 * dd + 1]};
+    uint32_t r = __builtin_bit_cast(uint32_t, c);
+    asm("v_pk_max_f16 %0, %0, %1\n\tv_pk_min_f16 %0, %0, %2" : "+v"(r) : "v"(0xFBFFFBFFu), "v"(0x7BFF7BFFu));  // +-65504
+    const uint32_t on = (word >> shift) & 0x00010001u;
+    return r & (on * 0xFFFFu);  // 0x0001 -> 0xFFFF in each half (no carry between the halves)
+}
+
 // One 128-unit layer for ONE 32-sample tile: in[KS] -> out[8].  Forward (BWD = false): out = relu(acc) packed,
 // mask = (acc > 0).  Backward (BWD = true): out = acc where mask is set (the ReLU derivative of the layer being
 // entered), else 0.  Two output tiles are accumulated side by side (two independent MFMA chains).
+//
+// The schedule is written out and pinned (sched_barrier), like policy_layer: left to itself the scheduler emitted
+// "ds_read, s_waitcnt lgkmcnt, MFMA" per K-step (LDS latency exposed 148 times per wave, one wave per SIMD) and lumps of
+// pack instructions behind s_nop 7-10 hazard waits.  K-step group q = (pair tp, step s):
+//     2 MFMAs on ring slot q % D     |     ds_read of group q + D's operands into that slot (D = 4 K-steps ahead)
+//     1/KS of the epilogue of the PREVIOUS pair (its accumulators finished a pair ago: no hazard wait)
 template <int KS, bool BWD>
 __device__ __forceinline__ void mlp_layer(const half8* __restrict__ W, int lane, const half8 (&in)[KS], half8 (&out)[8],
                                           uint32_t (&mask)[2]) {
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int D = KS < 4 ? KS : 4;
+    half8 a0[D], a1[D];
+    // operands of group q: tiles 2 tp and 2 tp + 1 at K-step s
+    auto fetch = [&](int q, int slot) {
+        const int tp = q / KS, s = q % KS;
+        a0[slot] = W[((2 * tp) * KS + s) * 64 + lane];
+        a1[slot] = W[((2 * tp + 1) * KS + s) * 64 + lane];
+    };
 #pragma unroll
-    for (int tp = 0; tp < 2; ++tp) {
-        const int t0 = 2 * tp, t1 = 2 * tp + 1;
-        f32x16p acc0 = zero, acc1 = zero;
+    for (int q = 0; q < D; ++q) fetch(q, q);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16p acc[2][2];   // [pair parity][tile in pair]
+    u32x4p o32[8];
+    uint32_t word[2] = {BWD ? mask[0] : 0u, BWD ? mask[1] : 0u};
+#pragma unroll
+    for (int tp = 0; tp <= 2; ++tp) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const half8 a0 = W[(t0 * KS + s) * 64 + lane];
-            const half8 a1 = W[(t1 * KS + s) * 64 + lane];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, in[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, in[s], acc1, 0, 0, 0);
+            const int q = tp * KS + s;
+            if (tp < 2) {
+                acc[tp][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[q % D], in[s], s == 0 ? zero : acc[tp][0], 0, 0, 0);
+                acc[tp][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[q % D], in[s], s == 0 ? zero : acc[tp][1], 0, 0, 0);
+                if (q + D < 2 * KS) fetch(q + D, q % D);
+            }
+            if (tp > 0) {
+                const int p = tp - 1;
+#pragma unroll
+                for (int d = (16 * s) / KS; d < (16 * (s + 1)) / KS; ++d)
+                    o32[4 * p + (d >> 2)][d & 3] = epilogue_dword<BWD>(acc[p], d, word[p]);   // out[2 (2p + ti) + sh]
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (BWD) {
-            out[2 * t0] = mask_pack(acc0, mask[tp], t0, 0);
-            out[2 * t0 + 1] = mask_pack(acc0, mask[tp], t0, 1);
-            out[2 * t1] = mask_pack(acc1, mask[tp], t1, 0);
-            out[2 * t1 + 1] = mask_pack(acc1, mask[tp], t1, 1);
-        } else {
-            out[2 * t0] = relu_pack(acc0, 0);
-            out[2 * t0 + 1] = relu_pack(acc0, 1);
-            out[2 * t1] = relu_pack(acc1, 0);
-            out[2 * t1 + 1] = relu_pack(acc1, 1);
-            uint32_t w = relu_bits(0u, out[2 * t0], t0, 0);
-            w = relu_bits(w, out[2 * t0 + 1], t0, 1);
-            w = relu_bits(w, out[2 * t1], t1, 0);
-            mask[tp] = relu_bits(w, out[2 * t1 + 1], t1, 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the second tile pair's A operands below the first pair's MFMAs
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[k] = __builtin_bit_cast(half8, o32[k]);
+    if (!BWD) {
+        mask[0] = word[0];
+        mask[1] = word[1];
     }
 }
 
@@ -301,13 +334,21 @@ __device__ __forceinline__ void tstore_hidden(const half8 (&X)[8], half8* __rest
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) id[s][j] = (rho_(8 * s + j, h) == c) ? (_Float16)1.0f : (_Float16)0.0f;
+    // software pipeline: the identity MFMAs of unit tile ut + 1 are issued before unit tile ut is packed and stored, so
+    // the pack never waits for the matrix core (it used to sit behind an s_nop 7-10 right after its MFMAs)
+    f32x16p acc[2];
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[0], id[0], zero, 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[1], id[1], acc[0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ut = 0; ut < 4; ++ut) {
-        f32x16p acc = zero;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut], id[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut + 1], id[1], acc, 0, 0, 0);
-        stream_store_h8(dst + ut * slot_stride + (2 * st) * 64 + lane, plain_pack(acc, 0));
-        stream_store_h8(dst + ut * slot_stride + (2 * st + 1) * 64 + lane, plain_pack(acc, 1));
+        if (ut < 3) {
+            acc[(ut + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut + 2], id[0], zero, 0, 0, 0);
+            acc[(ut + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut + 3], id[1], acc[(ut + 1) & 1], 0, 0, 0);
+        }
+        stream_store_h8(dst + ut * slot_stride + (2 * st) * 64 + lane, plain_pack(acc[ut & 1], 0));
+        stream_store_h8(dst + ut * slot_stride + (2 * st + 1) * 64 + lane, plain_pack(acc[ut & 1], 1));
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -333,7 +374,7 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half8* W = reinterpret_cast<half8*>(smem);
     const int net = blockIdx.y;
-    if (*a.stop) return;  // uniform over the grid
+    const int stop_flag = *a.stop;  // loaded with everything else, TESTED only before the first store: no exposed round trip
     PPO_TICK(a, 0);
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     // wave-uniform indices in scalar registers: the 25+ scratch-slot addresses become scalar bases + one lane offset
@@ -385,7 +426,7 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
         }
     }
     __syncthreads();
-    if (!live) return;  // whole wave
+    if (!live || stop_flag) return;  // whole wave / the target-KL early stop hit in an earlier launch (uniform over the grid)
     PPO_TICK(a, 1);
     // the per-sample scalars are parked in the LDS left over beside the operand images until the loss needs them
     float* stash = reinterpret_cast<float*>(W + D::kImage) + wave * 32 + c;
@@ -445,13 +486,20 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
         PPO_TICK(a, 6);
         mlp_layer<8, false>(W + P::kOff3, lane, y, x, m3);  // x = h3
         PPO_TICK(a, 7);
+        // the output layer's 8 operands and W4^T's 4 are fetched from LDS now, under the h3^T store / the loss arithmetic
+        half8 w4[8], w4t[4];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) w4[s] = W[P::kOff4 + s * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w4t[t] = W[D::kOffT4 + t * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
         tstore_hidden(x, tb + D::kSlotH3 * slot_stride, slot_stride, lane, et);
         PPO_TICK(a, 8);
         float out4[4];  // rows 0..3 of the output tile: registers 0..3 of lanes 0..31 (sample 32 et + lane)
         {
             f32x16p acc = zero;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[P::kOff4 + s * 64 + lane], x[s], acc, 0, 0, 0);
+            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4[s], x[s], acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) out4[r] = acc[r];
         }
@@ -519,7 +567,7 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
         // ---- backward: d3 = (W4^T d4) * relu'(z3);  d2 = (W3^T d3) * relu'(z2);  d1 = (W2^T d2) * relu'(z1)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[D::kOffT4 + t * 64 + lane], d4, zero, 0, 0, 0);
+            const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4t[t], d4, zero, 0, 0, 0);
             x[2 * t] = mask_pack(acc, m3[t >> 1], t, 0);
             x[2 * t + 1] = mask_pack(acc, m3[t >> 1], t, 1);
         }
@@ -551,7 +599,7 @@ __global__ void __launch_bounds__(64) ppo_phase_b_kernel(const half8* __restrict
                                                          int G, int groups_per_chunk, int num_chunks, float scale,
                                                          const int* __restrict__ stop) {
     using D = PpoDims<L>;
-    if (*stop) return;  // target-KL early stop hit in an earlier launch
+    const int stop_flag = *stop;  // target-KL early stop hit in an earlier launch: tested before the stores, not up front
     const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
     // XCD-aware mapping: workgroups go round-robin to the 8 XCDs (each with its own L2), so workgroup id % 8 selects the XCD.
     // All tile blocks of one sample chunk share their operands -> they get the same id % 8 and meet in one L2
@@ -584,33 +632,45 @@ __global__ void __launch_bounds__(64) ppo_phase_b_kernel(const half8* __restrict
     const int g1 = min(G, g0 + groups_per_chunk);
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     f32x16p acc[2][2] = {{zero, zero}, {zero, zero}};
-    // operands of group g + 1 are in flight while group g is multiplied (a wave is otherwise one round trip per group)
-    half8 a0[4], a1[4], b0[4], b1[4];
+    // Operands of the NEXT TWO groups are in flight while two groups are multiplied (a wave is otherwise one memory round trip
+    // per group: with 16 KB in flight per wave x 768 waves the kernel sat at 3.5 TB/s -- Little's law for ~2 us of loaded HBM
+    // latency -- so the batch in flight is doubled to 32 KB per wave).
+    constexpr int kPF = 2;                       // groups per batch
+    half8 a0[kPF][4], a1[kPF][4], b0[kPF][4], b1[kPF][4];
+    auto fetch = [&](int g, half8 (&xa0)[4], half8 (&xa1)[4], half8 (&xb0)[4], half8 (&xb1)[4]) {
+        const int gc = g < g1 ? g : (g1 - 1 > 0 ? g1 - 1 : 0);   // clamped: loads past the chunk re-read its last group (unused)
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const size_t e = ((size_t)min(g0, G - 1) * 4 + kk) * 64;
-        a0[kk] = A0[e]; a1[kk] = A1[e]; b0[kk] = B0[e]; b1[kk] = B1[e];
+        for (int kk = 0; kk < 4; ++kk) {
+            const size_t e = ((size_t)gc * 4 + kk) * 64;
+            xa0[kk] = A0[e]; xa1[kk] = A1[e]; xb0[kk] = B0[e]; xb1[kk] = B1[e];
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < kPF; ++j) fetch(g0 + j, a0[j], a1[j], b0[j], b1[j]);
+    for (int g = g0; g < g1; g += kPF) {
+        half8 na0[kPF][4], na1[kPF][4], nb0[kPF][4], nb1[kPF][4];
+#pragma unroll
+        for (int j = 0; j < kPF; ++j) fetch(g + kPF + j, na0[j], na1[j], nb0[j], nb1[j]);
+#pragma unroll
+        for (int j = 0; j < kPF; ++j) {
+            if (g + j < g1) {   // wave-uniform
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[j][kk], b0[j][kk], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[j][kk], b1[j][kk], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[j][kk], b0[j][kk], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[j][kk], b1[j][kk], acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kPF; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                a0[j][kk] = na0[j][kk]; a1[j][kk] = na1[j][kk]; b0[j][kk] = nb0[j][kk]; b1[j][kk] = nb1[j][kk];
+            }
     }
-    for (int g = g0; g < g1; ++g) {
-        half8 na0[4], na1[4], nb0[4], nb1[4];
-        const int gn = g + 1 < g1 ? g + 1 : g;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const size_t e = ((size_t)gn * 4 + kk) * 64;
-            na0[kk] = A0[e]; na1[kk] = A1[e]; nb0[kk] = B0[e]; nb1[kk] = B1[e];
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kk], b0[kk], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kk], b1[kk], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kk], b0[kk], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kk], b1[kk], acc[1][1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            a0[kk] = na0[kk]; a1[kk] = na1[kk]; b0[kk] = nb0[kk]; b1[kk] = nb1[kk];
-        }
-    }
+    if (stop_flag) return;
     // D: register r of lane (c, h) = dW[row = 32 to + rho(r, h)][col = 32 ti + c]
     const int O = net == 0 ? 4 : 1;
     const NetOff o = net_off(L, O);
@@ -686,7 +746,9 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
         constexpr int kMaxChunks = 32;
         float gs[kMaxChunks];
 #pragma unroll
-        for (int q = 0; q < kMaxChunks; ++q) gs[q] = q < a.chunks ? a.partial[(size_t)q * n + i] : 0.0f;
+        for (int q = 0; q < kMaxChunks; ++q) gs[q] = a.partial[(size_t)(q < a.chunks ? q : 0) * n + i];  // unconditional loads
+#pragma unroll
+        for (int q = 0; q < kMaxChunks; ++q) gs[q] = q < a.chunks ? gs[q] : 0.0f;
 #pragma unroll
         for (int w = kMaxChunks / 2; w >= 1; w >>= 1)
 #pragma unroll
@@ -746,7 +808,7 @@ __device__ __forceinline__ void pack_scatter(_Float16* __restrict__ img, int O, 
 template <int L>
 __global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
     PpoCtrl* c = a.ctrl;
-    if (a.take_step && c->stop) return;  // set by an EARLIER launch: uniform over the grid (SB3: no update after the early stop)
+    const int stop_flag = c->stop;       // set by an EARLIER launch: uniform over the grid; tested after the reduction below
     const unsigned int gen = c->gen;
     const int n = a.n;
     const int i = blockIdx.x * kApplyThreads + threadIdx.x;
@@ -763,6 +825,7 @@ __global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
         if (last_block && threadIdx.x < 4 && a.stats) a.stats[threadIdx.x] += red[4 + threadIdx.x];
         return;
     }
+    if (stop_flag) return;  // SB3: no update after the early stop
     // ---- squared norm, then a grid-wide barrier: every workgroup of this launch is resident (247 x 256 threads on 256 CUs)
     double sq = (double)g * g, unused = 0.0;
     block_sum2_f64<kApplyThreads>(sq, unused);
