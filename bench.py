@@ -281,8 +281,9 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
 
             cl()
             cl_s, cl_ts, cl_R = timed_region(rt, cl, min(repeats, 3))
-            cl_ms = env.last_rollout_ms()
-            pol_flop = 2.0 * ((L + 1) * 128 + 2 * 128 * 128 + 128 * 32)   # issued f16 MACs x 2 (padded tiles, as executed)
+            cl_ms = cl_s * 1e3   # bracket time per launch (back-to-back launches; rocprofv3's per-kernel average agrees with it,
+            #                      while the hipEvent pair of a queued launch can include part of its predecessor)
+            pol_flop = 2.0 * (16 * ((L + 16) // 16) * 128 + 2 * 128 * 128 + 128 * 32)   # f16 MACs x 2 as issued (padded tiles): PMC 81 920 at L = 17 / 24
             cl_tf = pol_flop * n * Kc / (cl_ms * 1e-3) / 1e12
             res["closed_loop"] = {
                 "what": "qr_rollout_policy: K x [obs -> policy MLP (L->120->120->120->4, f16 MFMA) -> Gaussian sample -> env.step] in "
@@ -293,7 +294,7 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
                              "flop_per_env_step": pol_flop, "traffic": None,
                              "note": "f16 matrix-core flop of the policy MLP as issued (160-180 v_mfma_f32_32x32x16_f16 per 64 envs); the "
                                      "kernel is one wave per SIMD: issue-order-bound between MFMA chain, sampling and the env step "
-                                     "(profiles/r02_pmc_compute.json: MFMA busy ~39 % of wave cycles)"}}
+                                     "(profiles/r02_pmc_compute.json: MFMA busy ~39 percent of wave cycles)"}}
             del state
         except Exception as ex:  # pragma: no cover
             res["closed_loop"] = {"error": repr(ex)}
