@@ -291,7 +291,11 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
                 "steps": Kc, "ms_per_step": cl_s * 1e3 / Kc, "value": n * rt.world * Kc / cl_s, "unit": "env-steps/s",
                 "kernel_us_per_step": cl_ms * 1e3 / Kc,
                 "roofline": {"bound": "mfma", "achieved": cl_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": cl_tf / MFMA_F16_PEAK_TF,
-                             "flop_per_env_step": pol_flop, "traffic": None,
+                             "flop_per_env_step": pol_flop,
+                             "traffic": None if pmc.get("closed_loop_hbm_bytes_per_step") is None else pmc["closed_loop_hbm_bytes_per_step"] * Kc,
+                             "hbm": None if pmc.get("closed_loop_hbm_bytes_per_step") is None else {
+                                 "achieved": pmc["closed_loop_hbm_bytes_per_step"] / (cl_ms * 1e-3 / Kc) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": pmc["closed_loop_hbm_bytes_per_step"] / (cl_ms * 1e-3 / Kc) / 1e9 / HBM_PEAK_GBS},
                              "note": "f16 matrix-core flop of the policy MLP as issued (160-180 v_mfma_f32_32x32x16_f16 per 64 envs); the "
                                      "kernel is one wave per SIMD: issue-order-bound between MFMA chain, sampling and the env step "
                                      "(profiles/r02_pmc_compute.json: MFMA busy ~39 percent of wave cycles)"}}

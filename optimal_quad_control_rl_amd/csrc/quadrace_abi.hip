@@ -414,6 +414,19 @@ int qr_step_launches(qr_env* e, int32_t K, const float* actions_dev, float* obs_
         return fail(QR_E_INVALID, "qr_step_launches: actions/obs/rew/done buffers are required");
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)e->cfg.num_envs;
+    // a caller that is itself capturing `stream` into a graph gets plain kernel nodes (a graph launch cannot be captured)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        for (int k = 0; k < K; ++k) {
+            qr::Params Pk = e->P;
+            if (Pk.term_obs) Pk.term_obs += (size_t)k * n * e->L;
+            QR_HIP(qr::launch_step(e->cfg.variant, Pk, actions_dev + (size_t)k * n * 4, obs_out_dev + (size_t)k * n * e->L,
+                                   rew_out_dev + (size_t)k * n, done_out_dev + (size_t)k * n,
+                                   trunc_out_dev ? trunc_out_dev + (size_t)k * n : nullptr, st));
+        }
+        e->timing_valid = false;
+        return QR_OK;
+    }
     qr_env::StepGraph& g = e->sg;
     const bool hit = g.exec && g.K == K && g.act == actions_dev && g.obs == obs_out_dev && g.rew == rew_out_dev &&
                      g.done == done_out_dev && g.trunc == trunc_out_dev && std::memcmp(&g.P, &e->P, sizeof(e->P)) == 0;
@@ -545,7 +558,9 @@ int qr_profile_steps(qr_env* e, int32_t K, const float* actions_dev, float* obs_
     for (auto& x : ev) QR_HIP(hipEventCreate(&x));
     for (int k = 0; k < K; ++k) {
         QR_HIP(hipEventRecord(ev[2 * k], st));
-        QR_HIP(qr::launch_step(e->cfg.variant, e->P, actions_dev + (size_t)k * n * 4, obs_out_dev + (size_t)k * n * e->L,
+        qr::Params Pk = e->P;
+        if (Pk.term_obs) Pk.term_obs += (size_t)k * n * e->L;   // terminal-observation rows [k][env]
+        QR_HIP(qr::launch_step(e->cfg.variant, Pk, actions_dev + (size_t)k * n * 4, obs_out_dev + (size_t)k * n * e->L,
                                rew_out_dev + (size_t)k * n, done_out_dev + (size_t)k * n,
                                trunc_out_dev ? trunc_out_dev + (size_t)k * n : nullptr, st));
         QR_HIP(hipEventRecord(ev[2 * k + 1], st));

@@ -89,8 +89,7 @@ __device__ __forceinline__ void store_obs(float* __restrict__ obs_out, int i, co
 // transposes through a wave-private LDS tile and writes the block with fully coalesced 16-byte-per-lane stores
 // (1 KiB per instruction).  LDS operations of one wave execute in order; the fences only pin the compiler.
 template <int V, int GA>
-__device__ __forceinline__ void store_obs_coalesced(float* __restrict__ tile, float* __restrict__ obs_out,
-                                                    size_t wave_first_env, int lane, const float* o) {
+__device__ __forceinline__ void obs_tile_write(float* __restrict__ tile, int lane, const float* o) {
     constexpr int L = obs_len<V, GA>();
     float* row = tile + lane * L;
     if constexpr (L % 4 == 0) {
@@ -103,6 +102,11 @@ __device__ __forceinline__ void store_obs_coalesced(float* __restrict__ tile, fl
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+template <int V, int GA>
+__device__ __forceinline__ void obs_tile_flush(const float* __restrict__ tile, float* __restrict__ obs_out, size_t wave_first_env,
+                                               int lane) {
+    constexpr int L = obs_len<V, GA>();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     constexpr int kVec = 16 * L;  // float4 elements in the block (64*L floats; 64*L*4 bytes is a multiple of 16)
     const float4* t4 = reinterpret_cast<const float4*>(tile);
@@ -114,6 +118,12 @@ __device__ __forceinline__ void store_obs_coalesced(float* __restrict__ tile, fl
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+template <int V, int GA>
+__device__ __forceinline__ void store_obs_coalesced(float* __restrict__ tile, float* __restrict__ obs_out,
+                                                    size_t wave_first_env, int lane, const float* o) {
+    obs_tile_write<V, GA>(tile, lane, o);
+    obs_tile_flush<V, GA>(tile, obs_out, wave_first_env, lane);
 }
 
 // Terminal observation (optional, Params::term_obs): the gate-frame observation of the final state of an episode, written
@@ -384,7 +394,13 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
                 eps[0] = bm_ra * bm_ca; eps[1] = bm_ra * bm_sa; eps[2] = bm_rb * bm_cb; eps[3] = bm_rb * bm_sb;
             }
         };
-        policy_forward<L>(W, lane, o, mean, noise_slice);
+        // The observation row of this step (the policy's input) is stored under the third layer's MFMAs: LDS transpose in
+        // slot 0, coalesced block store in slot 2 (full waves; the ragged tail wave stores its rows afterwards).
+        auto obs_slice = [&](int slot) {
+            if (slot == 0 && full_wave) obs_tile_write<V, GA>(tile, lane, o);
+            if (slot == 2 && full_wave) obs_tile_flush<V, GA>(tile, obs_out + (size_t)k * n * L, (size_t)wave_first, lane);
+        };
+        policy_forward<L>(W, lane, o, mean, noise_slice, obs_slice);
         QR_TICK(P, 9);
         float a[4] = {mean[0], mean[1], mean[2], mean[3]};
         float logp = A.logp_const;
@@ -395,9 +411,8 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
             logp = fmaf(-0.5f * e, e, logp);
         }
         QR_TICK(P, 10);
-        // rollout buffer row t: the observation the action was computed from, the unclipped action, its log-prob
-        if (full_wave) store_obs_coalesced<V, GA>(tile, obs_out + (size_t)k * n * L, (size_t)wave_first, lane, o);
-        else if (active) store_obs<V, GA>(obs_out + (size_t)k * n * L, i, o);
+        // rollout buffer row t: the observation the action was computed from (stored above), the unclipped action, its log-prob
+        if (!full_wave && active) store_obs<V, GA>(obs_out + (size_t)k * n * L, i, o);
         if (active) {
             stream_store(act_out + (size_t)k * n + i, make_float4(a[0], a[1], a[2], a[3]));
             stream_store(logp_out + (size_t)k * n + i, logp);

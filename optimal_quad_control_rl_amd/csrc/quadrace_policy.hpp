@@ -140,10 +140,11 @@ __device__ __forceinline__ void policy_layer(const half8* __restrict__ W, int la
 
 // Full policy forward for the wave's 64 envs.  o[L] = this lane's observation (lane = env); mean[4] = action means
 // of this lane's env.  Wlds = packed f16 weights in LDS (PolicyDims<L> layout).  Must be called by all 64 lanes.
-// `filler(slot)`, slot = 0..31, is called once per K-step of the second hidden layer (see policy_layer).
-template <int L, class Filler = NoFiller>
+// `filler2(slot)` / `filler3(slot)`, slot = 0..31, are called once per K-step of the second / third hidden layer (see
+// policy_layer): independent caller work that runs in the MFMA shadow.
+template <int L, class Filler2 = NoFiller, class Filler3 = NoFiller>
 __device__ __forceinline__ void policy_forward(const half8* __restrict__ Wlds, int lane, const float* o, float mean[4],
-                                               Filler&& filler = Filler()) {
+                                               Filler2&& filler2 = Filler2(), Filler3&& filler3 = Filler3()) {
     using D = PolicyDims<L>;
     // ---- layer 1 B operands: input k = 16s + 8h + j; lanes 0..31 supply h = 0, lanes 32..63 h = 1 (of env l-32)
     half8 in1[2][D::kSteps1];
@@ -162,8 +163,8 @@ __device__ __forceinline__ void policy_forward(const half8* __restrict__ Wlds, i
     }
     half8 h1[2][8], h2[2][8];
     policy_layer<D::kSteps1>(Wlds, lane, in1, h1);
-    policy_layer<8>(Wlds + D::kOff2, lane, h1, h2, filler);
-    policy_layer<8>(Wlds + D::kOff3, lane, h2, h1);
+    policy_layer<8>(Wlds + D::kOff2, lane, h1, h2, filler2);
+    policy_layer<8>(Wlds + D::kOff3, lane, h2, h1, filler3);
     // ---- output layer: one 32-row tile, rows 0..3 = action means
     f32x16p acc0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     f32x16p acc1 = acc0;

@@ -142,7 +142,9 @@ class Quadcopter3DGates(_Base):
     Extra keyword-only arguments (not in the reference): `device` (cuda ordinal), `seed`, `residual`
     ('default' = the reference's NNDroneModel weights, None = no residual model, or a 740-float blob),
     `env_id_base` (global index of env 0 when sharding over GPUs), `infos_mode` ('reference' reproduces the
-    shared-dict behaviour of R:589-594, 'per_env' gives one dict per done env, 'none' skips the list).
+    shared-dict behaviour of R:589-594, 'per_env' gives one dict per done env, 'sb3' gives one dict per done env whose
+    `terminal_observation` is the TRUE final observation of the episode -- what SB3's time-limit bootstrap expects --
+    and `TimeLimit.truncated` only for the envs that hit the time limit, 'none' skips the list).
     """
 
     VARIANT = QR_VARIANT_E2E
@@ -401,6 +403,8 @@ class Quadcopter3DGates(_Base):
         """SB3-facing step: NumPy in, NumPy out (one H->D copy of the actions, one batch of async D->H copies into
         pinned buffers, one synchronisation).  Use step_device() to stay on the GPU."""
         act = self._to_dev(self.actions, torch.float32)
+        if self.infos_mode == "sb3" and getattr(self, "_term_obs_buf", None) is None:
+            self.set_terminal_obs_buffer(torch.zeros((self.num_envs, self.state_len), dtype=torch.float32, device=self.device))
         dev = self.step_device(act)
         host = self._host_buffers()
         for h, d in zip(host, dev):
@@ -425,6 +429,14 @@ class Quadcopter3DGates(_Base):
                 shared["TimeLimit.truncated"] = True
             return [shared] * self.num_envs
         infos = [{} for _ in range(self.num_envs)]
+        if self.infos_mode == "sb3":
+            if done_np.any():
+                idx = np.nonzero(done_np)[0]
+                term = self._term_obs_buf[torch.as_tensor(idx, device=self.device)].cpu().numpy()   # rows written by the step kernel
+                for j, i in enumerate(idx):
+                    infos[i]["terminal_observation"] = term[j]
+                    infos[i]["TimeLimit.truncated"] = bool(trunc_np[i])
+            return infos
         if done_np.any():
             for i in np.nonzero(done_np)[0]:
                 infos[i]["terminal_observation"] = obs_np[i]

@@ -320,3 +320,85 @@ def test_derives_from_sb3_vecenv_when_present(tmp_path):
     env = dict(os.environ, PYTHONPATH=str(tmp_path) + os.pathsep + os.environ.get("PYTHONPATH", ""))
     out = subprocess.run([sys.executable, "-c", SB3_CHILD % root], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "sb3 child ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_step_launches_graph_follows_configuration_changes():
+    """qr_step_launches replays a captured graph while (K, buffers, env configuration) are unchanged; the kernel parameters
+    are baked into the graph nodes, so ANY configuration change between two calls must re-capture: same buffers, but
+    max_steps / pause / disturbance table edited in between -- results must equal a fresh env doing the same."""
+    from optimal_quad_control_rl_amd import Quadcopter3DGates, TRAIN_DISTURBANCE_RANGES, zigzag_track
+
+    n, K = 4096, 12
+    dev = torch.device("cuda", 0)
+    acts = torch.rand((K, n, 4), device=dev, generator=torch.Generator(device=dev).manual_seed(5)) * 2 - 1
+
+    def make():
+        e = Quadcopter3DGates(n, *zigzag_track(), gates_ahead=1, seed=3, infos_mode="none")
+        e.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+        return e
+
+    def buffers(e):
+        L = e.state_len
+        return (torch.empty((K, n, L), device=dev), torch.empty((K, n), device=dev),
+                torch.empty((K, n), dtype=torch.uint8, device=dev), torch.empty((K, n), dtype=torch.uint8, device=dev))
+
+    a, b = make(), make()
+    out_a, out_b = buffers(a), buffers(b)
+    a.reset_device(); b.reset_device()
+    a.step_sequence_device(acts, out_a)                 # captures the graph
+    a.step_sequence_device(acts, out_a)                 # replays it
+    b.rollout_device(acts, out_b); b.rollout_device(acts, out_b)
+    assert all(torch.equal(x, y) for x, y in zip(out_a, out_b))
+    for e in (a, b):
+        e.max_steps = 30                                # every env is truncated inside the next window
+    a.step_sequence_device(acts, out_a)                 # same K, same buffers: must NOT replay the old parameters
+    b.rollout_device(acts, out_b)
+    assert all(torch.equal(x, y) for x, y in zip(out_a, out_b)) and int(out_a[3].sum()) >= n
+    for e in (a, b):
+        e.pause = True
+    before = a.get_state_tensors()[0].clone()
+    a.step_sequence_device(acts, out_a); b.rollout_device(acts, out_b)
+    assert torch.equal(a.get_state_tensors()[0], before) and torch.equal(out_a[1], out_b[1]) and int(out_a[2].sum()) == 0
+    for e in (a, b):
+        e.pause = False
+        e.disturbance_scale = 0.0                       # table edit: resets draw zero disturbances from now on
+        e.max_steps = 5
+    a.step_sequence_device(acts, out_a); b.rollout_device(acts, out_b)
+    assert all(torch.equal(x, y) for x, y in zip(out_a, out_b))
+    assert float(a.get_state_tensors()[1].abs().max()) == 0.0
+    # the action CONTENT may change under the same pointer: the graph reads the buffer at replay time
+    acts2 = acts.clone()
+    acts.mul_(-1.0)
+    a.step_sequence_device(acts, out_a); b.rollout_device(acts, out_b)
+    assert all(torch.equal(x, y) for x, y in zip(out_a, out_b))
+    a.close(); b.close()
+
+
+def test_sb3_infos_mode_hands_out_true_terminal_observations():
+    """infos_mode="sb3": per-env dicts; `terminal_observation` = the observation of the episode's FINAL state (not the first row of
+    the next episode, which is what obs[i] already holds), `TimeLimit.truncated` only where the time limit ended the episode."""
+    from optimal_quad_control_rl_amd import Quadcopter3DGatesINDI, square_track
+
+    n = 512
+    env = Quadcopter3DGatesINDI(n, *square_track(), gates_ahead=1, seed=2, infos_mode="sb3")
+    env.max_steps = 25
+    env.reset()
+    rng = np.random.default_rng(4)
+    seen = 0
+    for k in range(60):
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        pre = env.world_states.copy(); pre_t = env.target_gates.copy(); pre_s = env.step_counts.copy()
+        obs, rew, done, infos = env.step(a)
+        assert len(infos) == n and all((("terminal_observation" in infos[i]) == bool(done[i])) for i in range(n))
+        if done.any():
+            # (the values themselves are pinned against the oracle in test_terminal_observation_vs_oracle_and_across_kernels)
+            for i in np.nonzero(done)[0][:8]:
+                t = infos[i]["terminal_observation"]
+                assert t.shape == (env.state_len,) and np.isfinite(t).all()
+                assert not np.allclose(t, obs[i])                      # not the post-reset row
+                assert infos[i]["TimeLimit.truncated"] == bool(pre_s[i] + 1 >= 25)
+                # position part of the observation is continuous with the pre-step state (one 10 ms Euler step apart)
+                assert np.abs(t[5:8] - pre[i][5:8]).max() < 1.0
+            seen += int(done.sum())
+    assert seen > n
+    env.close()

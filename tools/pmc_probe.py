@@ -24,5 +24,13 @@ out = (torch.empty((K, n, L), device="cuda"), torch.empty((K, n), device="cuda")
 env.reset_device()
 env.step_sequence_device(actions, out)
 env.rollout_device(actions, out)
+# closed-loop kernel (policy MLP + sampling + env step), K steps per launch
+from optimal_quad_control_rl_amd.policy import MfmaPolicy
+from optimal_quad_control_rl_amd.ppo import ActorCritic
+torch.manual_seed(0)
+pol = MfmaPolicy(L, 0).load_torch(ActorCritic(L, 4).cuda().pi)
+res = None
+for r in range(3):
+    res = env.rollout_policy_device(pol, K, torch.zeros(4), noise_seed=0, first_step=r * K, out=None if res is None else res[:6])
 torch.cuda.synchronize()
 print("pmc probe done")

@@ -35,13 +35,15 @@ def summarise(rows):
     cal = [v for v in cal if v > 0.9 * max(cal)]  # only the 256 MiB calibration copies, not small H2D uploads
     step = [v for k, v in rows if "step_kernel" in k]
     roll = [v for k, v in rows if "rollout_kernel" in k]
-    return (sum(cal) / len(cal), sum(step[4:]) / max(1, len(step[4:])), sum(roll) / max(1, len(roll)))
+    rpol = [v for k, v in rows if "rollout_policy_kernel" in k]
+    return (sum(cal) / len(cal), sum(step[4:]) / max(1, len(step[4:])), sum(roll) / max(1, len(roll)),
+            sum(rpol) / max(1, len(rpol)))
 
 
 def main(variant, n, fetch_csv, write_csv, out="profiles/pmc_summary.json"):
     n = int(n)
-    f_cal, f_step, f_roll = summarise(load(fetch_csv, "FETCH_SIZE"))
-    w_cal, w_step, w_roll = summarise(load(write_csv, "WRITE_SIZE"))
+    f_cal, f_step, f_roll, f_rpol = summarise(load(fetch_csv, "FETCH_SIZE"))
+    w_cal, w_step, w_roll, w_rpol = summarise(load(write_csv, "WRITE_SIZE"))
     f_scale = CAL_BYTES / (f_cal * 1024.0)  # bytes per reported KiB*1024 (expected 2.0 on gfx950)
     w_scale = CAL_BYTES / (w_cal * 1024.0)
     res = {
@@ -54,6 +56,9 @@ def main(variant, n, fetch_csv, write_csv, out="profiles/pmc_summary.json"):
                                     "read_bytes": f_roll * 1024 * f_scale / K_FUSED,
                                     "write_bytes": w_roll * 1024 * w_scale / K_FUSED},
     }
+    res["rollout_policy_kernel_per_step"] = {"read_bytes": f_rpol * 1024 * f_scale / K_FUSED, "write_bytes": w_rpol * 1024 * w_scale / K_FUSED}
+    res["closed_loop_hbm_bytes_per_step"] = (res["rollout_policy_kernel_per_step"]["read_bytes"] +
+                                             res["rollout_policy_kernel_per_step"]["write_bytes"])
     res["hbm_bytes_per_launch"] = res["step_kernel"]["read_bytes"] + res["step_kernel"]["write_bytes"]
     res["fused_hbm_bytes_per_step"] = (res["rollout_kernel_per_step"]["read_bytes"] +
                                        res["rollout_kernel_per_step"]["write_bytes"])
