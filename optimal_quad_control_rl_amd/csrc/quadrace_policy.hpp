@@ -93,7 +93,7 @@ __device__ __forceinline__ uint32_t relu_pack2(float lo, float hi) {
 // BETWEEN the MFMAs in program order to overlap with them.  The schedule is therefore written out and pinned with
 // sched_barrier (left to itself the scheduler emitted "ds_read, s_waitcnt lgkmcnt(0), MFMA, MFMA" per K-step -- the LDS
 // latency exposed 32 times per layer -- and one lump of 48 pack instructions per tile behind the MFMAs):
-//   K-step g of output tile t:   ds_read of tile t+1's operand g   (a whole tile ahead of its use)
+//   K-step g of output tile t:   ds_read of the operand 4 K-steps ahead (ring of 4)
 //                                2 MFMAs (env tiles 0 and 1) on tile t's operand g
 //                                1/KS of the ReLU + f16 pack of tile t-1 (its accumulators finished a tile ago)
 //                                `filler(slot)`: a slice of INDEPENDENT caller work (the closed-loop kernel draws its
@@ -101,24 +101,35 @@ __device__ __forceinline__ uint32_t relu_pack2(float lo, float hi) {
 struct NoFiller {
     __device__ __forceinline__ void operator()(int) const {}
 };
-template <int KS, class Filler = NoFiller>
+// kChainOut (third hidden layer): the output layer's image follows this layer's in LDS, so the ring simply keeps fetching, and
+// the output layer's K-steps 0..5 -- which only need this layer's tiles 0..2 -- are issued in the groups that pack tile 3
+// (they have no MFMAs of their own); K-steps 6 and 7 follow.  accO[et] = the output tile (rows 0..3 = action means).
+template <int KS, class Filler = NoFiller, bool kChainOut = false>
 __device__ __forceinline__ void policy_layer(const half8* __restrict__ W, int lane, const half8 (&in)[2][KS],
-                                             half8 (&out)[2][8], Filler&& filler = Filler()) {
+                                             half8 (&out)[2][8], Filler&& filler = Filler(), f32x16p* accO = nullptr) {
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     f32x16p acc[2][2];  // [tile parity][env tile]
-    half8 a[2][KS];     // [tile parity][K-step]: A operands, fetched one tile ahead of their MFMAs
-    u32x4p o32[2][8];   // the packed outputs, dword by dword
+    constexpr int kTotal = 4 * KS + (kChainOut ? 8 : 0);   // image elements (K-step operands) this call consumes
+    constexpr int D = KS < 4 ? KS : 4;   // A operands are fetched D K-steps (>= 256 cycles of MFMA time) ahead, into a ring of
+    half8 a[D];                          // D registers-quads (a whole-tile double buffer cost 64 VGPRs and pushed the closed-loop
+    u32x4p o32[2][8];                    // kernel into AGPR copies); o32 = the packed outputs, dword by dword
 #pragma unroll
-    for (int s = 0; s < KS; ++s) a[0][s] = W[s * 64 + lane];
+    for (int q = 0; q < D; ++q) a[q] = W[q * 64 + lane];   // group q = t KS + g reads element (t KS + g) of the layer image
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t <= 4; ++t) {
 #pragma unroll
         for (int g = 0; g < KS; ++g) {
-            if (t < 3) a[(t + 1) & 1][g] = W[((t + 1) * KS + g) * 64 + lane];
+            const int q = t * KS + g;
             if (t < 4) {
-                acc[t & 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t & 1][g], in[0][g], g == 0 ? zero : acc[t & 1][0], 0, 0, 0);
-                acc[t & 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t & 1][g], in[1][g], g == 0 ? zero : acc[t & 1][1], 0, 0, 0);
+                acc[t & 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q % D], in[0][g], g == 0 ? zero : acc[t & 1][0], 0, 0, 0);
+                acc[t & 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q % D], in[1][g], g == 0 ? zero : acc[t & 1][1], 0, 0, 0);
+                if (q + D < kTotal) a[q % D] = W[(q + D) * 64 + lane];
+            }
+            if (kChainOut && t == 4 && g < 6) {
+                accO[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q % D], __builtin_bit_cast(half8, o32[0][g]), g == 0 ? zero : accO[0], 0, 0, 0);
+                accO[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q % D], __builtin_bit_cast(half8, o32[1][g]), g == 0 ? zero : accO[1], 0, 0, 0);
+                if (q + D < kTotal) a[q % D] = W[(q + D) * 64 + lane];
             }
             if (t > 0) {  // dwords [16 g / KS, 16 (g + 1) / KS) of the previous tile: d = 8 et + 4 s + dd
                 const int p = (t - 1) & 1;
@@ -136,6 +147,14 @@ __device__ __forceinline__ void policy_layer(const half8* __restrict__ W, int la
     for (int et = 0; et < 2; ++et)
 #pragma unroll
         for (int k = 0; k < 8; ++k) out[et][k] = __builtin_bit_cast(half8, o32[et][k]);
+    if (kChainOut) {
+#pragma unroll
+        for (int g = 6; g < 8; ++g) {
+            const int q = 4 * KS + g;
+            accO[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q % D], out[0][g], accO[0], 0, 0, 0);
+            accO[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q % D], out[1][g], accO[1], 0, 0, 0);
+        }
+    }
 }
 
 // Full policy forward for the wave's 64 envs.  o[L] = this lane's observation (lane = env); mean[4] = action means
@@ -164,16 +183,11 @@ __device__ __forceinline__ void policy_forward(const half8* __restrict__ Wlds, i
     half8 h1[2][8], h2[2][8];
     policy_layer<D::kSteps1>(Wlds, lane, in1, h1);
     policy_layer<8>(Wlds + D::kOff2, lane, h1, h2, filler2);
-    policy_layer<8>(Wlds + D::kOff3, lane, h2, h1, filler3);
-    // ---- output layer: one 32-row tile, rows 0..3 = action means
-    f32x16p acc0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    f32x16p acc1 = acc0;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const half8 a = Wlds[D::kOff4 + s * 64 + lane];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, h1[0][s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, h1[1][s], acc1, 0, 0, 0);
-    }
+    // third hidden layer + output layer (one 32-row tile, rows 0..3 = action means) as one pipelined sequence
+    static_assert(D::kOff4 == D::kOff3 + 4 * 8 * 64, "the output image must follow the third layer's");
+    f32x16p accO[2];
+    policy_layer<8, Filler3, true>(Wlds + D::kOff3, lane, h2, h1, static_cast<Filler3&&>(filler3), accO);
+    const f32x16p acc0 = accO[0], acc1 = accO[1];
     // rows 0..3 live in registers 0..3 of lanes 0..31 (h = 0) of each env tile: bring tile 1 to lanes 32..63
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
