@@ -209,7 +209,8 @@ int qr_ppo_num_params(const qr_ppo* ppo);
 /* builds the f16 operand images from the parameters: call once before the first qr_ppo_minibatch and after any
  * change of theta made outside this library */
 int qr_ppo_pack(qr_ppo* ppo, const float* theta_dev, void* stream);
-/* gradient only (no clipping, no optimiser step): grad_out_dev [num_params + 4] -- the gradient followed by this
+/* gradient only (no clipping, no optimiser step; the operand images are rebuilt first unless theta_dev is the vector they were
+ * last built from / kept in step with): grad_out_dev [num_params + 4] -- the gradient followed by this
  * minibatch's statistics {sum of per-sample surrogate losses, sum of squared value errors, sum of approx-KL terms, number
  * of clipped samples}; stats_dev (may be NULL) float[4] is ACCUMULATED into with the same four sums */
 int qr_ppo_grad(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const float* act_dev,

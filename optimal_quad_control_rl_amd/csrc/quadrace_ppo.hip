@@ -969,6 +969,7 @@ struct qr_ppo {
     const int32_t* epoch_idx = nullptr;
     int epoch_B = 0, epoch_count = 0, epoch_cursor = 0;
     float target_kl = 0.0f;        // <= 0: no early stop
+    const float* packed_theta = nullptr;   // parameter vector the operand images were last built from (pack / apply)
 };
 
 namespace qr {
@@ -1164,6 +1165,7 @@ int qr_ppo_num_params(const qr_ppo* p) { return p ? p->num_params : ppofail(QR_E
 int qr_ppo_pack(qr_ppo* p, const float* theta_dev, void* stream) {
     if (!p || !theta_dev) return ppofail(QR_E_INVALID, "qr_ppo_pack: null argument");
     PPO_HIP(hipSetDevice(p->device));
+    p->packed_theta = theta_dev;
     return dispatch_L(p->L, [&](auto Lc) { return PpoOps<decltype(Lc)::value>::pack(p, theta_dev, (hipStream_t)stream); });
 }
 
@@ -1213,7 +1215,12 @@ int qr_ppo_grad(qr_ppo* p, const float* theta_dev, const float* obs_dev, const f
     hipStream_t st = (hipStream_t)stream;
     return dispatch_L(p->L, [&](auto Lc) {
         constexpr int L = decltype(Lc)::value;
-        if (int r = PpoOps<L>::pack(p, theta_dev, st)) return r;
+        // the operand images are current when they were built from this vector by qr_ppo_pack or kept in step with it by
+        // qr_ppo_minibatch / qr_ppo_apply (callers that edit theta themselves call qr_ppo_pack, as documented)
+        if (p->packed_theta != theta_dev) {
+            if (int r = PpoOps<L>::pack(p, theta_dev, st)) return r;
+            p->packed_theta = theta_dev;
+        }
         int chunks = 0;
         if (int r = PpoOps<L>::grad(p, b, st, &chunks)) return r;
         qr::ApplyArgs a{};
@@ -1236,6 +1243,7 @@ int qr_ppo_minibatch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam
         return rc;
     if (!adam_m_dev || !adam_v_dev || adam_step < 1) return ppofail(QR_E_INVALID, "qr_ppo_minibatch: bad Adam state");
     PPO_HIP(hipSetDevice(p->device));
+    p->packed_theta = theta_dev;   // the apply kernel keeps the images in step with this vector
     hipStream_t st = (hipStream_t)stream;
     return dispatch_L(p->L, [&](auto Lc) {
         constexpr int L = decltype(Lc)::value;
@@ -1262,6 +1270,7 @@ int qr_ppo_apply(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_d
     if (!p || !theta_dev || !adam_m_dev || !adam_v_dev || !grad_dev || adam_step < 1 || B < 1)
         return ppofail(QR_E_INVALID, "qr_ppo_apply: bad argument");
     PPO_HIP(hipSetDevice(p->device));
+    p->packed_theta = theta_dev;
     hipStream_t st = (hipStream_t)stream;
     return dispatch_L(p->L, [&](auto Lc) {
         constexpr int L = decltype(Lc)::value;
