@@ -36,7 +36,6 @@
 
 namespace qr {
 
-constexpr int kPpoBlock = 256;
 constexpr int kH = kPolHidden;  // 120
 
 struct NetOff { int w1, b1, w2, b2, w3, b3, w4, b4, total; };
