@@ -90,8 +90,11 @@ def make_env(variant, n, ga, env_id_base, seed=0, residual="default"):
 # distributed plumbing: one process per GPU (RCCL) -- or per CPU rank over gloo in tests/test_bench_gloo.py
 # ---------------------------------------------------------------------------------------------------------------------
 class Runtime:
-    def __init__(self, rank=0, local_rank=0, world=1, device=None, use_cuda=True):
+    def __init__(self, rank=0, local_rank=0, world=1, device=None, use_cuda=True, collectives=None):
         self.rank, self.local_rank, self.world, self.device, self.use_cuda = rank, local_rank, world, device, use_cuda
+        # collectives on: a process group exists.  Always for world > 1; QR_BENCH_FORCE_DIST=1 also turns it on for ONE rank, so
+        # that the RCCL code path (init, barrier, MAX all-reduce, all-gather, config 4) can be exercised on a 1-GPU box
+        self.collectives = (world > 1) if collectives is None else bool(collectives)
 
     @classmethod
     def from_env(cls, expected_world):
@@ -105,10 +108,12 @@ class Runtime:
             raise SystemExit(f"--gpus {expected_world} but WORLD_SIZE={world}")
         assert torch.cuda.is_available(), "bench.py needs an MI355X"
         torch.cuda.set_device(local_rank)
-        if world > 1:
+        collectives = world > 1 or os.environ.get("QR_BENCH_FORCE_DIST", "0") == "1"
+        if collectives:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        return cls(rank, local_rank, world, torch.device("cuda", local_rank), True)
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        return cls(rank, local_rank, world, torch.device("cuda", local_rank), True, collectives)
 
     def env_id_base(self, envs_per_rank):
         """global index of this rank's env 0: rank r owns global envs [r n, (r + 1) n) (keys the reset RNG stream)"""
@@ -122,14 +127,14 @@ class Runtime:
 
     def barrier(self):
         self.sync()
-        if self.world > 1:
+        if self.collectives:
             import torch.distributed as dist
 
             dist.barrier()
             self.sync()
 
     def max_over_ranks(self, x):
-        if self.world == 1:
+        if not self.collectives:
             return float(x)
         import torch
         import torch.distributed as dist
@@ -139,7 +144,7 @@ class Runtime:
         return float(t.item())
 
     def finish(self):
-        if self.world > 1:
+        if self.collectives:
             import torch.distributed as dist
 
             dist.barrier()
@@ -409,13 +414,13 @@ def run(args, rt, env_factory=make_env, closed_loop=True):
     result.update(m)
 
     # --- rollout-boundary exchange: RCCL all-gather of [obs | reward | done] of this run's shard ------------------------
-    if rt.world > 1 and not args.no_exchange:
+    if rt.collectives and not args.no_exchange:
         Kx = min(K, 64)
         result["exchange"] = exchange_probe(rt, out[0][:Kx], out[1][:Kx], out[2][:Kx])
     del out
 
     # --- BASELINE config 4: 32 768 envs per GPU (262 144 on 8), all-gather of every rollout --------------------------------
-    if rt.world > 1 and not args.no_exchange and not args.no_extras:
+    if rt.collectives and not args.no_exchange and not args.no_extras:
         import torch
 
         n4, K4 = 32768 if n >= 32768 else n, min(K, 64)
