@@ -815,6 +815,10 @@ __global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
     __shared__ float red[8];
     __shared__ double norm_sq_s;
     __shared__ float kl_s;
+    // Adam state and parameter of this element: loaded NOW, together with the chunk partials, so that their round trip is over
+    // before the grid barrier releases (they do not depend on the norm): measured -0.15 us
+    const bool owns = a.take_step && i < n;
+    const float m_in = owns ? a.m[i] : 0.0f, v_in = owns ? a.v[i] : 0.0f, th_in = owns ? a.theta[i] : 0.0f;
     const float g = reduce_grad_element(a, i, red);
     if (a.grad_out) {
         if (i < n) a.grad_out[i] = g;
@@ -880,11 +884,11 @@ __global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
         const float norm = (float)sqrt(norm_sq);
         const float clip = fminf(1.0f, a.max_norm / (norm + 1e-6f));  // torch.nn.utils.clip_grad_norm_
         const float gc = g * clip;
-        const float mi = a.beta1 * a.m[i] + (1.0f - a.beta1) * gc;
-        const float vi = a.beta2 * a.v[i] + (1.0f - a.beta2) * gc * gc;
+        const float mi = a.beta1 * m_in + (1.0f - a.beta1) * gc;
+        const float vi = a.beta2 * v_in + (1.0f - a.beta2) * gc * gc;
         a.m[i] = mi;
         a.v[i] = vi;
-        const float th = a.theta[i] - (a.lr / a.bc1) * mi / (sqrtf(vi) / a.bc2_sqrt + a.eps);  // torch.optim.Adam
+        const float th = th_in - (a.lr / a.bc1) * mi / (sqrtf(vi) / a.bc2_sqrt + a.eps);  // torch.optim.Adam
         a.theta[i] = th;
         // operand images of the next minibatch: this parameter's f16 copies (log_std has none)
         const int n4 = net_off(L, 4).total, n1 = net_off(L, 1).total;
