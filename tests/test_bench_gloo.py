@@ -65,6 +65,16 @@ class CpuBenchEnv:
         pass
 
 
+
+def _free_port():
+    """a TCP port the kernel just handed out (a pid-derived port collided with a socket in TIME_WAIT once)"""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -98,7 +108,7 @@ def _worker(rank, world, port, tmp):
 
 
 def test_bench_multirank_path_world2(tmp_path):
-    port = 33500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
 

@@ -38,6 +38,16 @@ class CpuStandInEnv:
         return tuple(torch.stack([o[j] for o in outs]) for j in range(4))
 
 
+
+def _free_port():
+    """a TCP port the kernel just handed out (a pid-derived port collided with a socket in TIME_WAIT once)"""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, n_global, K, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -68,7 +78,7 @@ def _worker(rank, world, port, n_global, K, tmp):
 
 
 def test_world2_sharded_rollout_and_allgather(tmp_path):
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_worker, args=(2, port, 64, 150, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
 
@@ -132,7 +142,7 @@ def _ddp_worker(rank, world, port, tmp):
 
 
 def test_world2_gradient_averaging_keeps_ranks_identical(tmp_path):
-    port = 31500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ddp_ok").exists()
 
@@ -172,6 +182,6 @@ def _kl_worker(rank, world, port, tmp):
 
 
 def test_world2_target_kl_decision_is_collective(tmp_path):
-    port = 35500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_kl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "kl_ok").exists()
