@@ -449,3 +449,36 @@ def test_data_parallel_training_over_rccl_on_one_rank():
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["world_size"] == 1 and j["train_steps"] >= 2e6 and j["native_update"] and j["fused_collect"]
     assert np.isfinite(j["eval_gates_per_12s"]) and j["train_Msteps_per_s"] > 1.0
+
+
+def test_numpy_step_path_buffers_and_async_semantics():
+    """SB3-facing NumPy path: same numbers as the device path; the observation array is the env's own (alternating) pinned buffer
+    -- intact during the NEXT step, recycled by the one after --, rewards / dones are fresh arrays; step_async() enqueues the
+    device work and step_wait() without a new step_async() steps again with the stored actions (reference behaviour, R:498-501)."""
+    from optimal_quad_control_rl_amd import Quadcopter3DGatesINDI, square_track
+
+    n = 1024
+    a_env = Quadcopter3DGatesINDI(n, *square_track(), gates_ahead=1, seed=5, infos_mode="reference")
+    b_env = Quadcopter3DGatesINDI(n, *square_track(), gates_ahead=1, seed=5, infos_mode="none")
+    o0 = a_env.reset()
+    b_env.reset_device()
+    rng = np.random.default_rng(8)
+    acts = [rng.uniform(-1, 1, (n, 4)).astype(np.float32) for _ in range(4)]
+    outs = []
+    for k in range(3):
+        a_env.step_async(acts[k])
+        obs, rew, done, infos = a_env.step_wait()
+        d_obs, d_rew, d_done, _ = b_env.step_device(torch.as_tensor(acts[k]).cuda())
+        assert np.array_equal(obs, d_obs.cpu().numpy()) and np.array_equal(rew, d_rew.cpu().numpy())
+        assert np.array_equal(done, d_done.cpu().numpy().astype(bool)) and len(infos) == n
+        outs.append((obs, obs.copy(), rew, rew.copy()))
+    assert np.array_equal(outs[1][0], outs[1][1])                 # step 1's array survived step 2
+    assert outs[0][0] is not outs[1][0] and np.shares_memory(outs[0][0], outs[2][0])   # two buffers alternate
+    assert np.array_equal(outs[0][2], outs[0][3]) and not np.shares_memory(outs[0][2], outs[2][2])   # rewards are never recycled
+    # step_wait() again, no step_async(): one more step with the stored actions
+    obs, rew, done, _ = a_env.step_wait()
+    d_obs, d_rew, _, _ = b_env.step_device(torch.as_tensor(acts[2]).cuda())
+    assert np.array_equal(obs, d_obs.cpu().numpy()) and np.array_equal(rew, d_rew.cpu().numpy())
+    with pytest.raises(ValueError):
+        a_env.step(np.zeros((n, 3), dtype=np.float32))
+    a_env.close(); b_env.close()
