@@ -180,9 +180,18 @@ class _Quad3DBase(_Base):
     def step_wait(self):
         self._act_h.copy_(torch.as_tensor(np.ascontiguousarray(self.actions, dtype=np.float32)))
         self._act_d.copy_(self._act_h, non_blocking=True)
-        st, rew, done, trunc = self.step_device(self._act_d)
-        packed = [t.cpu() for t in (st, rew, done, trunc)]   # .cpu() synchronises the stream
-        states, rewards = packed[0].numpy(), packed[1].numpy()
+        dev = self.step_device(self._act_d)
+        # async D->H into pinned buffers, ONE synchronisation (two alternating sets: like upstream, which hands out its own
+        # self.states, the state array is the env's buffer -- it survives the next step and is recycled by the one after)
+        if getattr(self, "_host_sets", None) is None:
+            self._host_sets = tuple(tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in dev) for _ in range(2))
+            self._host_flip = 0
+        self._host_flip ^= 1
+        packed = self._host_sets[self._host_flip]
+        for h, d in zip(packed, dev):
+            h.copy_(d, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        states, rewards = packed[0].numpy(), packed[1].numpy().copy()
         dones, truncs = packed[2].numpy().astype(bool), packed[3].numpy().astype(bool)
         # Write info dicts: upstream builds `[{}] * num_envs`, i.e. ONE dict shared by every env
         info = {}
