@@ -350,6 +350,42 @@ def host_path_probe(variant, n, ga):
             "ms_per_step": dt * 1e3, "value": n / dt, "unit": "env-steps/s"}
 
 
+def config5_probe(n, iters=3):
+    """BASELINE config 5 as a whole loop, short: PPO on the 4-gate square track with the E2E model (residual MLPs +
+    disturbances), reference hyper-parameters where they are the reference's (gamma 0.999, 10 epochs, 3 x 120 ReLU nets, R:784-795;
+    SB3's time-limit bootstrap) and this build's rollout shape (n envs x 32 steps, 16 384-row minibatches).  Collect =
+    qr_rollout_policy, GAE = qr_ppo_gae, update = qr_ppo_minibatch; `target_kl = None` like the reference, i.e. every one of
+    the epochs x minibatches updates runs.  Reports end-to-end env-steps/s of collect + update."""
+    import torch
+    from optimal_quad_control_rl_amd import Quadcopter3DGates, TRAIN_DISTURBANCE_RANGES, square_track
+    from optimal_quad_control_rl_amd.ppo import PPO
+
+    env = Quadcopter3DGates(n, *square_track(), gates_ahead=1, infos_mode="none", seed=1)
+    env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+    n_steps, mb = 32, 16384
+    model = PPO(env, seed=0, gamma=0.999, n_steps=n_steps, n_epochs=10, batch_size=min(mb, n * n_steps), learning_rate=3e-4,
+                target_kl=None, fused_collect=True, native_update=True)
+    model.collect(); model.train()   # warm-up iteration
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tc = 0.0
+    for _ in range(iters):
+        c0 = time.perf_counter()
+        model.collect()
+        torch.cuda.synchronize()
+        tc += time.perf_counter() - c0
+        model.train()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = iters * n * n_steps
+    updates = iters * 10 * ((n * n_steps) // min(mb, n * n_steps))
+    env.close()
+    return {"what": "config 5, whole loop (fused collect + GAE + all %d updates per rollout, no early stop), %d iterations" % (updates // iters, iters),
+            "envs": n, "n_steps": n_steps, "minibatch": min(mb, n * n_steps), "epochs": 10, "value": steps / dt, "unit": "env-steps/s",
+            "collect_ms_per_rollout": tc / iters * 1e3, "update_ms_per_rollout": (dt - tc) / iters * 1e3,
+            "us_per_update": (dt - tc) / updates * 1e6}
+
+
 def cpu_baseline(variant, n, ga, seconds):
     """The oracle (C port of the reference, parity-pinned against reference fixtures) on this box's host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -478,6 +514,10 @@ def run(args, rt, env_factory=make_env, closed_loop=True):
                 result["ppo_update"] = ppo_measure(L, 16384, 65536 * 8, 100)
             except Exception as ex:  # pragma: no cover
                 result["ppo_update"] = {"error": repr(ex)}
+            try:
+                result["config5"] = config5_probe(n)
+            except Exception as ex:  # pragma: no cover
+                result["config5"] = {"error": repr(ex)}
             try:
                 result["host_numpy_path"] = host_path_probe(args.variant, n, ga)
             except Exception as ex:  # pragma: no cover
