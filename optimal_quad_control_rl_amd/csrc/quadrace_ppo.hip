@@ -161,18 +161,20 @@ __global__ void __launch_bounds__(1024) ppo_adv_stats_kernel(const float* __rest
 
 // Device-resident control block of one qr_ppo handle
 struct PpoCtrl {
-    double sumsq[2][512];         // per-workgroup squared-gradient sums of the current update (one slot per workgroup: no
-                                  // same-address f64 atomics), double-buffered by barrier generation parity
-    unsigned int flags[512];      // grid barrier of ppo_apply_kernel: flags[b] = generation workgroup b has arrived in (plain
-                                  // stores: same-address read-modify-write atomics from 247 workgroups serialise at ~100 ns each)
-    unsigned int go;              // generation released by workgroup 0 once every flag shows it
+    // Grid barrier of ppo_apply_kernel.  arrive[b] = (generation workgroup b has arrived in) << 32 | f32 bits of its squared-gradient
+    // sum: ONE 64-bit store per workgroup carries flag and value (no same-address read-modify-write atomics: 247 of them serialise
+    // at ~100 ns each), so the master has the sums the moment it has seen the flags.  go = generation << 32 | f32 bits of the total,
+    // with the decision bits below in the generation word: every workgroup learns "released", the norm and the verdict from one load.
+    unsigned long long arrive[512];
+    unsigned long long go;
     unsigned int gen;             // completed barrier generations (= apply launches that were not skipped)
+    unsigned int pad_;
     int stop;                     // sticky: a minibatch exceeded 1.5 x target_kl (SB3's early stop); cleared by qr_ppo_control
     int applied;                  // optimiser steps taken since the last qr_ppo_control
     int skipped_nonfinite;        // updates dropped because the gradient norm was not finite
     int barrier_timeouts;         // must stay 0
-    float mb_stats[4];            // the current minibatch's sums: surrogate loss, squared value error, approx KL, clipped count
 };
+constexpr unsigned int kGoStop = 0x40000000u, kGoNonFinite = 0x80000000u, kGoGenMask = 0x3FFFFFFFu;
 
 // ---- phase A ------------------------------------------------------------------------------------------------------
 struct PpoBatch {
@@ -725,27 +727,65 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
         __syncthreads();
         return i < n ? a.ext_grad[i] : 0.0f;
     }
-    if (((int)blockIdx.x + 1) * kApplyThreads > n - 4) {  // the block(s) holding the log_std entries (the last one or two)
-        const int lane = threadIdx.x & 63;
-        for (int w = threadIdx.x >> 6; w < 8; w += kApplyThreads / 64) {
-            // statistics: 4 surrogate (policy waves, slot 4), 5 squared value error (value waves, slot 4), 6 approx kl, 7 clipped
-            const int slot = w < 4 ? w : (w == 4 || w == 5 ? 4 : (w == 6 ? 5 : 6));
-            const float* wv = a.wave_out + (w == 5 ? (size_t)a.Gw * 8 : 0) + slot;
-            float t = 0.0f;
-            for (int q = lane; q < a.Gw; q += 64) t += wv[(size_t)q * 8];
-            t = wave_sum(t);
-            if (lane == 0) red[w] = t;
+    // The block(s) holding the log_std entries (the last one or two) also sum phase A's per-wave sums.  All of their loads are
+    // issued up front, together with the chunk partials below: one memory round trip for the whole prologue (a wave that walked
+    // its 512 rows in a loop paid eight of them, and the grid barrier waits for exactly these blocks).
+    //   policy waves (net 0): slots 0..3 d log_std / B, 4 surrogate, 5 approx kl, 6 clipped;  value waves (net 1): slot 4 squared error
+    const bool owner = ((int)blockIdx.x + 1) * kApplyThreads > n - 4;
+    constexpr int kRowsPerThread = 4;   // up to 1024 waves per net (a 32 768-row minibatch); larger ones take the loop below
+    float4 lo[kRowsPerThread], hi[kRowsPerThread];
+    float vs[kRowsPerThread];
+    if (owner) {
+#pragma unroll
+        for (int r = 0; r < kRowsPerThread; ++r) {
+            const int q = r * kApplyThreads + (int)threadIdx.x;
+            const int qc = q < a.Gw ? q : 0;
+            lo[r] = *reinterpret_cast<const float4*>(a.wave_out + (size_t)qc * 8);
+            hi[r] = *reinterpret_cast<const float4*>(a.wave_out + (size_t)qc * 8 + 4);
+            vs[r] = a.wave_out[((size_t)a.Gw + qc) * 8 + 4];
+        }
+    }
+    float g = 0.0f;
+    constexpr int kMaxChunks = 32;
+    float gs[kMaxChunks];
+    if (i < n - 4) {  // weights and biases: the sample-chunk partials of phase B
+        // all (<= 32) chunk loads are issued before the first add: one memory round trip instead of four
+        // (the partials were written by the previous kernel, so they come from HBM / the memory-side cache)
+#pragma unroll
+        for (int q = 0; q < kMaxChunks; ++q) gs[q] = a.partial[(size_t)(q < a.chunks ? q : 0) * n + i];  // unconditional loads
+    }
+    if (owner) {
+        float t[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int r = 0; r < kRowsPerThread; ++r) {
+            const bool on = r * kApplyThreads + (int)threadIdx.x < a.Gw;
+            t[0] += on ? lo[r].x : 0.0f; t[1] += on ? lo[r].y : 0.0f; t[2] += on ? lo[r].z : 0.0f; t[3] += on ? lo[r].w : 0.0f;
+            t[4] += on ? hi[r].x : 0.0f; t[6] += on ? hi[r].y : 0.0f; t[7] += on ? hi[r].z : 0.0f;
+            t[5] += on ? vs[r] : 0.0f;
+        }
+        for (int q = kRowsPerThread * kApplyThreads + (int)threadIdx.x; q < a.Gw; q += kApplyThreads) {
+            const float4 l4 = *reinterpret_cast<const float4*>(a.wave_out + (size_t)q * 8);
+            const float4 h4 = *reinterpret_cast<const float4*>(a.wave_out + (size_t)q * 8 + 4);
+            t[0] += l4.x; t[1] += l4.y; t[2] += l4.z; t[3] += l4.w;
+            t[4] += h4.x; t[6] += h4.y; t[7] += h4.z;
+            t[5] += a.wave_out[((size_t)a.Gw + q) * 8 + 4];
+        }
+        __shared__ float part[8][kApplyThreads / 64];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float w = wave_sum(t[k]);
+            if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            float w = 0.0f;
+#pragma unroll
+            for (int q = 0; q < kApplyThreads / 64; ++q) w += part[threadIdx.x][q];
+            red[threadIdx.x] = w;
         }
         __syncthreads();
     }
-    float g = 0.0f;
-    if (i < n - 4) {  // weights and biases: sum the sample-chunk partials of phase B
-        // all (<= 32) chunk loads are issued before the first add: one memory round trip instead of four
-        // (the partials were written by the previous kernel, so they come from HBM / the memory-side cache)
-        constexpr int kMaxChunks = 32;
-        float gs[kMaxChunks];
-#pragma unroll
-        for (int q = 0; q < kMaxChunks; ++q) gs[q] = a.partial[(size_t)(q < a.chunks ? q : 0) * n + i];  // unconditional loads
+    if (i < n - 4) {
 #pragma unroll
         for (int q = 0; q < kMaxChunks; ++q) gs[q] = q < a.chunks ? gs[q] : 0.0f;
 #pragma unroll
@@ -813,8 +853,6 @@ __global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
     const int i = blockIdx.x * kApplyThreads + threadIdx.x;
     const bool last_block = blockIdx.x == gridDim.x - 1;
     __shared__ float red[8];
-    __shared__ double norm_sq_s;
-    __shared__ float kl_s;
     // Adam state and parameter of this element: loaded NOW, together with the chunk partials, so that their round trip is over
     // before the grid barrier releases (they do not depend on the norm): measured -0.15 us
     const bool owns = a.take_step && i < n;
@@ -829,59 +867,66 @@ __global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
         return;
     }
     if (stop_flag) return;  // SB3: no update after the early stop
-    // ---- squared norm, then a grid-wide barrier: every workgroup of this launch is resident (247 x 256 threads on 256 CUs)
+    // ---- squared norm across the grid: every workgroup of this launch is resident (247 x 256 threads on 256 CUs).
+    // Arrive: one 64-bit store per workgroup = generation | f32 sum.  The LAST workgroup is the master (it owns the minibatch
+    // statistics, so it can take the target-KL decision itself): its first wave polls all arrival words (one coalesced load per 64
+    // workgroups), adds the sums in a fixed order and releases `go` = generation | verdict bits | f32 total.  Everybody else
+    // polls that one word.  RELAXED polling (an agent-scope ACQUIRE load invalidates the XCD's L2 on every iteration and slowed
+    // the workgroups still summing partials); nothing but the polled word itself is consumed, so no fence is needed.  Bounded.
     double sq = (double)g * g, unused = 0.0;
     block_sum2_f64<kApplyThreads>(sq, unused);
+    const unsigned int want = (gen + 1u) & kGoGenMask;
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&c->sumsq[gen & 1][blockIdx.x], sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (last_block)
-            for (int k = 0; k < 4; ++k) __hip_atomic_store(&c->mb_stats[k], red[4 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&c->flags[blockIdx.x], gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long word = ((unsigned long long)want << 32) | (unsigned long long)__float_as_uint((float)sq);
+        __hip_atomic_store(&c->arrive[blockIdx.x], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // Barrier: workgroup 0's first wave polls all arrival flags (one coalesced load per 64 workgroups) and then releases
-    // `go`; everybody else polls that one word.  RELAXED polling (an agent-scope ACQUIRE load invalidates the XCD's L2 on every
-    // iteration and slowed the workgroups still summing partials), one acquire fence after the wait.  Bounded: cannot hang.
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
+    if (last_block && threadIdx.x < 64) {
         bool all = false;
+        double total = 0.0;
         for (int spins = 0; !all && spins < (1 << 20); ++spins) {
             bool mine = true;
-            for (int q = threadIdx.x; q < (int)gridDim.x; q += 64)
-                mine = mine && __hip_atomic_load(&c->flags[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen + 1u;
+            total = 0.0;
+            for (int q = threadIdx.x; q < (int)gridDim.x; q += 64) {
+                const unsigned long long w = __hip_atomic_load(&c->arrive[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mine = mine && (unsigned int)(w >> 32) == want;
+                total += (double)__uint_as_float((unsigned int)w);
+            }
             all = __ballot(mine) == ~0ull;
-            if (!all) __builtin_amdgcn_s_sleep(2);
+            if (!all) __builtin_amdgcn_s_sleep(1);
         }
+        total = wave_sum_f64(total);   // lanes in a fixed order: one value, whatever the arrival order was
         if (threadIdx.x == 0) {
             if (!all) atomicAdd(&c->barrier_timeouts, 1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const float nsq = (float)total;
+            const bool stop_m = a.kl_limit > 0.0f && red[6] > a.kl_limit;   // SB3: checked BEFORE the optimiser step of this minibatch
+            const bool finite_m = nsq <= 3.0e38f;                            // false for inf and NaN
             c->gen = gen + 1u;   // every workgroup has read `gen` before it arrived; visible to the next launch
-            __hip_atomic_store(&c->go, gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int hi = want | (stop_m ? kGoStop : 0u) | (finite_m ? 0u : kGoNonFinite);
+            __hip_atomic_store(&c->go, ((unsigned long long)hi << 32) | (unsigned long long)__float_as_uint(nsq), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    __shared__ unsigned long long go_s;
     if (threadIdx.x == 0) {
+        unsigned long long w = 0;
         int spins = 0;
-        while (__hip_atomic_load(&c->go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen + 1u) {
-            __builtin_amdgcn_s_sleep(4);
+        while ((((unsigned int)((w = __hip_atomic_load(&c->go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32)) & kGoGenMask) != want) {
+            __builtin_amdgcn_s_sleep(2);
             if (++spins > (1 << 20)) {  // never observed
                 atomicAdd(&c->barrier_timeouts, 1);
+                w = ((unsigned long long)(want | kGoNonFinite) << 32);   // take no step on a broken barrier
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        kl_s = __hip_atomic_load(&c->mb_stats[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        go_s = w;
     }
     __syncthreads();
-    // every workgroup adds the per-workgroup sums in the same order: one norm, bit-identical everywhere
-    double part = 0.0;
-    for (int q = threadIdx.x; q < (int)gridDim.x; q += kApplyThreads)
-        part += __hip_atomic_load(&c->sumsq[gen & 1][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    block_sum2_f64<kApplyThreads>(part, unused);
-    if (threadIdx.x == 0) norm_sq_s = part;
-    __syncthreads();
-    const double norm_sq = norm_sq_s;
-    const bool stop_now = a.kl_limit > 0.0f && kl_s > a.kl_limit;   // SB3: checked BEFORE the optimiser step of this minibatch
-    const bool finite = norm_sq <= 1.0e300;                          // false for inf and NaN
+    const unsigned long long gw = go_s;
+    const float norm_sq = __uint_as_float((unsigned int)gw);
+    const bool stop_now = ((unsigned int)(gw >> 32) & kGoStop) != 0u;
+    const bool finite = ((unsigned int)(gw >> 32) & kGoNonFinite) == 0u;
     if (!stop_now && finite && i < n) {
-        const float norm = (float)sqrt(norm_sq);
+        const float norm = sqrtf(norm_sq);
         const float clip = fminf(1.0f, a.max_norm / (norm + 1e-6f));  // torch.nn.utils.clip_grad_norm_
         const float gc = g * clip;
         const float mi = a.beta1 * m_in + (1.0f - a.beta1) * gc;

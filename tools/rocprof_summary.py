@@ -22,7 +22,7 @@ def main(path, like="%"):
     print(f"# total kernel time {total/1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
     print(f"{'calls':>7} {'total_ms':>10} {'avg_ns':>9} {'min_ns':>8} {'max_ns':>9} {'pct':>6} {'vgpr':>5} {'agpr':>5}"
           f" {'sgpr':>5} {'lds':>6} {'scr':>4} {'grid':>8} {'wg':>4}  name")
-    for r in rows[:12]:
+    for r in [r for k, r in enumerate(rows) if k < 12 or r[0].startswith(("qr::", "void qr::", "_ZN2qr"))]:   # top 12 + every kernel of this library
         print(f"{r[1]:7d} {r[2]/1e6:10.3f} {r[3]:9.0f} {r[4]:8d} {r[5]:9d} {100*r[2]/total:6.2f} {r[6]:5d} {r[7]:5d}"
               f" {r[8]:5d} {r[9]:6d} {r[10]:4d} {r[11]:8d} {r[12]:4d}  {r[0][:110]}")
     k = np.array(cur.execute("select start, end from kernels where name like '%step_kernel%' or name like '%rollout_kernel%'"
