@@ -9,7 +9,7 @@
 //   adv_stats   sum / sum of squares of the advantages of EVERY minibatch of an epoch in one launch (qr_ppo_epoch_begin;
 //               SB3 normalises per minibatch; phase A finishes the maths)
 //   phase A     per wave = one 32-sample tile of one net (8-wave workgroups): forward (f16 MFMA chain of quadrace_policy.hpp), per-sample loss
-//               gradients, backward through the transposed weight images -- activations h_l and deltas d_l never leave
+//               gradients, backward through W^T read out of the same LDS image (ds_read_b64_tr_b16) -- activations h_l and deltas d_l never leave
 //               registers in the "lane = sample" form.  Each of them is also emitted in the transposed operand form
 //               (lane = unit, k = sample) by multiplying with an identity operand on the matrix core, and written
 //               to a scratch buffer (f16, ~105 KB per 64 samples and net).  No atomics: log-std gradients and loss
@@ -60,10 +60,9 @@ template <int L>
 struct PpoDims {
     using P = PolicyDims<L>;
     static constexpr int kIT = (L + 1 + 31) / 32;  // 32-wide tiles of the layer-1 input (incl. the constant 1)
-    static constexpr int kOffT4 = P::kTotalHalf8;  // W4^T: [t][lane]
-    static constexpr int kOffT3 = kOffT4 + 4 * 64; // W3^T: [t][sp][lane]
-    static constexpr int kOffT2 = kOffT3 + 4 * 8 * 64;
-    static constexpr int kImage = kOffT2 + 4 * 8 * 64;  // half8 per net (forward image + 3 transposed images)
+    // half8 per net: the forward operand image of quadrace_policy.hpp and nothing else.  The backward pass needs W^T operands
+    // (lane = input unit, k = output units): it reads them out of the SAME image with ds_read_b64_tr_b16 (see lds_tr_pair).
+    static constexpr int kImage = P::kTotalHalf8;
     // transposed-operand scratch: slots of [group][kk = 2*st + s][lane] half8
     static constexpr int kSlotX0 = 0, kSlotH1 = kIT, kSlotH2 = kIT + 4, kSlotH3 = kIT + 8;
     static constexpr int kSlotD1 = kIT + 12, kSlotD2 = kIT + 16, kSlotD3 = kIT + 20, kSlotD4 = kIT + 24;
@@ -101,20 +100,10 @@ __global__ void __launch_bounds__(256) ppo_pack_kernel(const float* __restrict__
             const int ow = third ? o.w3 : o.w2, ob = third ? o.b3 : o.b2;
             if (row < kH) val = hid < kH ? th[ow + row * kH + hid] : (hid == kPolBiasUnit ? th[ob + row] : 0.0f);
             else val = (row == kPolBiasUnit && hid == kPolBiasUnit) ? 1.0f : 0.0f;
-        } else if (e < D::kOffT4) {  // output layer: rows 0..O-1 of one 32-row tile
+        } else {  // output layer: rows 0..O-1 of one 32-row tile
             const int sp = (e - P::kOff4) / 64;
             const int hid = 32 * (sp >> 1) + rho_(8 * (sp & 1) + j, h);
             if (c < O) val = hid < kH ? th[o.w4 + c * kH + hid] : (hid == kPolBiasUnit ? th[o.b4 + c] : 0.0f);
-        } else if (e < D::kOffT3) {  // W4^T: row = hidden unit i, k-slot (h, j) = output unit 8h + j
-            const int t = (e - D::kOffT4) / 64;
-            const int i = 32 * t + c, oo = 8 * h + j;
-            if (i < kH && oo < O) val = th[o.w4 + oo * kH + i];
-        } else {  // W3^T then W2^T: row = input unit i of that layer, k-slots = its output units (accumulator-row order)
-            const bool second = e >= D::kOffT2;
-            const int e2 = e - (second ? D::kOffT2 : D::kOffT3);
-            const int t = e2 / 512, sp = (e2 / 64) % 8;
-            const int i = 32 * t + c, oo = 32 * (sp >> 1) + rho_(8 * (sp & 1) + j, h);
-            if (i < kH && oo < kH) val = th[(second ? o.w2 : o.w3) + oo * kH + i];
         }
         v[j] = (_Float16)val;
     }
@@ -270,6 +259,101 @@ __device__ __forceinline__ uint32_t epilogue_dword(const f32x16p (&acc)[2], int 
     return r & (on * 0xFFFFu);  // 0x0001 -> 0xFFFF in each half (no carry between the halves)
 }
 
+// ---- W^T operands out of the forward image: ds_read_b64_tr_b16 (gfx950) ------------------------------------------------------
+// The backward pass multiplies with W^T: A operand lane (c', h') = input unit i = 32 t' + c' of the layer, its 8 halves = the
+// OUTPUT units oo = 16 sp' + 4 ((j >> 2) * 2 + h') + (j & 3) -- the same k-slot naming as the forward operands.  The forward
+// image stores, for an output row, runs of 4 consecutive input units as 8 contiguous bytes (input 16 sp + 4 q + jj of output row
+// 32 t + c sits at half8 index off + 512 t + 64 sp + 32 (q & 1) + c, halves 4 (q >> 1) + jj), and ds_read_b64_tr_b16 is a 4 x 16
+// transpose inside every 16-lane group (measured, tools/ubench/tr_read.hip): lane n receives, as its k-th half, element n % 4 of
+// the 8 bytes addressed by lane 4 k + n / 4.  So lane 4 k + m of a group points at [output unit oo_base + k][input units
+// i0 + 4 m ..+3] and lane n gets W[oo_base + 0..3][i0 + n]: one read = halves j = 0..3, a second one 128 bytes on (8 output rows
+// later) = halves 4..7.  Addresses = one lane constant + an immediate per operand; no second copy of the weights in LDS, none
+// to stage (68 of 148 KB per workgroup) and none to re-pack after the optimiser step.
+typedef unsigned u32x2p __attribute__((ext_vector_type(2)));
+template <int kByteOff>
+__device__ __forceinline__ u32x2p lds_tr_read(unsigned addr) {
+    u32x2p v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(kByteOff));
+    return v;
+}
+template <int kByteOff, int kSecond>
+__device__ __forceinline__ half8 lds_tr_pair(unsigned addr) {
+    const u32x2p lo = lds_tr_read<kByteOff>(addr), hi = lds_tr_read<kByteOff + kSecond>(addr);
+    const u32x4p r = {lo.x, lo.y, hi.x, hi.y};
+    return __builtin_bit_cast(half8, r);
+}
+// lane constants of the addresses (bytes, relative to the start of the layer images): hidden layers / output layer
+__device__ __forceinline__ unsigned tr_lane_hidden(int lane) {
+    return 16u * (64u * ((lane >> 4) & 1) + 32u * (lane & 1) + 4u * (lane >> 5) + ((lane >> 2) & 3)) + 8u * ((lane >> 1) & 1);
+}
+__device__ __forceinline__ unsigned tr_lane_out(int lane) {
+    return 16u * (64u * ((lane >> 4) & 1) + 32u * (lane & 1) + 8u * (lane >> 5) + ((lane >> 2) & 3)) + 8u * ((lane >> 1) & 1);
+}
+// The compiler does not see these reads: before the operands of one K-step group are used, wait until at most `kLater` LDS
+// operations issued after them are outstanding (LDS returns in order); tying the wait to the registers keeps the MFMAs behind it.
+template <int kLater>
+__device__ __forceinline__ void lds_tr_wait(half8& a0, half8& a1) {
+    u32x4p x = __builtin_bit_cast(u32x4p, a0), y = __builtin_bit_cast(u32x4p, a1);
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(kLater));
+    a0 = __builtin_bit_cast(half8, x);
+    a1 = __builtin_bit_cast(half8, y);
+}
+
+// Backward through one hidden layer for ONE 32-sample tile: out = (W^T in) where the forward unit was active (`mask`), W^T
+// operands read out of the layer's forward image at half8 offset kFwdOff.  Same pinned schedule as mlp_layer (two output tiles
+// side by side, epilogue of the previous pair in the shadow of the MFMAs), operand ring 3 deep = 12 reads in flight.
+template <int kFwdOff>
+__device__ __forceinline__ void mlp_layer_bwd(unsigned tr_lane_addr, const half8 (&in)[8], half8 (&out)[8], const uint32_t (&mask)[2]) {
+    const unsigned tr_addr = tr_lane_addr + 16u * (unsigned)kFwdOff;   // start of this layer's image (the immediates are 16-bit)
+    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int KS = 8, D = 3, kGroups = 2 * KS;
+    half8 a0[D], a1[D];
+    f32x16p acc[2][2];   // [pair parity][tile in pair]
+    u32x4p o32[8];
+    uint32_t word[2] = {mask[0], mask[1]};
+#define QR_TR_FETCH(Q, SLOT)                                                                                               \
+    do {                                                                                                                   \
+        constexpr int tp_ = (Q) / KS, s_ = (Q) % KS;                                                                       \
+        constexpr int c0_ = 16 * (512 * (s_ >> 1) + 128 * (2 * tp_) + 16 * (s_ & 1));   /* 16-bit immediate: layer-relative */  \
+        a0[SLOT] = lds_tr_pair<c0_, 128>(tr_addr);                                                                         \
+        a1[SLOT] = lds_tr_pair<c0_ + 16 * 128, 128>(tr_addr);                                                              \
+    } while (0)
+    QR_TR_FETCH(0, 0); QR_TR_FETCH(1, 1); QR_TR_FETCH(2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tp = 0; tp <= 2; ++tp) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int q = tp * KS + s;
+            if (tp < 2) {
+                // reads issued after group q's: the (up to) two later groups in the ring, 4 reads each
+                if (q + 2 < kGroups) lds_tr_wait<8>(a0[q % D], a1[q % D]);
+                else if (q + 1 < kGroups) lds_tr_wait<4>(a0[q % D], a1[q % D]);
+                else lds_tr_wait<0>(a0[q % D], a1[q % D]);
+                acc[tp][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[q % D], in[s], s == 0 ? zero : acc[tp][0], 0, 0, 0);
+                acc[tp][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[q % D], in[s], s == 0 ? zero : acc[tp][1], 0, 0, 0);
+                switch (q + D) {   // compile-time after unrolling: the group D steps ahead goes into the slot just consumed
+#define QR_TR_CASE(Q) case Q: QR_TR_FETCH(Q, (Q) % D); break;
+                    QR_TR_CASE(3) QR_TR_CASE(4) QR_TR_CASE(5) QR_TR_CASE(6) QR_TR_CASE(7) QR_TR_CASE(8) QR_TR_CASE(9)
+                    QR_TR_CASE(10) QR_TR_CASE(11) QR_TR_CASE(12) QR_TR_CASE(13) QR_TR_CASE(14) QR_TR_CASE(15)
+#undef QR_TR_CASE
+                    default: break;
+                }
+            }
+            if (tp > 0) {
+                const int p = tp - 1;
+#pragma unroll
+                for (int d = (16 * s) / KS; d < (16 * (s + 1)) / KS; ++d)
+                    o32[4 * p + (d >> 2)][d & 3] = epilogue_dword<true>(acc[p], d, word[p]);   // out[2 (2p + ti) + sh]
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef QR_TR_FETCH
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[k] = __builtin_bit_cast(half8, o32[k]);
+}
+
 // One 128-unit layer for ONE 32-sample tile: in[KS] -> out[8].  Forward (BWD = false): out = relu(acc) packed,
 // mask = (acc > 0).  Backward (BWD = true): out = acc where mask is set (the ReLU derivative of the layer being
 // entered), else 0.  Two output tiles are accumulated side by side (two independent MFMA chains).
@@ -363,7 +447,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // minibatches, so that 16 k samples still occupy all 256 CUs).  Every MFMA covers 32 samples anyway, so one wave
 // takes ONE tile through both passes of its network: half the live activations / deltas / masks (no scratch memory -- a
 // scratch reload would wait for all outstanding transposed-operand stores: same in-order counter) and two waves per SIMD
-// to overlap each other's matrix-core, LDS and store latencies.  (The 148 KB of operand images allow one workgroup per CU.)
+// to overlap each other's matrix-core, LDS and store latencies.  (80 KB of operand image + the stash: one workgroup per CU.)
 constexpr int kStashRows = 256;  // per-sample scalars of the workgroup's 4 x 64 samples, parked in LDS
 
 template <int L, int kPpoBlockA>
@@ -374,6 +458,7 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
     constexpr int KS1 = P::kSteps1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half8* W = reinterpret_cast<half8*>(smem);
+    const unsigned lds_base = (unsigned)(size_t)smem;   // LDS byte address of the operand image (for the transposed reads)
     const int net = blockIdx.y;
     const int stop_flag = *a.stop;  // loaded with everything else, TESTED only before the first store: no exposed round trip
     PPO_TICK(a, 0);
@@ -487,12 +572,18 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
         PPO_TICK(a, 6);
         mlp_layer<8, false>(W + P::kOff3, lane, y, x, m3);  // x = h3
         PPO_TICK(a, 7);
-        // the output layer's 8 operands and W4^T's 4 are fetched from LDS now, under the h3^T store / the loss arithmetic
+        // the output layer's 8 operands and W4^T's 4 (transposed reads of the same rows: hidden unit i = 32 t + c, k-slot (h, j) =
+        // output unit 8 h + j) are fetched from LDS now, under the h3^T store / the loss arithmetic
         half8 w4[8], w4t[4];
 #pragma unroll
         for (int s = 0; s < 8; ++s) w4[s] = W[P::kOff4 + s * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) w4t[t] = W[D::kOffT4 + t * 64 + lane];
+        {
+            const unsigned a4 = lds_base + tr_lane_out(lane) + 16u * (unsigned)P::kOff4;
+            w4t[0] = lds_tr_pair<16 * 128 * 0, 64>(a4);
+            w4t[1] = lds_tr_pair<16 * 128 * 1, 64>(a4);
+            w4t[2] = lds_tr_pair<16 * 128 * 2, 64>(a4);
+            w4t[3] = lds_tr_pair<16 * 128 * 3, 64>(a4);
+        }
         __builtin_amdgcn_sched_barrier(0);
         tstore_hidden(x, tb + D::kSlotH3 * slot_stride, slot_stride, lane, et);
         PPO_TICK(a, 8);
@@ -566,6 +657,8 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
             stream_store_h8(tb + D::kSlotD4 * slot_stride + (2 * et + 1) * 64 + lane, plain_pack(acc, 1));
         }
         // ---- backward: d3 = (W4^T d4) * relu'(z3);  d2 = (W3^T d3) * relu'(z2);  d1 = (W2^T d2) * relu'(z1)
+        lds_tr_wait<0>(w4t[0], w4t[1]);
+        lds_tr_wait<0>(w4t[2], w4t[3]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4t[t], d4, zero, 0, 0, 0);
@@ -575,11 +668,11 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
         PPO_TICK(a, 10);
         tstore_hidden(x, tb + D::kSlotD3 * slot_stride, slot_stride, lane, et);
         PPO_TICK(a, 11);
-        mlp_layer<8, true>(W + D::kOffT3, lane, x, y, m2);
+        mlp_layer_bwd<P::kOff3>(lds_base + tr_lane_hidden(lane), x, y, m2);
         PPO_TICK(a, 12);
         tstore_hidden(y, tb + D::kSlotD2 * slot_stride, slot_stride, lane, et);
         PPO_TICK(a, 13);
-        mlp_layer<8, true>(W + D::kOffT2, lane, y, x, m1);
+        mlp_layer_bwd<P::kOff2>(lds_base + tr_lane_hidden(lane), y, x, m1);
         PPO_TICK(a, 14);
         tstore_hidden(x, tb + D::kSlotD1 * slot_stride, slot_stride, lane, et);
         PPO_TICK(a, 15);
@@ -801,7 +894,7 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
 }
 
 // f16 operand-image positions of parameter `local` (index inside one net's block of the flat vector): the inverse of
-// ppo_pack_kernel's gather.  Every weight sits once in the forward image and (layers 2-4) once in the transposed image.
+// ppo_pack_kernel's gather.  Every weight sits once in the image.
 template <int L>
 __device__ __forceinline__ void pack_scatter(_Float16* __restrict__ img, int O, int local, float val) {
     using P = PolicyDims<L>;
@@ -826,19 +919,16 @@ __device__ __forceinline__ void pack_scatter(_Float16* __restrict__ img, int O, 
     } else if (local < o.b2) {                // w2[out][in]
         const int out = (local - o.w2) / kH, in = (local - o.w2) % kH;
         img[hidden_pos(P::kOff2, out, in, false)] = hv;
-        img[hidden_pos(D::kOffT2, in, out, false)] = hv;
     } else if (local < o.w3) {
         img[hidden_pos(P::kOff2, local - o.b2, kPolBiasUnit, false)] = hv;
     } else if (local < o.b3) {
         const int out = (local - o.w3) / kH, in = (local - o.w3) % kH;
         img[hidden_pos(P::kOff3, out, in, false)] = hv;
-        img[hidden_pos(D::kOffT3, in, out, false)] = hv;
     } else if (local < o.w4) {
         img[hidden_pos(P::kOff3, local - o.b3, kPolBiasUnit, false)] = hv;
-    } else if (local < o.b4) {                // w4[oo][i]: output tile rows 0..O-1; W4^T: row = hidden unit i, k-slot (h, j) = oo
+    } else if (local < o.b4) {                // w4[oo][i]: output tile rows 0..O-1
         const int oo = (local - o.w4) / kH, i = (local - o.w4) % kH;
         img[hidden_pos(P::kOff4, oo, i, true)] = hv;
-        img[((size_t)(D::kOffT4 + (i >> 5) * 64 + 32 * (oo >> 3) + (i & 31))) * 8 + (oo & 7)] = hv;
     } else {                                  // b4[oo]
         img[hidden_pos(P::kOff4, local - o.b4, kPolBiasUnit, true)] = hv;
     }

@@ -15,7 +15,7 @@ def measure(L=17, B=16384, R=65536 * 8, iters=100, with_torch=True):
     torch.manual_seed(0)
     obs = torch.randn((R, L), device=dev); act = torch.randn((R, 4), device=dev) * 0.5
     old_lp = torch.randn(R, device=dev) * 0.1 - 3.0; adv = torch.randn(R, device=dev); ret = torch.randn(R, device=dev)
-    perm = torch.randperm(R, device=dev).to(torch.int32)
+    perm = (torch.arange(R, device=dev) if os.environ.get("QR_BENCH_SEQUENTIAL_ROWS") else torch.randperm(R, device=dev)).to(torch.int32)
 
     def timed(fn, n):
         for k in range(10):
