@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <type_traits>
 
@@ -684,6 +685,342 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
     }
 }
 
+// ---- fused gradient kernel: phase A + phase B without the scratch round trip ------------------------------------------------
+// One workgroup = 4 waves = 4 tiles of 32 samples of ONE network per pass.  Forward and backward as in phase A, but the transposed
+// operand forms (lane = unit, k = sample) of d_l and h_(l-1) go to a 64 KB exchange area in LDS instead of HBM, and the workgroup
+// multiplies them right away: dW_l (16 tiles of 32 x 32 for a hidden layer) is split 2 x 2 over the 4 waves, K = the workgroup's
+// 128 samples, accumulators live for one layer only (64 VGPRs) and leave as plain f32 stores into partial[workgroup][param]
+// (f32 atomics were measured at ~0.3 lane-atomics per ns at any scope, tools/ubench/l2_atomics.hip; a workgroup that makes
+// several passes adds to its own partial).  Per minibatch: <= 128 partials of one network each (32 MB at most) instead of
+// 54.6 MB of f16 operands written by phase A and read 1.8 x by phase B.  LDS: 80 KB image | 64 KB exchange | 7 KB stash.
+constexpr int kExHalf8 = 2 * 4 * 8 * 64;   // exchange area: [X = d | h][unit tile][k-step = 2 wave + s][lane] half8
+
+// X (rows = samples, k = units) -> lane = unit, registers = samples, for the 4 unit tiles of a 128-wide matrix: identity MFMAs as
+// in tstore_hidden, packs written to this wave's two k-steps of the exchange area
+__device__ __forceinline__ void transpose_to_lds(const half8 (&X)[8], half8* __restrict__ Ex, int wave, int lane) {
+    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const int c = lane & 31, h = lane >> 5;
+    half8 id[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) id[s][j] = (rho_(8 * s + j, h) == c) ? (_Float16)1.0f : (_Float16)0.0f;
+    f32x16p acc[2];
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[0], id[0], zero, 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[1], id[1], acc[0], 0, 0, 0);
+#pragma unroll
+    for (int ut = 0; ut < 4; ++ut) {
+        if (ut < 3) {
+            acc[(ut + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut + 2], id[0], zero, 0, 0, 0);
+            acc[(ut + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut + 3], id[1], acc[(ut + 1) & 1], 0, 0, 0);
+        }
+        Ex[(ut * 8 + 2 * wave) * 64 + lane] = plain_pack(acc[ut & 1], 0);
+        Ex[(ut * 8 + 2 * wave + 1) * 64 + lane] = plain_pack(acc[ut & 1], 1);
+    }
+}
+
+// dW block of NTO x NTI tiles (<= 2 x 2): acc[bt][bi] += d^T tile (to0 + bt) x h^T tile (ti0 + bi) over the 8 k-steps in the exchange area
+template <int NTO, int NTI>
+__device__ __forceinline__ void dw_block(const half8* __restrict__ E, int to0, int ti0, int lane, f32x16p (&acc)[2][2]) {
+    const half8* Ed = E + lane;
+    const half8* Eh = E + 4 * 8 * 64 + lane;
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) {
+        const half8 a0 = Ed[(to0 * 8 + kq) * 64];
+        const half8 a1 = NTO > 1 ? Ed[((to0 + 1) * 8 + kq) * 64] : a0;
+        const half8 b0 = Eh[(ti0 * 8 + kq) * 64];
+        const half8 b1 = NTI > 1 ? Eh[((ti0 + 1) * 8 + kq) * 64] : b0;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+        if (NTI > 1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+        if (NTO > 1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+        if (NTO > 1 && NTI > 1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+
+// one 32 x 32 tile of dW (register r of lane (c, h) = dW[row 32 to + rho(r, h)][col 32 ti + c]) into this workgroup's partial;
+// column kInDim is the constant-1 unit = the bias.  `add`: a later pass of the same workgroup (all 16 old values are loaded
+// before the first add).  The row pitch is a compile-time constant, so the 16 rows are one base address + immediates.
+template <int kInDim>
+__device__ __forceinline__ void store_dw_tile(const f32x16p& acc, float* __restrict__ gw, float* __restrict__ gb, int out_dim, int to, int ti,
+                                              int lane, float scale, bool add) {
+    const int c = lane & 31, h = lane >> 5;
+    // Formed HERE: inside the pass loop of ppo_grad_kernel the row addresses are loop invariants, and hoisted out of the loop
+    // they occupied ~250 registers for the whole kernel (spilled to AGPRs and scratch).  The empty asm makes the lane's column
+    // opaque, so the address arithmetic stays next to the stores.
+    int col = 32 * ti + c;
+    asm volatile("" : "+v"(col));
+    if (col > kInDim) return;
+    const int row0 = 32 * to + 4 * h;
+    const bool bias = col == kInDim;
+    float* base = bias ? gb + row0 : gw + row0 * kInDim + col;
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r] * scale;
+    if (!bias) {
+        if (add) {
+            float old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = row0 + rho_(r, 0) < out_dim ? base[rho_(r, 0) * kInDim] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += old[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (row0 + rho_(r, 0) < out_dim) base[rho_(r, 0) * kInDim] = v[r];
+    } else {
+        if (add) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += row0 + rho_(r, 0) < out_dim ? base[rho_(r, 0)] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (row0 + rho_(r, 0) < out_dim) base[rho_(r, 0)] = v[r];
+    }
+}
+
+template <int L>
+__global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __restrict__ partial, int num_params) {
+    using D = PpoDims<L>;
+    using P = PolicyDims<L>;
+    constexpr int KS1 = P::kSteps1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8* W = reinterpret_cast<half8*>(smem);
+    half8* E = W + D::kImage;
+    const unsigned lds_base = (unsigned)(size_t)smem;
+    const int net = blockIdx.y;
+    const int stop_flag = *a.stop;
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int et = wave & 1;
+    const int O = net == 0 ? 4 : 1;
+    const NetOff o = net_off(L, O);
+    float* gn = partial + (size_t)blockIdx.x * num_params + (net == 0 ? 0 : net_off(L, 4).total);
+    const float scale = 1.0f / (float)a.B;
+    const double acc_s1 = a.acc[0], acc_s2 = a.acc[1];
+    float log_std_v[4];
+    {
+        const float* log_std = a.theta + net_off(L, 4).total + net_off(L, 1).total;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) log_std_v[k] = log_std[k];
+    }
+    const int pairs = (a.G + 1) / 2;   // passes of 2 sample groups = 128 samples
+    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float* stash = reinterpret_cast<float*>(E + kExHalf8) + wave * 32 + c;
+    for (int pair = blockIdx.x, pass = 0; pair < pairs; pair += gridDim.x, ++pass) {
+        const int g = 2 * pair + (wave >> 1);
+        const bool live = g < a.G;   // whole wave; a wave without samples runs on row 0 with zero deltas (it shares the barriers)
+        // all global loads of the pass up front (first pass: under the image staging)
+        const int b = a.idx[(live ? g : a.G - 1) * 64 + 32 * et + c];
+        float xin[KS1][8];
+        {
+            const float* row = a.obs + (size_t)b * L;
+#pragma unroll
+            for (int s = 0; s < KS1; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * s + 8 * h + j;
+                    xin[s][j] = row[k < L ? k : L - 1];
+                }
+        }
+        const float4 act_v = net == 0 ? reinterpret_cast<const float4*>(a.act)[b] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float old_logp_in = a.old_logp[b], adv_in = a.adv[b], ret_in = a.ret[b];
+        if (pass == 0) {   // operand image -> LDS, 8 independent 16-byte loads in flight per thread
+            const float4* src = reinterpret_cast<const float4*>(a.images + (size_t)net * D::kImage);
+            float4* dst = reinterpret_cast<float4*>(W);
+            constexpr int kBatch = 8;
+            for (int base = 0; base < D::kImage; base += kBatch * 256) {
+                float4 v[kBatch];
+#pragma unroll
+                for (int q = 0; q < kBatch; ++q) {
+                    const int i = base + q * 256 + threadIdx.x;
+                    v[q] = src[i < D::kImage ? i : 0];
+                }
+#pragma unroll
+                for (int q = 0; q < kBatch; ++q) {
+                    const int i = base + q * 256 + threadIdx.x;
+                    if (i < D::kImage) dst[i] = v[q];
+                }
+            }
+        }
+        __syncthreads();   // image staged (first pass) / the previous pass has finished with the exchange area and the stash
+        if (stop_flag) return;   // uniform over the grid
+        if (h == 0) {
+            stash[0 * kStashRows] = act_v.x;
+            stash[1 * kStashRows] = act_v.y;
+            stash[2 * kStashRows] = act_v.z;
+            stash[3 * kStashRows] = act_v.w;
+            stash[4 * kStashRows] = old_logp_in;
+            stash[5 * kStashRows] = adv_in;
+            stash[6 * kStashRows] = ret_in;
+        }
+        half8 in[KS1];
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * s + 8 * h + j;
+                v[j] = k < L ? xin[s][j] : (k == L ? 1.0f : 0.0f);
+            }
+            in[s] = sat_pack(v);
+        }
+        const bool valid = h == 0 && live;
+        // ---- forward: the activations stay in registers until their layer's weight gradient has been formed
+        uint32_t m1[2], m2[2], m3[2];
+        half8 h1[8], h2[8], h3[8];
+        mlp_layer<KS1, false>(W, lane, in, h1, m1);
+        mlp_layer<8, false>(W + P::kOff2, lane, h1, h2, m2);
+        mlp_layer<8, false>(W + P::kOff3, lane, h2, h3, m3);
+        half8 w4[8], w4t[4];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) w4[s] = W[P::kOff4 + s * 64 + lane];
+        {
+            const unsigned a4 = lds_base + tr_lane_out(lane) + 16u * (unsigned)P::kOff4;
+            w4t[0] = lds_tr_pair<16 * 128 * 0, 64>(a4);
+            w4t[1] = lds_tr_pair<16 * 128 * 1, 64>(a4);
+            w4t[2] = lds_tr_pair<16 * 128 * 2, 64>(a4);
+            w4t[3] = lds_tr_pair<16 * 128 * 3, 64>(a4);
+        }
+        float out4[4];
+        {
+            f32x16p acc = zero;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4[s], h3[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out4[r] = acc[r];
+        }
+        // ---- per-sample loss gradients (x B; the 1/B of the batch means is applied when the tiles are stored)
+        float wsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        const float* st_ = stash;
+        float dout[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (net == 0) {
+            const float act[4] = {st_[0 * kStashRows], st_[1 * kStashRows], st_[2 * kStashRows], st_[3 * kStashRows]};
+            const float old_logp_v = st_[4 * kStashRows], adv_v = st_[5 * kStashRows];
+            float z[4], inv_std[4], logp = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float ls = log_std_v[k];
+                inv_std[k] = __expf(-ls);
+                z[k] = (act[k] - out4[k]) * inv_std[k];
+                logp += -0.5f * z[k] * z[k] - ls - 0.9189385332046727f;
+            }
+            const float log_ratio = valid ? logp - old_logp_v : 0.0f;
+            const float ratio = __expf(log_ratio);
+            const double amean = acc_s1 / a.B;
+            const double avar = fmax((acc_s2 - a.B * amean * amean) / (a.B > 1 ? a.B - 1 : 1), 0.0);
+            const float A = valid ? (adv_v - (float)amean) * (float)(1.0 / (sqrt(avar) + 1e-8)) : 0.0f;
+            const bool flows = A >= 0.0f ? (ratio <= 1.0f + a.clip) : (ratio >= 1.0f - a.clip);
+            const float gl = (flows && valid) ? -A * ratio : 0.0f;
+            float dls[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dout[k] = gl * z[k] * inv_std[k];
+                dls[k] = gl * (z[k] * z[k] - 1.0f);
+            }
+            const float clipped_ratio = fminf(fmaxf(ratio, 1.0f - a.clip), 1.0f + a.clip);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wsum[k] = wave_sum(dls[k]) * scale;
+            wsum[4] = wave_sum(valid ? -fminf(A * ratio, A * clipped_ratio) : 0.0f);
+            wsum[5] = wave_sum(valid ? (ratio - 1.0f) - log_ratio : 0.0f);
+            wsum[6] = wave_sum(valid && fabsf(ratio - 1.0f) > a.clip ? 1.0f : 0.0f);
+        } else {
+            const float err = valid ? out4[0] - st_[6 * kStashRows] : 0.0f;
+            dout[0] = a.vf_coef * 2.0f * err;
+            wsum[4] = wave_sum(err * err);
+        }
+        if (live && lane == 0) {
+            float4* wo = reinterpret_cast<float4*>(a.wave_out + (((size_t)net * a.G + g) * 2 + et) * 8);
+            wo[0] = make_float4(wsum[0], wsum[1], wsum[2], wsum[3]);
+            wo[1] = make_float4(wsum[4], wsum[5], wsum[6], wsum[7]);
+        }
+        const bool add = pass > 0;
+        f32x16p dw[2][2];
+        // ---- layer 4: d4 (k-slot (h, j) = output unit 8 h + j) transposed, h3 transposed, dW4 tile (0, wave)
+        half8 d4;
+        {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (j < 4 && valid) ? dout[j < 4 ? j : 0] : 0.0f;
+            d4 = sat_pack(v);
+            half8 id;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) id[j] = (8 * h + j == c) ? (_Float16)1.0f : (_Float16)0.0f;
+            const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(d4, id, zero, 0, 0, 0);
+            E[(0 * 8 + 2 * wave) * 64 + lane] = plain_pack(acc, 0);
+            E[(0 * 8 + 2 * wave + 1) * 64 + lane] = plain_pack(acc, 1);
+        }
+        transpose_to_lds(h3, E + 4 * 8 * 64, wave, lane);
+        __syncthreads();
+        dw[0][0] = zero;
+        dw_block<1, 1>(E, 0, wave, lane, dw);
+        store_dw_tile<kH>(dw[0][0], gn + o.w4, gn + o.b4, O, 0, wave, lane, scale, add);
+        // d3 = (W4^T d4) * relu'(z3) -- independent of the exchange area
+        half8 dA[8], dB[8];
+        lds_tr_wait<0>(w4t[0], w4t[1]);
+        lds_tr_wait<0>(w4t[2], w4t[3]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4t[t], d4, zero, 0, 0, 0);
+            dA[2 * t] = mask_pack(acc, m3[t >> 1], t, 0);
+            dA[2 * t + 1] = mask_pack(acc, m3[t >> 1], t, 1);
+        }
+        __syncthreads();   // everybody is done reading the layer-4 operands
+        // ---- layer 3: dW3 = d3^T x h2
+        transpose_to_lds(dA, E, wave, lane);
+        transpose_to_lds(h2, E + 4 * 8 * 64, wave, lane);
+        __syncthreads();
+        {
+            const int to0 = 2 * (wave >> 1), ti0 = 2 * (wave & 1);
+            dw[0][0] = zero; dw[0][1] = zero; dw[1][0] = zero; dw[1][1] = zero;
+            dw_block<2, 2>(E, to0, ti0, lane, dw);
+#pragma unroll
+            for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi) store_dw_tile<kH>(dw[bt][bi], gn + o.w3, gn + o.b3, kH, to0 + bt, ti0 + bi, lane, scale, add);
+        }
+        mlp_layer_bwd<P::kOff3>(lds_base + tr_lane_hidden(lane), dA, dB, m2);   // d2
+        __syncthreads();
+        // ---- layer 2: dW2 = d2^T x h1
+        transpose_to_lds(dB, E, wave, lane);
+        transpose_to_lds(h1, E + 4 * 8 * 64, wave, lane);
+        __syncthreads();
+        {
+            const int to0 = 2 * (wave >> 1), ti0 = 2 * (wave & 1);
+            dw[0][0] = zero; dw[0][1] = zero; dw[1][0] = zero; dw[1][1] = zero;
+            dw_block<2, 2>(E, to0, ti0, lane, dw);
+#pragma unroll
+            for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi) store_dw_tile<kH>(dw[bt][bi], gn + o.w2, gn + o.b2, kH, to0 + bt, ti0 + bi, lane, scale, add);
+        }
+        mlp_layer_bwd<P::kOff2>(lds_base + tr_lane_hidden(lane), dB, dA, m1);   // d1
+        __syncthreads();
+        // ---- layer 1: dW1 = d1^T x x0 (input tiles: column unit = input index, input L = the constant 1 = bias)
+        transpose_to_lds(dA, E, wave, lane);
+#pragma unroll
+        for (int ut = 0; ut < D::kIT; ++ut) {
+            f32x16p acc = zero;
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                half8 id;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) id[j] = (16 * s + 8 * h + j == 32 * ut + c) ? (_Float16)1.0f : (_Float16)0.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(in[s], id, acc, 0, 0, 0);
+            }
+            E[((4 + ut) * 8 + 2 * wave) * 64 + lane] = plain_pack(acc, 0);
+            E[((4 + ut) * 8 + 2 * wave + 1) * 64 + lane] = plain_pack(acc, 1);
+        }
+        __syncthreads();
+        {
+            dw[0][0] = zero; dw[0][1] = zero;
+            dw_block<1, D::kIT>(E, wave, 0, lane, dw);
+#pragma unroll
+            for (int bi = 0; bi < D::kIT; ++bi) store_dw_tile<L>(dw[0][bi], gn + o.w1, gn + o.b1, kH, wave, bi, lane, scale, add);
+        }
+        // (the barrier at the top of the next pass separates these reads from its writes)
+    }
+}
+
 // ---- phase B: weight gradients -------------------------------------------------------------------------------------------
 // One wave = a 2x2 block of 32x32 weight tiles of one layer (operands shared: 4 loads feed 4 MFMAs) over a chunk of the
 // minibatch's sample groups.  Results go, NOT atomically, to partial[chunk][param]; the norm kernel sums the chunks.
@@ -841,8 +1178,8 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
     float g = 0.0f;
     constexpr int kMaxChunks = 32;
     float gs[kMaxChunks];
-    if (i < n - 4) {  // weights and biases: the sample-chunk partials of phase B
-        // all (<= 32) chunk loads are issued before the first add: one memory round trip instead of four
+    if (i < n - 4) {  // weights and biases: the partials of the gradient kernel (one per workgroup / sample chunk)
+        // the first 32 chunk loads are issued before the first add: one memory round trip instead of four
         // (the partials were written by the previous kernel, so they come from HBM / the memory-side cache)
 #pragma unroll
         for (int q = 0; q < kMaxChunks; ++q) gs[q] = a.partial[(size_t)(q < a.chunks ? q : 0) * n + i];  // unconditional loads
@@ -886,7 +1223,17 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
 #pragma unroll
             for (int q = 0; q < w; ++q) gs[q] += gs[q + w];
         g = gs[0];
-        for (int cix = kMaxChunks; cix < a.chunks; ++cix) g += a.partial[(size_t)cix * n + i];
+        for (int base = kMaxChunks; base < a.chunks; base += kMaxChunks) {   // further batches of 32 (the fused kernel writes up to 128)
+#pragma unroll
+            for (int q = 0; q < kMaxChunks; ++q) gs[q] = a.partial[(size_t)(base + q < a.chunks ? base + q : 0) * n + i];
+#pragma unroll
+            for (int q = 0; q < kMaxChunks; ++q) gs[q] = base + q < a.chunks ? gs[q] : 0.0f;
+#pragma unroll
+            for (int w = kMaxChunks / 2; w >= 1; w >>= 1)
+#pragma unroll
+                for (int q = 0; q < w; ++q) gs[q] += gs[q + w];
+            g += gs[0];
+        }
     } else if (i < n) {  // log_std; entropy = sum(log_std) + const
         g = red[i - (n - 4)] - a.ent_coef;
     }
@@ -1092,6 +1439,8 @@ __global__ void __launch_bounds__(256) ppo_gae_kernel(int T, int N, const float*
 struct qr_ppo {
     int L = 0, device = 0, max_B = 0, num_params = 0;
     int image_half8 = 0, slots = 0, max_chunks = 32;  // chunks = split of the minibatch's sample groups in phase B
+    static constexpr int kFusedChunks = 128;          // workgroups (= partials) per network of the fused gradient kernel
+    bool fused = true;                                // QR_PPO_SPLIT=1: the two-kernel form (phase A + phase B through scratch)
     qr::half8* d_images = nullptr;
     qr::half8* d_tbuf = nullptr;
     float* d_partial = nullptr;  // [max_chunks][num_params] phase-B outputs
@@ -1163,6 +1512,21 @@ struct PpoOps {
             configured = true;
         }
         if (int rc = adv_stats(p, b, st)) return rc;
+        if (p->fused) {   // one kernel: forward, backward and the weight gradients of 128 samples per workgroup and pass
+            const size_t lds_f = ((size_t)D::kImage + qr::kExHalf8) * 16 + 7 * qr::kStashRows * sizeof(float);
+            static bool configured_f = false;
+            if (!configured_f) {
+                PPO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qr::ppo_grad_kernel<L>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+                configured_f = true;
+            }
+            const int pairs = (b.G + 1) / 2;
+            const int wgs = pairs < qr_ppo::kFusedChunks ? pairs : qr_ppo::kFusedChunks;
+            hipLaunchKernelGGL((qr::ppo_grad_kernel<L>), dim3(wgs, 2), dim3(256), lds_f, st, b, p->d_partial, p->num_params);
+            PPO_HIP(hipGetLastError());
+            *chunks_out = wgs;
+            return QR_OK;
+        }
         // split the minibatch's sample groups into chunks: 2 * kBlocksPerNet x chunks waves in phase B
         int chunks = p->max_chunks;
         if (chunks > b.G) chunks = b.G;
@@ -1261,12 +1625,16 @@ int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo
     });
     if (rc != QR_OK) { delete p; return rc; }
     p->num_params = qr::ppo_num_params(obs_len);
+    {
+        const char* split = getenv("QR_PPO_SPLIT");
+        p->fused = !(split && split[0] == '1');
+    }
     PPO_HIP(hipSetDevice(device));
     const size_t tbytes = (size_t)2 * p->slots * (max_minibatch / 64) * 256 * 16;
     const size_t mbbytes = (size_t)(qr_ppo::kMaxEpochMinibatches + 1) * 2 * sizeof(double);
     hipError_t e = hipMalloc((void**)&p->d_images, (size_t)2 * p->image_half8 * 16);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_tbuf, tbytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_partial, (size_t)p->max_chunks * p->num_params * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_partial, (size_t)qr_ppo::kFusedChunks * p->num_params * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_wave, (size_t)2 * 2 * (max_minibatch / 64) * 8 * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_ctrl, sizeof(qr::PpoCtrl));
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_mbstats, mbbytes);
