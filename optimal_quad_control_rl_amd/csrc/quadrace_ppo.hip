@@ -789,6 +789,7 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
     const unsigned lds_base = (unsigned)(size_t)smem;
     const int net = blockIdx.y;
     const int stop_flag = *a.stop;
+    PPO_TICK(a, 0);
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int et = wave & 1;
@@ -809,8 +810,23 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
     for (int pair = blockIdx.x, pass = 0; pair < pairs; pair += gridDim.x, ++pass) {
         const int g = 2 * pair + (wave >> 1);
         const bool live = g < a.G;   // whole wave; a wave without samples runs on row 0 with zero deltas (it shares the barriers)
-        // all global loads of the pass up front (first pass: under the image staging)
+        // All global loads of the pass up front.  Issue order = return order (one in-order counter): row index first, then -- first
+        // pass -- ALL of the thread's operand-image loads (20 x 16 bytes for 80 KB: one round trip, nothing else needs the registers
+        // yet), then the loads that depend on the row index: the gather's second round trip flies while the image lands in LDS.
         const int b = a.idx[(live ? g : a.G - 1) * 64 + 32 * et + c];
+        constexpr int kImgLoads = (D::kImage + 255) / 256;
+        const int img_rot = (int)(blockIdx.x % kImgLoads);
+        f32x4p img[kImgLoads];
+        if (pass == 0) {
+            const f32x4p* src = reinterpret_cast<const f32x4p*>(a.images + (size_t)net * D::kImage);
+            // every workgroup walks the image in a different rotation: all 128 workgroups of a network read the SAME 80 KB, and in
+            // the same order they would all be queueing on one L2 channel at a time
+#pragma unroll
+            for (int q = 0; q < kImgLoads; ++q) {
+                const int i = ((q + img_rot) % kImgLoads) * 256 + threadIdx.x;
+                img[q] = src[i < D::kImage ? i : 0];
+            }
+        }
         float xin[KS1][8];
         {
             const float* row = a.obs + (size_t)b * L;
@@ -824,26 +840,17 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
         }
         const float4 act_v = net == 0 ? reinterpret_cast<const float4*>(a.act)[b] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         const float old_logp_in = a.old_logp[b], adv_in = a.adv[b], ret_in = a.ret[b];
-        if (pass == 0) {   // operand image -> LDS, 8 independent 16-byte loads in flight per thread
-            const float4* src = reinterpret_cast<const float4*>(a.images + (size_t)net * D::kImage);
-            float4* dst = reinterpret_cast<float4*>(W);
-            constexpr int kBatch = 8;
-            for (int base = 0; base < D::kImage; base += kBatch * 256) {
-                float4 v[kBatch];
+        if (pass == 0) {
+            f32x4p* dst = reinterpret_cast<f32x4p*>(W);
 #pragma unroll
-                for (int q = 0; q < kBatch; ++q) {
-                    const int i = base + q * 256 + threadIdx.x;
-                    v[q] = src[i < D::kImage ? i : 0];
-                }
-#pragma unroll
-                for (int q = 0; q < kBatch; ++q) {
-                    const int i = base + q * 256 + threadIdx.x;
-                    if (i < D::kImage) dst[i] = v[q];
-                }
+            for (int q = 0; q < kImgLoads; ++q) {
+                const int i = ((q + img_rot) % kImgLoads) * 256 + threadIdx.x;
+                if (i < D::kImage) dst[i] = img[q];
             }
         }
         __syncthreads();   // image staged (first pass) / the previous pass has finished with the exchange area and the stash
         if (stop_flag) return;   // uniform over the grid
+        PPO_TICK(a, 1);
         if (h == 0) {
             stash[0 * kStashRows] = act_v.x;
             stash[1 * kStashRows] = act_v.y;
@@ -869,8 +876,11 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
         uint32_t m1[2], m2[2], m3[2];
         half8 h1[8], h2[8], h3[8];
         mlp_layer<KS1, false>(W, lane, in, h1, m1);
+        PPO_TICK(a, 2);
         mlp_layer<8, false>(W + P::kOff2, lane, h1, h2, m2);
+        PPO_TICK(a, 3);
         mlp_layer<8, false>(W + P::kOff3, lane, h2, h3, m3);
+        PPO_TICK(a, 4);
         half8 w4[8], w4t[4];
 #pragma unroll
         for (int s = 0; s < 8; ++s) w4[s] = W[P::kOff4 + s * 64 + lane];
@@ -934,6 +944,7 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
             wo[1] = make_float4(wsum[4], wsum[5], wsum[6], wsum[7]);
         }
         const bool add = pass > 0;
+        PPO_TICK(a, 5);
         f32x16p dw[2][2];
         // ---- layer 4: d4 (k-slot (h, j) = output unit 8 h + j) transposed, h3 transposed, dW4 tile (0, wave)
         half8 d4;
@@ -951,6 +962,7 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
         }
         transpose_to_lds(h3, E + 4 * 8 * 64, wave, lane);
         __syncthreads();
+        PPO_TICK(a, 6);
         dw[0][0] = zero;
         dw_block<1, 1>(E, 0, wave, lane, dw);
         store_dw_tile<kH>(dw[0][0], gn + o.w4, gn + o.b4, O, 0, wave, lane, scale, add);
@@ -964,11 +976,13 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
             dA[2 * t] = mask_pack(acc, m3[t >> 1], t, 0);
             dA[2 * t + 1] = mask_pack(acc, m3[t >> 1], t, 1);
         }
+        PPO_TICK(a, 7);
         __syncthreads();   // everybody is done reading the layer-4 operands
         // ---- layer 3: dW3 = d3^T x h2
         transpose_to_lds(dA, E, wave, lane);
         transpose_to_lds(h2, E + 4 * 8 * 64, wave, lane);
         __syncthreads();
+        PPO_TICK(a, 8);
         {
             const int to0 = 2 * (wave >> 1), ti0 = 2 * (wave & 1);
             dw[0][0] = zero; dw[0][1] = zero; dw[1][0] = zero; dw[1][1] = zero;
@@ -978,12 +992,15 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
 #pragma unroll
                 for (int bi = 0; bi < 2; ++bi) store_dw_tile<kH>(dw[bt][bi], gn + o.w3, gn + o.b3, kH, to0 + bt, ti0 + bi, lane, scale, add);
         }
+        PPO_TICK(a, 9);
         mlp_layer_bwd<P::kOff3>(lds_base + tr_lane_hidden(lane), dA, dB, m2);   // d2
+        PPO_TICK(a, 10);
         __syncthreads();
         // ---- layer 2: dW2 = d2^T x h1
         transpose_to_lds(dB, E, wave, lane);
         transpose_to_lds(h1, E + 4 * 8 * 64, wave, lane);
         __syncthreads();
+        PPO_TICK(a, 11);
         {
             const int to0 = 2 * (wave >> 1), ti0 = 2 * (wave & 1);
             dw[0][0] = zero; dw[0][1] = zero; dw[1][0] = zero; dw[1][1] = zero;
@@ -993,7 +1010,9 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
 #pragma unroll
                 for (int bi = 0; bi < 2; ++bi) store_dw_tile<kH>(dw[bt][bi], gn + o.w2, gn + o.b2, kH, to0 + bt, ti0 + bi, lane, scale, add);
         }
+        PPO_TICK(a, 12);
         mlp_layer_bwd<P::kOff2>(lds_base + tr_lane_hidden(lane), dB, dA, m1);   // d1
+        PPO_TICK(a, 13);
         __syncthreads();
         // ---- layer 1: dW1 = d1^T x x0 (input tiles: column unit = input index, input L = the constant 1 = bias)
         transpose_to_lds(dA, E, wave, lane);
@@ -1011,12 +1030,14 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
             E[((4 + ut) * 8 + 2 * wave + 1) * 64 + lane] = plain_pack(acc, 1);
         }
         __syncthreads();
+        PPO_TICK(a, 14);
         {
             dw[0][0] = zero; dw[0][1] = zero;
             dw_block<1, D::kIT>(E, wave, 0, lane, dw);
 #pragma unroll
             for (int bi = 0; bi < D::kIT; ++bi) store_dw_tile<L>(dw[0][bi], gn + o.w1, gn + o.b1, kH, wave, bi, lane, scale, add);
         }
+        PPO_TICK(a, 15);
         // (the barrier at the top of the next pass separates these reads from its writes)
     }
 }

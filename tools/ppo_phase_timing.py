@@ -38,10 +38,17 @@ for k in range(12):
     torch.cuda.synchronize()
     reps.append(ticks.cpu().numpy().copy())
 t = np.stack(reps)[2:]
-names = ["entry", "image -> LDS + barrier", "index / obs gather, layer-1 operand, X0^T store", "fwd layer 1", "h1^T store", "fwd layer 2",
-         "h2^T store", "fwd layer 3", "h3^T store", "output layer + loss gradient", "d4, d4^T store, d3", "d3^T store", "d2", "d2^T store",
-         "d1", "d1^T store"]
-print("phase A of one wave (one 32-sample tile through forward, loss and backward):")
+split = os.environ.get("QR_PPO_SPLIT") == "1"
+if split:
+    names = ["entry", "image -> LDS + barrier", "index / obs gather, layer-1 operand, X0^T store", "fwd layer 1", "h1^T store", "fwd layer 2",
+             "h2^T store", "fwd layer 3", "h3^T store", "output layer + loss gradient", "d4, d4^T store, d3", "d3^T store", "d2", "d2^T store",
+             "d1", "d1^T store"]
+    print("phase A of one wave (one 32-sample tile through forward, loss and backward; QR_PPO_SPLIT=1):")
+else:
+    names = ["entry", "gather issue, image -> LDS, barrier", "fwd layer 1", "fwd layer 2", "fwd layer 3", "output layer + loss gradient",
+             "d4^T, h3^T -> LDS, barrier", "dW4 + stores, d3", "barrier, d3^T, h2^T -> LDS, barrier", "dW3 (2 x 2 tiles) + stores", "d2 (transposed reads)",
+             "barrier, d2^T, h1^T -> LDS, barrier", "dW2 (2 x 2 tiles) + stores", "d1 (transposed reads)", "barrier, d1^T, x0^T -> LDS, barrier", "dW1 + stores"]
+    print("fused gradient kernel, one wave (one 32-sample tile; queues drained at every stamp):")
 for s in range(1, 16):
-    print(f"  {s:2d} {names[s]:42s} {np.median(t[:, :, s] - t[:, :, s - 1]):8.0f} cycles")
+    print(f"  {s:2d} {names[s]:52s} {np.median(t[:, :, s] - t[:, :, s - 1]):8.0f} cycles")
 print(f"  in-wave total {np.median(t[:, :, 15] - t[:, :, 0]):8.0f} cycles;  first entry -> last exit {np.median(t[:, :, 15].max(1) - t[:, :, 0].min(1)):8.0f} cycles (100 MHz clock64 ticks x ~24 = shader cycles)")
