@@ -216,9 +216,11 @@ int qr_ppo_pack(qr_ppo* ppo, const float* theta_dev, void* stream);
 int qr_ppo_grad(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const float* act_dev,
                 const float* old_logp_dev, const float* adv_dev, const float* ret_dev, const int32_t* idx_dev, int32_t B,
                 float clip, float vf_coef, float ent_coef, float* grad_out_dev, float* stats_dev, void* stream);
-/* one complete minibatch update of theta (and the Adam moments); adam_step = 1, 2, ... counts updates.  Three launches:
- * forward/backward (phase A), weight gradients (phase B), and ONE kernel that reduces the gradient, takes its global norm
- * across a grid-wide barrier, clips, applies Adam and re-packs the f16 operand images.  A non-finite gradient norm makes
+/* one complete minibatch update of theta (and the Adam moments); adam_step = 1, 2, ... counts updates.  Two launches:
+ * ONE gradient kernel (forward, loss, backward and the weight gradients of 128 samples per workgroup and pass; per-workgroup
+ * f32 partials) and ONE kernel that reduces the partials, takes the global norm across a grid-wide barrier, clips, applies
+ * Adam and re-packs the f16 operand images.  (Environment QR_PPO_SPLIT=1 at qr_ppo_create: the earlier three-launch form,
+ * forward/backward and weight gradients as two kernels with the operands passed through an HBM scratch buffer.)  A non-finite gradient norm makes
  * the whole update a no-op (counted, see qr_ppo_status).  stats_dev (may be NULL) float[4] is accumulated into. */
 int qr_ppo_minibatch(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* adam_v_dev, const float* obs_dev,
                      const float* act_dev, const float* old_logp_dev, const float* adv_dev, const float* ret_dev,

@@ -4,25 +4,26 @@
 // (policy mean / value), a state-independent log-std, clipped surrogate + vf_coef * MSE value loss, per-minibatch
 // advantage normalisation, global grad-norm clipping, Adam.  With the collect phase fused into one kernel
 // (qr_rollout_policy) torch's minibatch update was > 95 % of training time: ~100 small launches around
-// 16 k x 120 x 120 GEMMs.  Here one minibatch is three launches (phase A, phase B, apply) plus one adv_stats launch per EPOCH:
+// 16 k x 120 x 120 GEMMs.  Here one minibatch is two launches (grad, apply) plus one adv_stats launch per EPOCH:
 //
 //   adv_stats   sum / sum of squares of the advantages of EVERY minibatch of an epoch in one launch (qr_ppo_epoch_begin;
-//               SB3 normalises per minibatch; phase A finishes the maths)
-//   phase A     per wave = one 32-sample tile of one net (8-wave workgroups): forward (f16 MFMA chain of quadrace_policy.hpp), per-sample loss
-//               gradients, backward through W^T read out of the same LDS image (ds_read_b64_tr_b16) -- activations h_l and deltas d_l never leave
-//               registers in the "lane = sample" form.  Each of them is also emitted in the transposed operand form
-//               (lane = unit, k = sample) by multiplying with an identity operand on the matrix core, and written
-//               to a scratch buffer (f16, ~105 KB per 64 samples and net).  No atomics: log-std gradients and loss
-//               statistics leave as per-wave sums.
-//   phase B     dW_l = d_l^T x h_(l-1): one wave per 2x2 block of 32x32 weight tiles and chunk of the sample groups,
-//               v_mfma_f32_32x32x16_f16 with k = sample, plain stores to partial[chunk][param].  Biases ride along as the
-//               constant-1 unit of every layer.
-//   apply       ONE kernel: sums the chunk partials and the per-wave sums into the gradient, accumulates its squared norm,
-//               crosses a grid-wide barrier (62 co-resident workgroups), then clip scale, torch.optim.Adam arithmetic, and each
-//               thread scatters its new parameter as f16 into the forward / transposed operand images of the next minibatch;
-//               SB3's target-KL early stop is decided here, on the device, before the step is taken
+//               SB3 normalises per minibatch; the gradient kernel finishes the maths)
+//   grad        ppo_grad_kernel: a workgroup = 4 waves = 4 tiles of 32 samples of one net per pass.  Forward (f16 MFMA chain of
+//               quadrace_policy.hpp), per-sample loss gradients, backward through W^T read out of the SAME LDS image
+//               (ds_read_b64_tr_b16) -- activations h_l and deltas d_l stay in registers in the "lane = sample" form.  Per layer
+//               both are turned into the operand form (lane = unit, k = sample) by multiplying with an identity operand on
+//               the matrix core, exchanged through 64 KB of LDS, and dW_l = d_l^T x h_(l-1) is formed at once: 2 x 2 weight
+//               tiles per wave, k = the workgroup's 128 samples, plain f32 stores to partial[workgroup][param].  Biases ride
+//               along as the constant-1 unit of every layer.  No atomics anywhere: log-std gradients and loss statistics
+//               leave as per-wave sums.
+//   apply       ONE kernel: sums the partials and the per-wave sums into the gradient, accumulates its squared norm, crosses a
+//               grid-wide barrier (247 co-resident workgroups), then clip scale, torch.optim.Adam arithmetic, and each thread
+//               scatters its new parameter as f16 into the operand image of the next minibatch; SB3's target-KL early stop is
+//               decided here, on the device, before the step is taken
 //   (pack       the gather form of the same image layout: initial images / after external changes of theta;
-//    reduce     gradient + minibatch statistics only, for the data-parallel path: qr_ppo_grad -> all-reduce -> qr_ppo_apply)
+//    reduce     gradient + minibatch statistics only, for the data-parallel path: qr_ppo_grad -> all-reduce -> qr_ppo_apply;
+//    phase A + phase B   the earlier split form of `grad` -- transposed operands through an HBM scratch buffer, weight gradients
+//               by one wave per 2 x 2 tile block and sample chunk -- kept selectable with QR_PPO_SPLIT=1)
 //
 // Operand layouts are those of quadrace_policy.hpp (verified on MI355X with tools/ubench/mfma_layout.hip).
 #include <hip/hip_runtime.h>
