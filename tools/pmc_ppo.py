@@ -39,9 +39,10 @@ else:
         cal = [v for k, v in rows if "copy" in k.lower() or "elementwise" in k.lower()]
         cal = [v for v in cal if v > 0.9 * max(cal)]
         out = {"cal": sum(cal) / len(cal)}
-        for name in ("ppo_adv_stats", "ppo_phase_a", "ppo_phase_b", "ppo_apply"):
-            v = [x for k, x in rows if name in k][4:]
-            out[name] = sum(v) / max(1, len(v))
+        for name in ("ppo_adv_stats", "ppo_grad", "ppo_phase_a", "ppo_phase_b", "ppo_apply"):   # ppo_grad: the fused form (default);
+            v = [x for k, x in rows if name in k][4:]                                            # phase A / B: QR_PPO_SPLIT=1
+            if v:
+                out[name] = sum(v) / len(v)
         return out
 
     f = per_kernel(load(sys.argv[2], "FETCH_SIZE")); w = per_kernel(load(sys.argv[3], "WRITE_SIZE"))

@@ -20,3 +20,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/pmc_ppo.py summarise /tmp/pmc_ppo_FETCH_SIZE/p_counter_collection.csv /tmp/pmc_ppo_WRITE_SIZE/p_counter_collection.csv $O/${T}_pmc_ppo_summary.json > /dev/null 2>&1
 ls -la $O
+# the split form of the PPO gradient (phase A + phase B through HBM scratch) for comparison
+(cd /tmp && QR_PPO_SPLIT=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_ppo_split -o ppo -- python $R/tools/bench_ppo_update.py --iters 100 > /dev/null 2>&1)
+python tools/rocprof_summary.py /tmp/prof_ppo_split/ppo_results.db > $O/${T}_ppo_update_split_kernel_stats.txt 2>&1
+python tools/ppo_phase_timing.py 2>/dev/null | grep -v amdgpu > $O/${T}_ppo_phase_timing.txt
+ls -la $O
