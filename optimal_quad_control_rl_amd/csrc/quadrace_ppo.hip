@@ -738,6 +738,102 @@ __device__ __forceinline__ void dw_block(const half8* __restrict__ E, int to0, i
     }
 }
 
+// ---- exchange of the 128-wide matrices as NATURAL packs, read back transposed ------------------------------------------------
+// A wave's pack array X[sp] (lane = sample c, half8 = 8 units of k-step sp) has the same shape as a one-row-tile weight image
+// (rows = samples, k-slots = units), so the operand form (lane = unit 32 t + c', half8 = 8 samples) comes out of it with the same
+// ds_read_b64_tr_b16 pair as W^T does out of the forward image -- no identity MFMAs, no f32 -> f16 conversion, no packing: the
+// writer side is 8 plain 16-byte stores per matrix (the identity-MFMA transposes were measured at 3.8 k cycles per layer for the
+// two matrices, a quarter of the kernel).  Region X (0 = d, 1 = h), wave w: half8 index ((4 X + w) * 8 + sp) * 64 + lane.
+__device__ __forceinline__ void packs_to_lds(const half8 (&X)[8], half8* __restrict__ Ex, int wave, int lane) {
+#pragma unroll
+    for (int sp = 0; sp < 8; ++sp) Ex[(wave * 8 + sp) * 64 + lane] = X[sp];
+}
+// byte immediate of operand (region, wave w, unit tile offset bt from the base tile, sample half sp)
+#define QR_EX_OFF(REGION, W, BT, SP) (16 * (((REGION) * 4 + (W)) * 512 + 128 * (BT) + 16 * (SP)))
+
+// dW block of 2 x 2 tiles from natural packs: base_d / base_h = exchange address + lane constant + 2 KB x first tile.  K-steps
+// (w, sp) = 8; per step four operands = 8 transposed reads, issued half a step at a time so that at most 12 are in flight
+// (the counter has 4 bits): A(k) = d operands, B(k) = h operands; order A0 B0 A1 | wait, MFMAs(k), B(k+1), A(k+2).
+__device__ __forceinline__ void dw_block_tr(unsigned base_d, unsigned base_h, f32x16p (&acc)[2][2]) {
+    half8 a0[2], a1[2], b0[2], b1[2];
+#define QR_EX_A(KQ, SLOT)                                                                 \
+    do {                                                                                  \
+        a0[SLOT] = lds_tr_pair<QR_EX_OFF(0, (KQ) >> 1, 0, (KQ) & 1), 128>(base_d);        \
+        a1[SLOT] = lds_tr_pair<QR_EX_OFF(0, (KQ) >> 1, 1, (KQ) & 1), 128>(base_d);        \
+    } while (0)
+#define QR_EX_B(KQ, SLOT)                                                                 \
+    do {                                                                                  \
+        b0[SLOT] = lds_tr_pair<QR_EX_OFF(1, (KQ) >> 1, 0, (KQ) & 1), 128>(base_h);        \
+        b1[SLOT] = lds_tr_pair<QR_EX_OFF(1, (KQ) >> 1, 1, (KQ) & 1), 128>(base_h);        \
+    } while (0)
+#define QR_EX_STEP(KQ)                                                                                            \
+    do {                                                                                                          \
+        if ((KQ) < 7) { lds_tr_wait<4>(a0[(KQ) & 1], a1[(KQ) & 1]); lds_tr_wait<4>(b0[(KQ) & 1], b1[(KQ) & 1]); } \
+        else { lds_tr_wait<0>(a0[(KQ) & 1], a1[(KQ) & 1]); lds_tr_wait<0>(b0[(KQ) & 1], b1[(KQ) & 1]); }          \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[(KQ) & 1], b0[(KQ) & 1], acc[0][0], 0, 0, 0);       \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[(KQ) & 1], b1[(KQ) & 1], acc[0][1], 0, 0, 0);       \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[(KQ) & 1], b0[(KQ) & 1], acc[1][0], 0, 0, 0);       \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[(KQ) & 1], b1[(KQ) & 1], acc[1][1], 0, 0, 0);       \
+    } while (0)
+    QR_EX_A(0, 0); QR_EX_B(0, 0); QR_EX_A(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(0); QR_EX_B(1, 1); QR_EX_A(2, 0); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(1); QR_EX_B(2, 0); QR_EX_A(3, 1); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(2); QR_EX_B(3, 1); QR_EX_A(4, 0); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(3); QR_EX_B(4, 0); QR_EX_A(5, 1); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(4); QR_EX_B(5, 1); QR_EX_A(6, 0); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(5); QR_EX_B(6, 0); QR_EX_A(7, 1); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(6); QR_EX_B(7, 1); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(7);
+#undef QR_EX_STEP
+#undef QR_EX_B
+#undef QR_EX_A
+}
+
+// one tile: A operands = a tile in the identity-MFMA ("old") format at Eold[k-step][lane] (d4^T), B operands = unit tile of a
+// natural-pack matrix in region 1 (base_h as above).  8 k-steps in two halves of 4 (8 transposed reads in flight).
+template <int K0>
+__device__ __forceinline__ void dw_tile_old_tr_half(const half8* __restrict__ Eold, unsigned base_h, int lane, f32x16p& acc) {
+    half8 b0 = lds_tr_pair<QR_EX_OFF(1, (K0 + 0) >> 1, 0, (K0 + 0) & 1), 128>(base_h);
+    half8 b1 = lds_tr_pair<QR_EX_OFF(1, (K0 + 1) >> 1, 0, (K0 + 1) & 1), 128>(base_h);
+    half8 b2 = lds_tr_pair<QR_EX_OFF(1, (K0 + 2) >> 1, 0, (K0 + 2) & 1), 128>(base_h);
+    half8 b3 = lds_tr_pair<QR_EX_OFF(1, (K0 + 3) >> 1, 0, (K0 + 3) & 1), 128>(base_h);
+    const half8 x0 = Eold[(K0 + 0) * 64 + lane], x1 = Eold[(K0 + 1) * 64 + lane];
+    const half8 x2 = Eold[(K0 + 2) * 64 + lane], x3 = Eold[(K0 + 3) * 64 + lane];
+    lds_tr_wait<0>(b0, b1);
+    lds_tr_wait<0>(b2, b3);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x2, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3, b3, acc, 0, 0, 0);
+}
+
+// NTI (1 or 2) tiles: A operands = unit tile of a natural-pack matrix in region 0 (base_d), B operands = tiles in the old format
+// at Eold[(bi * 8 + k-step) * 64 + lane] (x0^T)
+template <int NTI, int K0>
+__device__ __forceinline__ void dw_tiles_tr_old_half(unsigned base_d, const half8* __restrict__ Eold, int lane, f32x16p (&acc)[2][2]) {
+    half8 a0 = lds_tr_pair<QR_EX_OFF(0, (K0 + 0) >> 1, 0, (K0 + 0) & 1), 128>(base_d);
+    half8 a1 = lds_tr_pair<QR_EX_OFF(0, (K0 + 1) >> 1, 0, (K0 + 1) & 1), 128>(base_d);
+    half8 a2 = lds_tr_pair<QR_EX_OFF(0, (K0 + 2) >> 1, 0, (K0 + 2) & 1), 128>(base_d);
+    half8 a3 = lds_tr_pair<QR_EX_OFF(0, (K0 + 3) >> 1, 0, (K0 + 3) & 1), 128>(base_d);
+    const half8 y00 = Eold[(K0 + 0) * 64 + lane], y01 = Eold[(K0 + 1) * 64 + lane];
+    const half8 y02 = Eold[(K0 + 2) * 64 + lane], y03 = Eold[(K0 + 3) * 64 + lane];
+    lds_tr_wait<0>(a0, a1);
+    lds_tr_wait<0>(a2, a3);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, y00, acc[0][0], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, y01, acc[0][0], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, y02, acc[0][0], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, y03, acc[0][0], 0, 0, 0);
+    if (NTI > 1) {
+        const half8 y10 = Eold[(8 + K0 + 0) * 64 + lane], y11 = Eold[(8 + K0 + 1) * 64 + lane];
+        const half8 y12 = Eold[(8 + K0 + 2) * 64 + lane], y13 = Eold[(8 + K0 + 3) * 64 + lane];
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, y10, acc[0][1], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, y11, acc[0][1], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, y12, acc[0][1], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, y13, acc[0][1], 0, 0, 0);
+    }
+}
+
 // one 32 x 32 tile of dW (register r of lane (c, h) = dW[row 32 to + rho(r, h)][col 32 ti + c]) into this workgroup's partial;
 // column kInDim is the constant-1 unit = the bias.  `add`: a later pass of the same workgroup (all 16 old values are loaded
 // before the first add).  The row pitch is a compile-time constant, so the 16 rows are one base address + immediates.
@@ -788,6 +884,7 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
     half8* W = reinterpret_cast<half8*>(smem);
     half8* E = W + D::kImage;
     const unsigned lds_base = (unsigned)(size_t)smem;
+    const unsigned ex_lane = lds_base + 16u * (unsigned)D::kImage + tr_lane_hidden((int)(threadIdx.x & 63));   // exchange area + lane constant
     const int net = blockIdx.y;
     const int stop_flag = *a.stop;
     PPO_TICK(a, 0);
@@ -961,11 +1058,12 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
             E[(0 * 8 + 2 * wave) * 64 + lane] = plain_pack(acc, 0);
             E[(0 * 8 + 2 * wave + 1) * 64 + lane] = plain_pack(acc, 1);
         }
-        transpose_to_lds(h3, E + 4 * 8 * 64, wave, lane);
+        packs_to_lds(h3, E + 4 * 8 * 64, wave, lane);
         __syncthreads();
         PPO_TICK(a, 6);
         dw[0][0] = zero;
-        dw_block<1, 1>(E, 0, wave, lane, dw);
+        dw_tile_old_tr_half<0>(E, ex_lane + 2048u * (unsigned)wave, lane, dw[0][0]);   // tile (0, wave): h3 unit tile = wave
+        dw_tile_old_tr_half<4>(E, ex_lane + 2048u * (unsigned)wave, lane, dw[0][0]);
         store_dw_tile<kH>(dw[0][0], gn + o.w4, gn + o.b4, O, 0, wave, lane, scale, add);
         // d3 = (W4^T d4) * relu'(z3) -- independent of the exchange area
         half8 dA[8], dB[8];
@@ -980,14 +1078,14 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
         PPO_TICK(a, 7);
         __syncthreads();   // everybody is done reading the layer-4 operands
         // ---- layer 3: dW3 = d3^T x h2
-        transpose_to_lds(dA, E, wave, lane);
-        transpose_to_lds(h2, E + 4 * 8 * 64, wave, lane);
+        packs_to_lds(dA, E, wave, lane);
+        packs_to_lds(h2, E + 4 * 8 * 64, wave, lane);
         __syncthreads();
         PPO_TICK(a, 8);
         {
             const int to0 = 2 * (wave >> 1), ti0 = 2 * (wave & 1);
             dw[0][0] = zero; dw[0][1] = zero; dw[1][0] = zero; dw[1][1] = zero;
-            dw_block<2, 2>(E, to0, ti0, lane, dw);
+            dw_block_tr(ex_lane + 2048u * (unsigned)to0, ex_lane + 2048u * (unsigned)ti0, dw);
 #pragma unroll
             for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
@@ -998,14 +1096,14 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
         PPO_TICK(a, 10);
         __syncthreads();
         // ---- layer 2: dW2 = d2^T x h1
-        transpose_to_lds(dB, E, wave, lane);
-        transpose_to_lds(h1, E + 4 * 8 * 64, wave, lane);
+        packs_to_lds(dB, E, wave, lane);
+        packs_to_lds(h1, E + 4 * 8 * 64, wave, lane);
         __syncthreads();
         PPO_TICK(a, 11);
         {
             const int to0 = 2 * (wave >> 1), ti0 = 2 * (wave & 1);
             dw[0][0] = zero; dw[0][1] = zero; dw[1][0] = zero; dw[1][1] = zero;
-            dw_block<2, 2>(E, to0, ti0, lane, dw);
+            dw_block_tr(ex_lane + 2048u * (unsigned)to0, ex_lane + 2048u * (unsigned)ti0, dw);
 #pragma unroll
             for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
@@ -1016,7 +1114,7 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
         PPO_TICK(a, 13);
         __syncthreads();
         // ---- layer 1: dW1 = d1^T x x0 (input tiles: column unit = input index, input L = the constant 1 = bias)
-        transpose_to_lds(dA, E, wave, lane);
+        packs_to_lds(dA, E, wave, lane);
 #pragma unroll
         for (int ut = 0; ut < D::kIT; ++ut) {
             f32x16p acc = zero;
@@ -1034,7 +1132,8 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
         PPO_TICK(a, 14);
         {
             dw[0][0] = zero; dw[0][1] = zero;
-            dw_block<1, D::kIT>(E, wave, 0, lane, dw);
+            dw_tiles_tr_old_half<D::kIT, 0>(ex_lane + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw);   // tiles (wave, 0..kIT-1)
+            dw_tiles_tr_old_half<D::kIT, 4>(ex_lane + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw);
 #pragma unroll
             for (int bi = 0; bi < D::kIT; ++bi) store_dw_tile<L>(dw[0][bi], gn + o.w1, gn + o.b1, kH, wave, bi, lane, scale, add);
         }
