@@ -744,9 +744,25 @@ __device__ __forceinline__ void dw_block(const half8* __restrict__ E, int to0, i
 // ds_read_b64_tr_b16 pair as W^T does out of the forward image -- no identity MFMAs, no f32 -> f16 conversion, no packing: the
 // writer side is 8 plain 16-byte stores per matrix (the identity-MFMA transposes were measured at 3.8 k cycles per layer for the
 // two matrices, a quarter of the kernel).  Region X (0 = d, 1 = h), wave w: half8 index ((4 X + w) * 8 + sp) * 64 + lane.
+// Chunk (16 bytes) c5 = sample (bits 0-4), b = unit-slot parity (bit 5), a.. = k-step (bits 6-8).  A transposed read's 32-lane group
+// touches the 16 chunks {k (2 bits), a, b} for fixed h' -- 64 a + 32 b apart they would share banks 4-way (256 B rows), so bits 2-3
+// of the chunk index are XORed with (b, a): the group's chunks then fill one aligned 256-byte block = all 64 banks once.
 __device__ __forceinline__ void packs_to_lds(const half8 (&X)[8], half8* __restrict__ Ex, int wave, int lane) {
+    const int h = lane >> 5;
 #pragma unroll
-    for (int sp = 0; sp < 8; ++sp) Ex[(wave * 8 + sp) * 64 + lane] = X[sp];
+    for (int sp = 0; sp < 8; ++sp) Ex[(wave * 8 + sp) * 64 + (lane ^ ((h | ((sp & 1) << 1)) << 2))] = X[sp];
+}
+// lane constants of the two reads of an operand (second = halves 4..7 = 8 samples on): bit 2 of the chunk index is h' ^ b, bit 3 is
+// second ^ a, so the two reads differ by more than an immediate and get one address register each
+__device__ __forceinline__ unsigned ex_lane_const(int lane, int second) {
+    const int a = (lane >> 4) & 1, b = lane & 1, hh = lane >> 5, k = (lane >> 2) & 3, mhi = (lane >> 1) & 1;
+    return 16u * (unsigned)(64 * a + 32 * b + 4 * (hh ^ b) + 8 * (second ^ a) + k) + 8u * (unsigned)mhi;
+}
+template <int kByteOff>
+__device__ __forceinline__ half8 lds_tr_pair2(unsigned addr0, unsigned addr1) {
+    const u32x2p lo = lds_tr_read<kByteOff>(addr0), hi = lds_tr_read<kByteOff>(addr1);
+    const u32x4p r = {lo.x, lo.y, hi.x, hi.y};
+    return __builtin_bit_cast(half8, r);
 }
 // byte immediate of operand (region, wave w, unit tile offset bt from the base tile, sample half sp)
 #define QR_EX_OFF(REGION, W, BT, SP) (16 * (((REGION) * 4 + (W)) * 512 + 128 * (BT) + 16 * (SP)))
@@ -754,17 +770,17 @@ __device__ __forceinline__ void packs_to_lds(const half8 (&X)[8], half8* __restr
 // dW block of 2 x 2 tiles from natural packs: base_d / base_h = exchange address + lane constant + 2 KB x first tile.  K-steps
 // (w, sp) = 8; per step four operands = 8 transposed reads, issued half a step at a time so that at most 12 are in flight
 // (the counter has 4 bits): A(k) = d operands, B(k) = h operands; order A0 B0 A1 | wait, MFMAs(k), B(k+1), A(k+2).
-__device__ __forceinline__ void dw_block_tr(unsigned base_d, unsigned base_h, f32x16p (&acc)[2][2]) {
+__device__ __forceinline__ void dw_block_tr(unsigned base_d0, unsigned base_d1, unsigned base_h0, unsigned base_h1, f32x16p (&acc)[2][2]) {
     half8 a0[2], a1[2], b0[2], b1[2];
-#define QR_EX_A(KQ, SLOT)                                                                 \
-    do {                                                                                  \
-        a0[SLOT] = lds_tr_pair<QR_EX_OFF(0, (KQ) >> 1, 0, (KQ) & 1), 128>(base_d);        \
-        a1[SLOT] = lds_tr_pair<QR_EX_OFF(0, (KQ) >> 1, 1, (KQ) & 1), 128>(base_d);        \
+#define QR_EX_A(KQ, SLOT)                                                                           \
+    do {                                                                                            \
+        a0[SLOT] = lds_tr_pair2<QR_EX_OFF(0, (KQ) >> 1, 0, (KQ) & 1)>(base_d0, base_d1);            \
+        a1[SLOT] = lds_tr_pair2<QR_EX_OFF(0, (KQ) >> 1, 1, (KQ) & 1)>(base_d0, base_d1);            \
     } while (0)
-#define QR_EX_B(KQ, SLOT)                                                                 \
-    do {                                                                                  \
-        b0[SLOT] = lds_tr_pair<QR_EX_OFF(1, (KQ) >> 1, 0, (KQ) & 1), 128>(base_h);        \
-        b1[SLOT] = lds_tr_pair<QR_EX_OFF(1, (KQ) >> 1, 1, (KQ) & 1), 128>(base_h);        \
+#define QR_EX_B(KQ, SLOT)                                                                           \
+    do {                                                                                            \
+        b0[SLOT] = lds_tr_pair2<QR_EX_OFF(1, (KQ) >> 1, 0, (KQ) & 1)>(base_h0, base_h1);            \
+        b1[SLOT] = lds_tr_pair2<QR_EX_OFF(1, (KQ) >> 1, 1, (KQ) & 1)>(base_h0, base_h1);            \
     } while (0)
 #define QR_EX_STEP(KQ)                                                                                            \
     do {                                                                                                          \
@@ -793,11 +809,11 @@ __device__ __forceinline__ void dw_block_tr(unsigned base_d, unsigned base_h, f3
 // one tile: A operands = a tile in the identity-MFMA ("old") format at Eold[k-step][lane] (d4^T), B operands = unit tile of a
 // natural-pack matrix in region 1 (base_h as above).  8 k-steps in two halves of 4 (8 transposed reads in flight).
 template <int K0>
-__device__ __forceinline__ void dw_tile_old_tr_half(const half8* __restrict__ Eold, unsigned base_h, int lane, f32x16p& acc) {
-    half8 b0 = lds_tr_pair<QR_EX_OFF(1, (K0 + 0) >> 1, 0, (K0 + 0) & 1), 128>(base_h);
-    half8 b1 = lds_tr_pair<QR_EX_OFF(1, (K0 + 1) >> 1, 0, (K0 + 1) & 1), 128>(base_h);
-    half8 b2 = lds_tr_pair<QR_EX_OFF(1, (K0 + 2) >> 1, 0, (K0 + 2) & 1), 128>(base_h);
-    half8 b3 = lds_tr_pair<QR_EX_OFF(1, (K0 + 3) >> 1, 0, (K0 + 3) & 1), 128>(base_h);
+__device__ __forceinline__ void dw_tile_old_tr_half(const half8* __restrict__ Eold, unsigned base_h0, unsigned base_h1, int lane, f32x16p& acc) {
+    half8 b0 = lds_tr_pair2<QR_EX_OFF(1, (K0 + 0) >> 1, 0, (K0 + 0) & 1)>(base_h0, base_h1);
+    half8 b1 = lds_tr_pair2<QR_EX_OFF(1, (K0 + 1) >> 1, 0, (K0 + 1) & 1)>(base_h0, base_h1);
+    half8 b2 = lds_tr_pair2<QR_EX_OFF(1, (K0 + 2) >> 1, 0, (K0 + 2) & 1)>(base_h0, base_h1);
+    half8 b3 = lds_tr_pair2<QR_EX_OFF(1, (K0 + 3) >> 1, 0, (K0 + 3) & 1)>(base_h0, base_h1);
     const half8 x0 = Eold[(K0 + 0) * 64 + lane], x1 = Eold[(K0 + 1) * 64 + lane];
     const half8 x2 = Eold[(K0 + 2) * 64 + lane], x3 = Eold[(K0 + 3) * 64 + lane];
     lds_tr_wait<0>(b0, b1);
@@ -811,11 +827,11 @@ __device__ __forceinline__ void dw_tile_old_tr_half(const half8* __restrict__ Eo
 // NTI (1 or 2) tiles: A operands = unit tile of a natural-pack matrix in region 0 (base_d), B operands = tiles in the old format
 // at Eold[(bi * 8 + k-step) * 64 + lane] (x0^T)
 template <int NTI, int K0>
-__device__ __forceinline__ void dw_tiles_tr_old_half(unsigned base_d, const half8* __restrict__ Eold, int lane, f32x16p (&acc)[2][2]) {
-    half8 a0 = lds_tr_pair<QR_EX_OFF(0, (K0 + 0) >> 1, 0, (K0 + 0) & 1), 128>(base_d);
-    half8 a1 = lds_tr_pair<QR_EX_OFF(0, (K0 + 1) >> 1, 0, (K0 + 1) & 1), 128>(base_d);
-    half8 a2 = lds_tr_pair<QR_EX_OFF(0, (K0 + 2) >> 1, 0, (K0 + 2) & 1), 128>(base_d);
-    half8 a3 = lds_tr_pair<QR_EX_OFF(0, (K0 + 3) >> 1, 0, (K0 + 3) & 1), 128>(base_d);
+__device__ __forceinline__ void dw_tiles_tr_old_half(unsigned base_d0, unsigned base_d1, const half8* __restrict__ Eold, int lane, f32x16p (&acc)[2][2]) {
+    half8 a0 = lds_tr_pair2<QR_EX_OFF(0, (K0 + 0) >> 1, 0, (K0 + 0) & 1)>(base_d0, base_d1);
+    half8 a1 = lds_tr_pair2<QR_EX_OFF(0, (K0 + 1) >> 1, 0, (K0 + 1) & 1)>(base_d0, base_d1);
+    half8 a2 = lds_tr_pair2<QR_EX_OFF(0, (K0 + 2) >> 1, 0, (K0 + 2) & 1)>(base_d0, base_d1);
+    half8 a3 = lds_tr_pair2<QR_EX_OFF(0, (K0 + 3) >> 1, 0, (K0 + 3) & 1)>(base_d0, base_d1);
     const half8 y00 = Eold[(K0 + 0) * 64 + lane], y01 = Eold[(K0 + 1) * 64 + lane];
     const half8 y02 = Eold[(K0 + 2) * 64 + lane], y03 = Eold[(K0 + 3) * 64 + lane];
     lds_tr_wait<0>(a0, a1);
@@ -884,7 +900,8 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
     half8* W = reinterpret_cast<half8*>(smem);
     half8* E = W + D::kImage;
     const unsigned lds_base = (unsigned)(size_t)smem;
-    const unsigned ex_lane = lds_base + 16u * (unsigned)D::kImage + tr_lane_hidden((int)(threadIdx.x & 63));   // exchange area + lane constant
+    const unsigned ex_lane0 = lds_base + 16u * (unsigned)D::kImage + ex_lane_const((int)(threadIdx.x & 63), 0);   // exchange area + lane
+    const unsigned ex_lane1 = lds_base + 16u * (unsigned)D::kImage + ex_lane_const((int)(threadIdx.x & 63), 1);   // constants (two reads)
     const int net = blockIdx.y;
     const int stop_flag = *a.stop;
     PPO_TICK(a, 0);
@@ -1062,8 +1079,8 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
         __syncthreads();
         PPO_TICK(a, 6);
         dw[0][0] = zero;
-        dw_tile_old_tr_half<0>(E, ex_lane + 2048u * (unsigned)wave, lane, dw[0][0]);   // tile (0, wave): h3 unit tile = wave
-        dw_tile_old_tr_half<4>(E, ex_lane + 2048u * (unsigned)wave, lane, dw[0][0]);
+        dw_tile_old_tr_half<0>(E, ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, lane, dw[0][0]);   // tile (0, wave)
+        dw_tile_old_tr_half<4>(E, ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, lane, dw[0][0]);
         store_dw_tile<kH>(dw[0][0], gn + o.w4, gn + o.b4, O, 0, wave, lane, scale, add);
         // d3 = (W4^T d4) * relu'(z3) -- independent of the exchange area
         half8 dA[8], dB[8];
@@ -1085,7 +1102,7 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
         {
             const int to0 = 2 * (wave >> 1), ti0 = 2 * (wave & 1);
             dw[0][0] = zero; dw[0][1] = zero; dw[1][0] = zero; dw[1][1] = zero;
-            dw_block_tr(ex_lane + 2048u * (unsigned)to0, ex_lane + 2048u * (unsigned)ti0, dw);
+            dw_block_tr(ex_lane0 + 2048u * (unsigned)to0, ex_lane1 + 2048u * (unsigned)to0, ex_lane0 + 2048u * (unsigned)ti0, ex_lane1 + 2048u * (unsigned)ti0, dw);
 #pragma unroll
             for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
@@ -1103,7 +1120,7 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
         {
             const int to0 = 2 * (wave >> 1), ti0 = 2 * (wave & 1);
             dw[0][0] = zero; dw[0][1] = zero; dw[1][0] = zero; dw[1][1] = zero;
-            dw_block_tr(ex_lane + 2048u * (unsigned)to0, ex_lane + 2048u * (unsigned)ti0, dw);
+            dw_block_tr(ex_lane0 + 2048u * (unsigned)to0, ex_lane1 + 2048u * (unsigned)to0, ex_lane0 + 2048u * (unsigned)ti0, ex_lane1 + 2048u * (unsigned)ti0, dw);
 #pragma unroll
             for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
@@ -1132,8 +1149,8 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
         PPO_TICK(a, 14);
         {
             dw[0][0] = zero; dw[0][1] = zero;
-            dw_tiles_tr_old_half<D::kIT, 0>(ex_lane + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw);   // tiles (wave, 0..kIT-1)
-            dw_tiles_tr_old_half<D::kIT, 4>(ex_lane + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw);
+            dw_tiles_tr_old_half<D::kIT, 0>(ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw);   // tiles (wave, 0..kIT-1)
+            dw_tiles_tr_old_half<D::kIT, 4>(ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw);
 #pragma unroll
             for (int bi = 0; bi < D::kIT; ++bi) store_dw_tile<L>(dw[0][bi], gn + o.w1, gn + o.b1, kH, wave, bi, lane, scale, add);
         }
