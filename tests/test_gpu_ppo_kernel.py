@@ -344,3 +344,25 @@ def test_epoch_table_equals_per_minibatch_statistics_and_nonfinite_guard():
     assert torch.equal(up_a.theta, before) and torch.equal(up_a.m, m_before)
     up_a.minibatch(obs, act, old_lp, adv, ret, perm[:B], lr=3e-4)               # and training continues afterwards
     assert up_a.status()[1] == 1 and torch.isfinite(up_a.theta).all()
+
+
+@pytest.mark.parametrize("L,B", [(17, 1024), (24, 16384), (36, 40000 // 64 * 64)])
+def test_fused_gradient_kernel_equals_split_form(L, B, monkeypatch):
+    """The fused gradient kernel (default) and the two-kernel form (QR_PPO_SPLIT=1: transposed operands through HBM scratch,
+    weight gradients by sample chunk) compute the same sums in a different order: gradients and minibatch statistics agree to
+    f32 summation noise -- including a ragged last pass (B = 39 936 rows = 312 pairs of sample groups over 128 workgroups)."""
+    from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
+
+    pol, ref, up_fused, obs, act, old_lp, adv, ret = _setup(L, rows=max(B, 4096) * 2, seed=3, max_minibatch=B)
+    monkeypatch.setenv("QR_PPO_SPLIT", "1")
+    up_split = MfmaPpoUpdater(pol, L, obs.device, max_minibatch=B)
+    monkeypatch.delenv("QR_PPO_SPLIT")
+    idx = torch.randperm(obs.shape[0], device=obs.device)[:B].to(torch.int32)
+    g_f = up_fused.grad(obs, act, old_lp, adv, ret, idx, clip=0.2, vf_coef=0.5, ent_coef=0.01, stats=True).clone()
+    g_s = up_split.grad(obs, act, old_lp, adv, ret, idx, clip=0.2, vf_coef=0.5, ent_coef=0.01, stats=True).clone()
+    torch.cuda.synchronize()
+    n = g_f.numel() - 4
+    scale = float(g_s[:n].abs().max())
+    assert float((g_f[:n] - g_s[:n]).abs().max()) <= 2e-5 * scale + 1e-7
+    assert torch.allclose(g_f[n:], g_s[n:], rtol=1e-5, atol=1e-6)     # the four minibatch statistics
+    up_fused.close(); up_split.close()
