@@ -284,12 +284,25 @@ __device__ __forceinline__ half8 lds_tr_pair(unsigned addr) {
     const u32x4p r = {lo.x, lo.y, hi.x, hi.y};
     return __builtin_bit_cast(half8, r);
 }
-// lane constants of the addresses (bytes, relative to the start of the layer images): hidden layers / output layer
-__device__ __forceinline__ unsigned tr_lane_hidden(int lane) {
-    return 16u * (64u * ((lane >> 4) & 1) + 32u * (lane & 1) + 4u * (lane >> 5) + ((lane >> 2) & 3)) + 8u * ((lane >> 1) & 1);
+template <int kByteOff>
+__device__ __forceinline__ half8 lds_tr_pair2(unsigned addr0, unsigned addr1) {
+    const u32x2p lo = lds_tr_read<kByteOff>(addr0), hi = lds_tr_read<kByteOff>(addr1);
+    const u32x4p r = {lo.x, lo.y, hi.x, hi.y};
+    return __builtin_bit_cast(half8, r);
 }
-__device__ __forceinline__ unsigned tr_lane_out(int lane) {
-    return 16u * (64u * ((lane >> 4) & 1) + 32u * (lane & 1) + 8u * (lane >> 5) + ((lane >> 2) & 3)) + 8u * ((lane >> 1) & 1);
+// Lane constants of the addresses (bytes, relative to the start of the layer images): hidden layers / output layer, for the first
+// (second = 0) and second read of an operand pair.  Chunk index bits: k = source row (bits 0-1), then h' and `second` (hidden
+// layers: bit 2 = h', bit 3 = second; output layer: bit 2 = second, bit 3 = h'), b = lane & 1 (bit 5), a = 16-lane group parity
+// (bit 6).  Swizzled image: bits 2-3 ^= (b, a).
+__device__ __forceinline__ unsigned tr_lane_hidden(int lane, int second = 0, bool swz = false) {
+    const int a = (lane >> 4) & 1, b = lane & 1, hh = lane >> 5, k = (lane >> 2) & 3, mhi = (lane >> 1) & 1;
+    const int bit2 = swz ? hh ^ b : hh, bit3 = swz ? second ^ a : second;
+    return 16u * (unsigned)(64 * a + 32 * b + 4 * bit2 + 8 * bit3 + k) + 8u * (unsigned)mhi;
+}
+__device__ __forceinline__ unsigned tr_lane_out(int lane, int second = 0, bool swz = false) {
+    const int a = (lane >> 4) & 1, b = lane & 1, hh = lane >> 5, k = (lane >> 2) & 3, mhi = (lane >> 1) & 1;
+    const int bit2 = swz ? second ^ b : second, bit3 = swz ? hh ^ a : hh;
+    return 16u * (unsigned)(64 * a + 32 * b + 4 * bit2 + 8 * bit3 + k) + 8u * (unsigned)mhi;
 }
 // The compiler does not see these reads: before the operands of one K-step group are used, wait until at most `kLater` LDS
 // operations issued after them are outstanding (LDS returns in order); tying the wait to the registers keeps the MFMAs behind it.
@@ -304,9 +317,13 @@ __device__ __forceinline__ void lds_tr_wait(half8& a0, half8& a1) {
 // Backward through one hidden layer for ONE 32-sample tile: out = (W^T in) where the forward unit was active (`mask`), W^T
 // operands read out of the layer's forward image at half8 offset kFwdOff.  Same pinned schedule as mlp_layer (two output tiles
 // side by side, epilogue of the previous pair in the shadow of the MFMAs), operand ring 3 deep = 12 reads in flight.
+// Two lane-address registers (first / second read of an operand pair): for the plain image they differ by 128 bytes, for the
+// swizzled one (ppo_grad_kernel) by the swizzle too -- see tr_lane_hidden().
 template <int kFwdOff>
-__device__ __forceinline__ void mlp_layer_bwd(unsigned tr_lane_addr, const half8 (&in)[8], half8 (&out)[8], const uint32_t (&mask)[2]) {
-    const unsigned tr_addr = tr_lane_addr + 16u * (unsigned)kFwdOff;   // start of this layer's image (the immediates are 16-bit)
+__device__ __forceinline__ void mlp_layer_bwd(unsigned tr_lane_addr0, unsigned tr_lane_addr1, const half8 (&in)[8], half8 (&out)[8],
+                                              const uint32_t (&mask)[2]) {
+    const unsigned tr_addr0 = tr_lane_addr0 + 16u * (unsigned)kFwdOff;   // start of this layer's image (the immediates are 16-bit)
+    const unsigned tr_addr1 = tr_lane_addr1 + 16u * (unsigned)kFwdOff;
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int KS = 8, D = 3, kGroups = 2 * KS;
     half8 a0[D], a1[D];
@@ -317,8 +334,8 @@ __device__ __forceinline__ void mlp_layer_bwd(unsigned tr_lane_addr, const half8
     do {                                                                                                                   \
         constexpr int tp_ = (Q) / KS, s_ = (Q) % KS;                                                                       \
         constexpr int c0_ = 16 * (512 * (s_ >> 1) + 128 * (2 * tp_) + 16 * (s_ & 1));   /* 16-bit immediate: layer-relative */  \
-        a0[SLOT] = lds_tr_pair<c0_, 128>(tr_addr);                                                                         \
-        a1[SLOT] = lds_tr_pair<c0_ + 16 * 128, 128>(tr_addr);                                                              \
+        a0[SLOT] = lds_tr_pair2<c0_>(tr_addr0, tr_addr1);                                                                  \
+        a1[SLOT] = lds_tr_pair2<c0_ + 16 * 128>(tr_addr0, tr_addr1);                                                       \
     } while (0)
     QR_TR_FETCH(0, 0); QR_TR_FETCH(1, 1); QR_TR_FETCH(2, 2);
     __builtin_amdgcn_sched_barrier(0);
@@ -365,17 +382,21 @@ __device__ __forceinline__ void mlp_layer_bwd(unsigned tr_lane_addr, const half8
 // pack instructions behind s_nop 7-10 hazard waits.  K-step group q = (pair tp, step s):
 //     2 MFMAs on ring slot q % D     |     ds_read of group q + D's operands into that slot (D = 4 K-steps ahead)
 //     1/KS of the epilogue of the PREVIOUS pair (its accumulators finished a pair ago: no hazard wait)
-template <int KS, bool BWD>
+// kSwz: the image in LDS is chunk-swizzled (ppo_grad_kernel: bits 2-3 of the 16-byte chunk index XORed with bits 5-6, so that the
+// backward pass's transposed reads are bank-conflict free); chunk row r = tile * KS + s then sits at lane ^ ((h | (r & 1) << 1) << 2).
+template <int KS, bool BWD, bool kSwz = false>
 __device__ __forceinline__ void mlp_layer(const half8* __restrict__ W, int lane, const half8 (&in)[KS], half8 (&out)[8],
                                           uint32_t (&mask)[2]) {
+    const int lane_e = kSwz ? lane ^ ((lane >> 5) << 2) : lane;           // chunk rows (tile * KS + s) of even / odd parity
+    const int lane_o = kSwz ? lane ^ (((lane >> 5) | 2) << 2) : lane;
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int D = KS < 4 ? KS : 4;
     half8 a0[D], a1[D];
     // operands of group q: tiles 2 tp and 2 tp + 1 at K-step s
     auto fetch = [&](int q, int slot) {
         const int tp = q / KS, s = q % KS;
-        a0[slot] = W[((2 * tp) * KS + s) * 64 + lane];
-        a1[slot] = W[((2 * tp + 1) * KS + s) * 64 + lane];
+        a0[slot] = W[((2 * tp) * KS + s) * 64 + ((((2 * tp) * KS + s) & 1) ? lane_o : lane_e)];
+        a1[slot] = W[((2 * tp + 1) * KS + s) * 64 + ((((2 * tp + 1) * KS + s) & 1) ? lane_o : lane_e)];
     };
 #pragma unroll
     for (int q = 0; q < D; ++q) fetch(q, q);
@@ -670,11 +691,11 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
         PPO_TICK(a, 10);
         tstore_hidden(x, tb + D::kSlotD3 * slot_stride, slot_stride, lane, et);
         PPO_TICK(a, 11);
-        mlp_layer_bwd<P::kOff3>(lds_base + tr_lane_hidden(lane), x, y, m2);
+        mlp_layer_bwd<P::kOff3>(lds_base + tr_lane_hidden(lane, 0), lds_base + tr_lane_hidden(lane, 1), x, y, m2);
         PPO_TICK(a, 12);
         tstore_hidden(y, tb + D::kSlotD2 * slot_stride, slot_stride, lane, et);
         PPO_TICK(a, 13);
-        mlp_layer_bwd<P::kOff2>(lds_base + tr_lane_hidden(lane), y, x, m1);
+        mlp_layer_bwd<P::kOff2>(lds_base + tr_lane_hidden(lane, 0), lds_base + tr_lane_hidden(lane, 1), y, x, m1);
         PPO_TICK(a, 14);
         tstore_hidden(x, tb + D::kSlotD1 * slot_stride, slot_stride, lane, et);
         PPO_TICK(a, 15);
@@ -757,12 +778,6 @@ __device__ __forceinline__ void packs_to_lds(const half8 (&X)[8], half8* __restr
 __device__ __forceinline__ unsigned ex_lane_const(int lane, int second) {
     const int a = (lane >> 4) & 1, b = lane & 1, hh = lane >> 5, k = (lane >> 2) & 3, mhi = (lane >> 1) & 1;
     return 16u * (unsigned)(64 * a + 32 * b + 4 * (hh ^ b) + 8 * (second ^ a) + k) + 8u * (unsigned)mhi;
-}
-template <int kByteOff>
-__device__ __forceinline__ half8 lds_tr_pair2(unsigned addr0, unsigned addr1) {
-    const u32x2p lo = lds_tr_read<kByteOff>(addr0), hi = lds_tr_read<kByteOff>(addr1);
-    const u32x4p r = {lo.x, lo.y, hi.x, hi.y};
-    return __builtin_bit_cast(half8, r);
 }
 // byte immediate of operand (region, wave w, unit tile offset bt from the base tile, sample half sp)
 #define QR_EX_OFF(REGION, W, BT, SP) (16 * (((REGION) * 4 + (W)) * 512 + 128 * (BT) + 16 * (SP)))
@@ -960,7 +975,7 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
 #pragma unroll
             for (int q = 0; q < kImgLoads; ++q) {
                 const int i = ((q + img_rot) % kImgLoads) * 256 + threadIdx.x;
-                if (i < D::kImage) dst[i] = img[q];
+                if (i < D::kImage) dst[i ^ (((i >> 5) & 3) << 2)] = img[q];   // chunk swizzle: conflict-free transposed reads
             }
         }
         __syncthreads();   // image staged (first pass) / the previous pass has finished with the exchange area and the stash
@@ -990,21 +1005,22 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
         // ---- forward: the activations stay in registers until their layer's weight gradient has been formed
         uint32_t m1[2], m2[2], m3[2];
         half8 h1[8], h2[8], h3[8];
-        mlp_layer<KS1, false>(W, lane, in, h1, m1);
+        mlp_layer<KS1, false, true>(W, lane, in, h1, m1);
         PPO_TICK(a, 2);
-        mlp_layer<8, false>(W + P::kOff2, lane, h1, h2, m2);
+        mlp_layer<8, false, true>(W + P::kOff2, lane, h1, h2, m2);
         PPO_TICK(a, 3);
-        mlp_layer<8, false>(W + P::kOff3, lane, h2, h3, m3);
+        mlp_layer<8, false, true>(W + P::kOff3, lane, h2, h3, m3);
         PPO_TICK(a, 4);
         half8 w4[8], w4t[4];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) w4[s] = W[P::kOff4 + s * 64 + lane];
+        for (int s = 0; s < 8; ++s) w4[s] = W[P::kOff4 + s * 64 + (lane ^ ((h | ((s & 1) << 1)) << 2))];
         {
-            const unsigned a4 = lds_base + tr_lane_out(lane) + 16u * (unsigned)P::kOff4;
-            w4t[0] = lds_tr_pair<16 * 128 * 0, 64>(a4);
-            w4t[1] = lds_tr_pair<16 * 128 * 1, 64>(a4);
-            w4t[2] = lds_tr_pair<16 * 128 * 2, 64>(a4);
-            w4t[3] = lds_tr_pair<16 * 128 * 3, 64>(a4);
+            const unsigned a40 = lds_base + tr_lane_out(lane, 0, true) + 16u * (unsigned)P::kOff4;
+            const unsigned a41 = lds_base + tr_lane_out(lane, 1, true) + 16u * (unsigned)P::kOff4;
+            w4t[0] = lds_tr_pair2<16 * 128 * 0>(a40, a41);
+            w4t[1] = lds_tr_pair2<16 * 128 * 1>(a40, a41);
+            w4t[2] = lds_tr_pair2<16 * 128 * 2>(a40, a41);
+            w4t[3] = lds_tr_pair2<16 * 128 * 3>(a40, a41);
         }
         float out4[4];
         {
@@ -1109,7 +1125,7 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
                 for (int bi = 0; bi < 2; ++bi) store_dw_tile<kH>(dw[bt][bi], gn + o.w3, gn + o.b3, kH, to0 + bt, ti0 + bi, lane, scale, add);
         }
         PPO_TICK(a, 9);
-        mlp_layer_bwd<P::kOff3>(lds_base + tr_lane_hidden(lane), dA, dB, m2);   // d2
+        mlp_layer_bwd<P::kOff3>(lds_base + tr_lane_hidden(lane, 0, true), lds_base + tr_lane_hidden(lane, 1, true), dA, dB, m2);   // d2
         PPO_TICK(a, 10);
         __syncthreads();
         // ---- layer 2: dW2 = d2^T x h1
@@ -1127,7 +1143,7 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
                 for (int bi = 0; bi < 2; ++bi) store_dw_tile<kH>(dw[bt][bi], gn + o.w2, gn + o.b2, kH, to0 + bt, ti0 + bi, lane, scale, add);
         }
         PPO_TICK(a, 12);
-        mlp_layer_bwd<P::kOff2>(lds_base + tr_lane_hidden(lane), dB, dA, m1);   // d1
+        mlp_layer_bwd<P::kOff2>(lds_base + tr_lane_hidden(lane, 0, true), lds_base + tr_lane_hidden(lane, 1, true), dB, dA, m1);   // d1
         PPO_TICK(a, 13);
         __syncthreads();
         // ---- layer 1: dW1 = d1^T x x0 (input tiles: column unit = input index, input L = the constant 1 = bias)
