@@ -397,7 +397,10 @@ __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const f
     // still busy stalls the whole wave, so output-layer VALU work only overlaps the matrix pipe when it sits BETWEEN
     // two MFMAs in program order.  The 20 MFMAs (20 x 64 cycles = the floor of this phase) are therefore issued as one
     // stream and the ReLU + dot product of each finished accumulator is cut into 4-row chunks (8 VALU instructions)
-    // that are placed, pinned by sched_barrier, behind the MFMAs of the NEXT accumulator:
+    // that are written, pinned by sched_barrier, behind the MFMAs of the NEXT accumulator.  (What the compiler makes of it:
+    // the ReLUs -- inline asm -- stay there; the fmaf()s are pure nodes and instruction selection linearises all of them
+    // behind the last MFMA, paired into v_pk_fma_f32.  Forcing them between the MFMAs as asm v_fmac_f32 was measured
+    // SLOWER, fused step 2.54 -> 2.80 us: a VALU instruction between two dependent f32 MFMAs costs more than its slot.)
     //   thrust tile 0 (4 MFMA) | moment tile 0 (6 MFMA) + thrust-0 dot | thrust tile 1 (4) + 3 moment-0 dots
     //   | moment tile 1 (6) + thrust-1 dot | 3 moment-1 dots (exposed)
     // Same operations on the same operands in the same per-chain order as a plain 16-row loop -> bit-identical results.
