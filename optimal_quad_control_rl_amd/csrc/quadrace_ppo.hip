@@ -708,56 +708,16 @@ __global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) 
 }
 
 // ---- fused gradient kernel: phase A + phase B without the scratch round trip ------------------------------------------------
-// One workgroup = 4 waves = 4 tiles of 32 samples of ONE network per pass.  Forward and backward as in phase A, but the transposed
-// operand forms (lane = unit, k = sample) of d_l and h_(l-1) go to a 64 KB exchange area in LDS instead of HBM, and the workgroup
+// One workgroup = 4 waves = 4 tiles of 32 samples of ONE network per pass.  Forward and backward as in phase A, but d_l and h_(l-1)
+// go to a 64 KB exchange area in LDS instead of HBM -- as the waves' natural packs, read back in the operand form (lane = unit,
+// k = sample) with transposed LDS reads; only the narrow d4 and x0 still take the identity-MFMA route -- and the workgroup
 // multiplies them right away: dW_l (16 tiles of 32 x 32 for a hidden layer) is split 2 x 2 over the 4 waves, K = the workgroup's
 // 128 samples, accumulators live for one layer only (64 VGPRs) and leave as plain f32 stores into partial[workgroup][param]
 // (f32 atomics were measured at ~0.3 lane-atomics per ns at any scope, tools/ubench/l2_atomics.hip; a workgroup that makes
 // several passes adds to its own partial).  Per minibatch: <= 128 partials of one network each (32 MB at most) instead of
 // 54.6 MB of f16 operands written by phase A and read 1.8 x by phase B.  LDS: 80 KB image | 64 KB exchange | 7 KB stash.
-constexpr int kExHalf8 = 2 * 4 * 8 * 64;   // exchange area: [X = d | h][unit tile][k-step = 2 wave + s][lane] half8
-
-// X (rows = samples, k = units) -> lane = unit, registers = samples, for the 4 unit tiles of a 128-wide matrix: identity MFMAs as
-// in tstore_hidden, packs written to this wave's two k-steps of the exchange area
-__device__ __forceinline__ void transpose_to_lds(const half8 (&X)[8], half8* __restrict__ Ex, int wave, int lane) {
-    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    const int c = lane & 31, h = lane >> 5;
-    half8 id[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) id[s][j] = (rho_(8 * s + j, h) == c) ? (_Float16)1.0f : (_Float16)0.0f;
-    f32x16p acc[2];
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[0], id[0], zero, 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[1], id[1], acc[0], 0, 0, 0);
-#pragma unroll
-    for (int ut = 0; ut < 4; ++ut) {
-        if (ut < 3) {
-            acc[(ut + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut + 2], id[0], zero, 0, 0, 0);
-            acc[(ut + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut + 3], id[1], acc[(ut + 1) & 1], 0, 0, 0);
-        }
-        Ex[(ut * 8 + 2 * wave) * 64 + lane] = plain_pack(acc[ut & 1], 0);
-        Ex[(ut * 8 + 2 * wave + 1) * 64 + lane] = plain_pack(acc[ut & 1], 1);
-    }
-}
-
-// dW block of NTO x NTI tiles (<= 2 x 2): acc[bt][bi] += d^T tile (to0 + bt) x h^T tile (ti0 + bi) over the 8 k-steps in the exchange area
-template <int NTO, int NTI>
-__device__ __forceinline__ void dw_block(const half8* __restrict__ E, int to0, int ti0, int lane, f32x16p (&acc)[2][2]) {
-    const half8* Ed = E + lane;
-    const half8* Eh = E + 4 * 8 * 64 + lane;
-#pragma unroll
-    for (int kq = 0; kq < 8; ++kq) {
-        const half8 a0 = Ed[(to0 * 8 + kq) * 64];
-        const half8 a1 = NTO > 1 ? Ed[((to0 + 1) * 8 + kq) * 64] : a0;
-        const half8 b0 = Eh[(ti0 * 8 + kq) * 64];
-        const half8 b1 = NTI > 1 ? Eh[((ti0 + 1) * 8 + kq) * 64] : b0;
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-        if (NTI > 1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-        if (NTO > 1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-        if (NTO > 1 && NTI > 1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
-    }
-}
+constexpr int kExHalf8 = 2 * 4 * 8 * 64;   // exchange area: [X = d | h][wave][k-step of the pack][lane] half8 (chunk-swizzled), or, for
+                                           // d4^T / x0^T, [X][unit tile][k-step = 2 wave + s][lane] in the identity-MFMA form
 
 // ---- exchange of the 128-wide matrices as NATURAL packs, read back transposed ------------------------------------------------
 // A wave's pack array X[sp] (lane = sample c, half8 = 8 units of k-step sp) has the same shape as a one-row-tile weight image
