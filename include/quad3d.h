@@ -34,6 +34,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libquadrace.so is built with -fvisibility=hidden: only what this header declares is exported */
+#pragma GCC visibility push(default)
 
 enum { Q3_KIND_HOVER = 0, Q3_KIND_GATES = 1 };
 
@@ -68,6 +70,7 @@ int q3_step_many(q3_env* env, const float* actions_dev, int num_steps, void* rew
 int q3_get_state(q3_env* env, void* states_dev, int32_t* target_dev, int32_t* steps_dev, void* stream);
 int q3_set_state(q3_env* env, const void* states_dev, const int32_t* target_dev, const int32_t* steps_dev, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

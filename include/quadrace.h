@@ -46,8 +46,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libquadrace.so is built with -fvisibility=hidden: only what this header declares is exported */
+#pragma GCC visibility push(default)
 
-#define QR_ABI_VERSION 2
+#define QR_ABI_VERSION 3
 
 enum {
     QR_OK = 0,
@@ -108,9 +110,10 @@ int qr_set_pause_if_collision(qr_env* env, int32_t on);
  * With a device buffer registered, every env that finishes an episode at a step writes the gate-frame observation of its
  * FINAL state -- taken before the auto-reset -- to row [env] (qr_step: buffer [N][obs_len]) or row [k][env] (qr_step_many,
  * qr_step_launches, qr_rollout_policy: buffer [K][N][obs_len], k = step within the call).  Rows of envs that did not
- * finish are not touched.  NULL (default) switches it off.  (The reference itself hands SB3 the post-reset row, a
- * consequence of filling `infos` after reset_(): see DESIGN.md.) */
-int qr_set_terminal_obs(qr_env* env, float* term_obs_dev);
+ * finish are not touched.  NULL (default) switches it off.  `rows` is the leading dimension of the buffer ([rows][N][obs_len];
+ * 1 for a plain [N][obs_len] buffer): a K-step call with K > rows fails with QR_E_INVALID instead of writing past the end.
+ * (The reference itself hands SB3 the post-reset row, a consequence of filling `infos` after reset_(): see DESIGN.md.) */
+int qr_set_terminal_obs(qr_env* env, float* term_obs_dev, int32_t rows);
 
 /* Philox4x32-10 key for the in-kernel reset RNG; also zeroes the per-env episode counters. */
 int qr_seed(qr_env* env, uint64_t seed);
@@ -259,6 +262,7 @@ int qr_ppo_apply(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* adam_v
                  float max_grad_norm, float lr, float beta1, float beta2, float eps, int32_t adam_step, float* stats_dev,
                  void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ for gfx950 behind a C ABI (include/quadrace.h -> libquadrace.so); this package i
 from .tracks import TRAIN_DISTURBANCE_RANGES, square_track, zigzag_track  # noqa: F401
 
 __all__ = ["Quadcopter3DGates", "Quadcopter3DGatesINDI", "zigzag_track", "square_track", "TRAIN_DISTURBANCE_RANGES",
-           "default_residual_blob", "ShardedRaceEnv", "Quadcopter3DVec", "Quadcopter3DVecGates"]
+           "default_residual_blob", "ShardedRaceEnv", "Quadcopter3DVec", "Quadcopter3DVecGates", "PPO", "VecMonitor"]
 
 
 def __getattr__(name):  # lazy: importing the package must not require torch / a GPU
@@ -19,6 +19,10 @@ def __getattr__(name):  # lazy: importing the package must not require torch / a
         from . import quad3d
 
         return getattr(quad3d, name)
+    if name in ("PPO", "VecMonitor"):  # SB3-shaped model object around the on-device PPO (R:783-831, R:3985-3996)
+        from . import sb3
+
+        return getattr(sb3, name)
     if name == "ShardedRaceEnv":
         from . import sharded
 

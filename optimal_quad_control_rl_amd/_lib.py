@@ -38,7 +38,7 @@ SIGNATURES = {
     "qr_set_limits": (C.c_int, [_vp, C.c_int32, C.c_float]),
     "qr_set_pause": (C.c_int, [_vp, C.c_int32]),
     "qr_set_pause_if_collision": (C.c_int, [_vp, C.c_int32]),
-    "qr_set_terminal_obs": (C.c_int, [_vp, _vp]),
+    "qr_set_terminal_obs": (C.c_int, [_vp, _vp, C.c_int32]),
     "qr_seed": (C.c_int, [_vp, C.c_uint64]),
     "qr_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "qr_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -112,7 +112,7 @@ def load(build_if_missing=True):
     for name, (rt, at) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError here = ABI drift between header and library
         fn.restype, fn.argtypes = rt, at
-    if L.qr_abi_version() != 2:
+    if L.qr_abi_version() != 3:
         raise RuntimeError("libquadrace ABI version mismatch")
     _lib = L
     return L

@@ -20,8 +20,10 @@ HEADERS = ["quadrace_device.hpp", "quadrace_policy.hpp", os.path.join("..", ".."
 # the per-step kernel and the fused rollout kernel produce bit-identical trajectories.
 # -amdgpu-mfma-vgpr-form: keep the MFMA accumulators of the residual MLP in VGPRs (gfx950 has a unified register file),
 # so the VALU epilogue reads them directly instead of through 64 v_accvgpr_read per step.
+# -fvisibility=hidden: the library exports the C ABI of include/*.h (declared there under `#pragma GCC visibility push(default)`)
+# and nothing else -- no C++ launchers, no kernel host stubs (tests/test_abi_host.py checks `nm -D`).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form",
-         "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
+         "-fvisibility=hidden", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 
 
 def _hipcc():
@@ -38,7 +40,8 @@ OBJ_DIR = os.path.join(PKG, "_obj")   # per-source objects (git- and gpurun-igno
 
 
 def _deps(src):
-    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__),
+                                                                                   os.path.join(CSRC, "exports.map")]
 
 
 def _obj(src, extra_flags=()):
@@ -72,7 +75,8 @@ def build_native(force=False, verbose=False, extra_flags=()):
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
     tmp = LIB + ".tmp.%d" % os.getpid()   # link beside the target, then rename: a concurrent dlopen never sees a partial file
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
+           "-o", tmp, *objs]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -41,6 +41,7 @@ struct qr_env {
     void* slab = nullptr;       // one HBM allocation holding every state plane
     float* d_tables = nullptr;  // [gate rows | fused MLP table]
     int num_gates = 0;
+    int term_rows = 0;          // leading dimension of the registered terminal-observation buffer (K-step calls need K <= rows)
     bool has_track = false;
     std::vector<float> gate_pos, gate_yaw, gate_pos_rel, gate_yaw_rel;
     float mlp_table[qr::kMlpTableFloats] = {};
@@ -152,6 +153,14 @@ int bind_device(const qr_env* e) {
 int check_ready(const qr_env* e) {
     if (int rc = bind_device(e)) return rc;
     if (!e->has_track) return fail(QR_E_STATE, "qr_set_track has not been called");
+    return QR_OK;
+}
+
+// K-step entry points write terminal observations to row [k][env]: the registered buffer must hold K rows of N envs
+int check_term_rows(const qr_env* e, int K, const char* who) {
+    if (e->P.term_obs && K > e->term_rows)
+        return fail(QR_E_INVALID, std::string(who) + ": num_steps exceeds the rows of the registered terminal-observation buffer "
+                                  "(qr_set_terminal_obs); register a [K][N][obs_len] buffer or NULL first");
     return QR_OK;
 }
 
@@ -358,9 +367,11 @@ int qr_set_pause_if_collision(qr_env* e, int32_t on) {
     return QR_OK;
 }
 
-int qr_set_terminal_obs(qr_env* e, float* term_obs_dev) {
+int qr_set_terminal_obs(qr_env* e, float* term_obs_dev, int32_t rows) {
     if (!e) return fail(QR_E_INVALID, "qr_set_terminal_obs: null env");
+    if (term_obs_dev && rows < 1) return fail(QR_E_INVALID, "qr_set_terminal_obs: rows must be >= 1");
     e->P.term_obs = term_obs_dev;
+    e->term_rows = term_obs_dev ? rows : 0;
     return QR_OK;
 }
 
@@ -394,6 +405,7 @@ int qr_step_many(qr_env* e, int32_t K, const float* actions_dev, float* obs_out_
                  uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream) {
     if (int rc = check_ready(e)) return rc;
     if (K < 1) return fail(QR_E_INVALID, "qr_step_many: num_steps must be >= 1");
+    if (int rc = check_term_rows(e, K, "qr_step_many")) return rc;
     if (!actions_dev || !obs_out_dev || !rew_out_dev || !done_out_dev)
         return fail(QR_E_INVALID, "qr_step_many: actions/obs/rew/done buffers are required");
     hipStream_t st = (hipStream_t)stream;
@@ -410,6 +422,7 @@ int qr_step_launches(qr_env* e, int32_t K, const float* actions_dev, float* obs_
                      uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream) {
     if (int rc = check_ready(e)) return rc;
     if (K < 1) return fail(QR_E_INVALID, "qr_step_launches: num_steps must be >= 1");
+    if (int rc = check_term_rows(e, K, "qr_step_launches")) return rc;
     if (!actions_dev || !obs_out_dev || !rew_out_dev || !done_out_dev)
         return fail(QR_E_INVALID, "qr_step_launches: actions/obs/rew/done buffers are required");
     hipStream_t st = (hipStream_t)stream;
@@ -471,6 +484,7 @@ int qr_rollout_policy(qr_env* e, qr_policy* policy, int32_t K, const float* log_
                       float* last_obs_dev, void* stream) {
     if (int rc = check_ready(e)) return rc;
     if (K < 1 || !policy || !log_std) return fail(QR_E_INVALID, "qr_rollout_policy: bad argument");
+    if (int rc = check_term_rows(e, K, "qr_rollout_policy")) return rc;
     if (!obs_out_dev || !act_out_dev || !logp_out_dev || !rew_out_dev || !done_out_dev)
         return fail(QR_E_INVALID, "qr_rollout_policy: obs/act/logp/rew/done buffers are required");
     if (e->P.flags & (qr::kFlagPause | qr::kFlagPauseIfCollision))
@@ -550,6 +564,7 @@ int qr_profile_steps(qr_env* e, int32_t K, const float* actions_dev, float* obs_
                      float* region_ms) {
     if (int rc = check_ready(e)) return rc;
     if (K < 1 || !mean_kernel_ms || !region_ms) return fail(QR_E_INVALID, "qr_profile_steps: bad argument");
+    if (int rc = check_term_rows(e, K, "qr_profile_steps")) return rc;
     if (!actions_dev || !obs_out_dev || !rew_out_dev || !done_out_dev)
         return fail(QR_E_INVALID, "qr_profile_steps: actions/obs/rew/done buffers are required");
     hipStream_t st = (hipStream_t)stream;
@@ -580,7 +595,7 @@ int qr_profile_steps(qr_env* e, int32_t K, const float* actions_dev, float* obs_
 
 #ifdef QR_PHASE_TIMING
 // profiling build only (tools/phase_timing.py): device buffer [n_waves][16] of shader-clock stamps, or NULL
-int qr_debug_set_ticks(qr_env* e, unsigned long long* ticks_dev) {
+__attribute__((visibility("default"))) int qr_debug_set_ticks(qr_env* e, unsigned long long* ticks_dev) {
     if (!e) return QR_E_INVALID;
     e->P.ticks = ticks_dev;
     e->P.tick_on = ticks_dev != nullptr;

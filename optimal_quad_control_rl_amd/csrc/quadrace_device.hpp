@@ -1,8 +1,10 @@
 // quadrace_device.hpp -- gfx950 device code of the vectorised quadrotor race environment.
 //
-// One lane simulates one environment.  Everything here is float32 elementwise ODE work (no MFMA):
-// the cost is HBM traffic for the state/obs plus ~2 k VALU instructions per env-step, so the layout
-// rules that matter are coalesced 16-byte-per-lane accesses and LDS-resident constant tables.
+// One lane simulates one environment.  The step is float32 elementwise ODE work (~570 VALU instructions per env-step)
+// plus ONE small per-wave GEMM: the first layer of the residual thrust / moment MLPs runs on the f32 matrix core
+// (20 x v_mfma_f32_32x32x2_f32 per wave-step, bit-exactly a k-ordered fmaf chain; see residual_mlp() for the measurements
+// that led there).  The layout rules that matter are coalesced 16-byte-per-lane accesses, LDS-resident constant tables
+// and MLP weights held once per wave in registers.
 //
 // Behavioural contract = the reference's Quadcopter3DGates (R: "3D quad race.ipynb",
 // I: "3D quad race INDI inner loop.ipynb"; raw .ipynb line numbers):

@@ -618,13 +618,8 @@ hipError_t launch_rollout_policy_vg(const Params& P, const PolicyArgs& A, int K,
     constexpr int L = obs_len<V, GA>();
     const size_t lds = (size_t)PolicyDims<L>::kTotalHalf8 * 16 +
                        sizeof(float) * (kResetTableFloats + kMaxGates * kGateStride + kBlock * L);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_policy_kernel<V, GA>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static unsigned long long configured = 0;   // per device ordinal
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(rollout_policy_kernel<V, GA>), lds, configured)) return e;
     hipLaunchKernelGGL((rollout_policy_kernel<V, GA>), grid_for(P.n), dim3(kBlock), lds, st, P, A, K, obs,
                        reinterpret_cast<float4*>(act), logp, rew, done, trunc, last_obs);
     return hipGetLastError();

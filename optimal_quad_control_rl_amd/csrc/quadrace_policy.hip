@@ -51,13 +51,8 @@ policy_kernel(const half8* __restrict__ weights, int n, const float* __restrict_
 template <int L>
 hipError_t launch_policy_L(const half8* w, int n, const float* obs, float* mean, hipStream_t st) {
     const size_t lds = (size_t)PolicyDims<L>::kTotalHalf8 * 16;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(policy_kernel<L>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static unsigned long long configured = 0;   // per device ordinal
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(policy_kernel<L>), lds, configured)) return e;
     hipLaunchKernelGGL(policy_kernel<L>, dim3((n + kPolBlock - 1) / kPolBlock), dim3(kPolBlock), lds, st, w, n, obs,
                        reinterpret_cast<float4*>(mean));
     return hipGetLastError();

@@ -22,6 +22,18 @@
 
 namespace qr {
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel, and one process may drive handles on
+// several GPUs (include/quadrace.h): each launch site keeps a mask of the device ordinals it has configured.
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, unsigned long long& done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && ((done_mask >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done_mask |= 1ull << dev;
+    return e;
+}
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16p __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2p __attribute__((ext_vector_type(2)));

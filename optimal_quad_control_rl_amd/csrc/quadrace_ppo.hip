@@ -1452,7 +1452,9 @@ __global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
             const bool stop_m = a.kl_limit > 0.0f && red[6] > a.kl_limit;   // SB3: checked BEFORE the optimiser step of this minibatch
             const bool finite_m = nsq <= 3.0e38f;                            // false for inf and NaN
             c->gen = gen + 1u;   // every workgroup has read `gen` before it arrived; visible to the next launch
-            const unsigned int hi = want | (stop_m ? kGoStop : 0u) | (finite_m ? 0u : kGoNonFinite);
+            // a barrier that timed out (never observed) releases with the non-finite verdict: NOBODY steps on a norm that lacks
+            // some workgroups' sums (the launch is counted in barrier_timeouts and in skipped_nonfinite)
+            const unsigned int hi = want | (stop_m ? kGoStop : 0u) | ((finite_m && all) ? 0u : kGoNonFinite);
             __hip_atomic_store(&c->go, ((unsigned long long)hi << 32) | (unsigned long long)__float_as_uint(nsq), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1617,23 +1619,16 @@ struct PpoOps {
     // phase A + phase B: per-sample-chunk partial gradients in d_partial, per-wave sums in d_wave; returns the chunk count
     static int grad(qr_ppo* p, qr::PpoBatch b, hipStream_t st, int* chunks_out) {
         const size_t lds = (size_t)D::kImage * 16 + 7 * qr::kStashRows * sizeof(float);  // operand images + per-sample stash
-        static bool configured = false;
-        if (!configured) {
-            PPO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 256>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            PPO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 512>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured = true;
+        static unsigned long long configured_a = 0, configured_a8 = 0;   // per device ordinal
+        if (!p->fused) {
+            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 256>), lds, configured_a));
+            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 512>), lds, configured_a8));
         }
         if (int rc = adv_stats(p, b, st)) return rc;
         if (p->fused) {   // one kernel: forward, backward and the weight gradients of 128 samples per workgroup and pass
             const size_t lds_f = ((size_t)D::kImage + qr::kExHalf8) * 16 + 7 * qr::kStashRows * sizeof(float);
-            static bool configured_f = false;
-            if (!configured_f) {
-                PPO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(qr::ppo_grad_kernel<L>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-                configured_f = true;
-            }
+            static unsigned long long configured_f = 0;   // per device ordinal
+            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad_kernel<L>), lds_f, configured_f));
             const int pairs = (b.G + 1) / 2;
             const int wgs = pairs < qr_ppo::kFusedChunks ? pairs : qr_ppo::kFusedChunks;
             hipLaunchKernelGGL((qr::ppo_grad_kernel<L>), dim3(wgs, 2), dim3(256), lds_f, st, b, p->d_partial, p->num_params);
@@ -1777,7 +1772,7 @@ int qr_ppo_destroy(qr_ppo* p) {
 }
 
 #ifdef QR_PHASE_TIMING
-int qr_ppo_debug_set_ticks(qr_ppo* p, unsigned long long* ticks_dev) { p->ticks = ticks_dev; return QR_OK; }
+__attribute__((visibility("default"))) int qr_ppo_debug_set_ticks(qr_ppo* p, unsigned long long* ticks_dev) { p->ticks = ticks_dev; return QR_OK; }
 #endif
 
 int qr_ppo_num_params(const qr_ppo* p) { return p ? p->num_params : ppofail(QR_E_INVALID, "qr_ppo_num_params: null handle"); }

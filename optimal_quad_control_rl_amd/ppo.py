@@ -523,8 +523,62 @@ class PPO:
         return self
 
     @torch.no_grad()
-    def predict(self, obs, deterministic=True):
+    def act_device(self, obs, deterministic=True):
+        """Device-tensor policy evaluation for evaluation loops that stay on the GPU: actions [n, 4] clipped to the Box, as a CUDA
+        tensor.  (The SB3-shaped `predict() -> (numpy actions, None)` of the reference's cells lives on `sb3.PPO`.)"""
         if not isinstance(obs, torch.Tensor):
             obs = torch.as_tensor(obs, dtype=torch.float32, device=self.dev)
         a, _, _ = self.policy.act(obs, deterministic=deterministic)
         return a.clamp(-1.0, 1.0)
+
+    # ------------------------------------------------------------------------------------------------ checkpoints
+    def sync_parameters(self):
+        """Call after the policy parameters were changed by anything but train() (e.g. a loaded checkpoint)."""
+        if self._updater is not None:
+            self._updater.pack()
+
+    @torch.no_grad()
+    def state_dict(self):
+        """Everything beyond the policy parameters that the next collect() / train() depends on: optimiser state, step counters,
+        episode accumulators, the env's state (positions in its reset streams included) and torch's generators (minibatch
+        permutations).  With the same env constructor arguments, load_state_dict() continues the run bit for bit."""
+        if self._updater is not None:
+            opt = dict(kind="mfma_adam", m=self._updater.m.clone(), v=self._updater.v.clone(), step=int(self._updater.step),
+                       betas=tuple(self._updater.betas), eps=float(self._updater.eps), lr=float(self.opt.param_groups[0]["lr"]))
+        else:
+            opt = dict(kind="torch_adam", state=self.opt.state_dict())
+        world, dist, target, steps, episode = self.env.get_state_tensors()
+        env = dict(world=world.cpu(), dist=None if dist is None else dist.cpu(), target=target.cpu(), steps=steps.cpu(),
+                   episode=episode.cpu())
+        return dict(optimizer=opt, num_timesteps=int(self.num_timesteps), ep_ret=self.ep_ret.cpu(), ep_len=self.ep_len.cpu(),
+                    ep_gates=self.ep_gates.cpu(), stats=dict(self.stats), noise_seed=int(self.noise_seed),
+                    lr0=float(self.lr0), lr_final_frac=float(self.lr_final_frac), total_hint=self.total_hint,
+                    kl_trips=int(getattr(self, "_kl_first_trips", 0)), env=env, rng_cpu=torch.get_rng_state(),
+                    rng_cuda=torch.cuda.get_rng_state(self.dev))
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        opt = sd["optimizer"]
+        if self._updater is not None:
+            assert opt["kind"] == "mfma_adam", "checkpoint was written by the torch optimiser path"
+            self._updater.m.copy_(opt["m"])
+            self._updater.v.copy_(opt["v"])
+            self._updater.step = int(opt["step"])
+            for g in self.opt.param_groups:
+                g["lr"] = float(opt["lr"])
+            self._updater.pack()
+        else:
+            assert opt["kind"] == "torch_adam", "checkpoint was written by the matrix-core update path"
+            self.opt.load_state_dict(opt["state"])
+        self.num_timesteps = int(sd["num_timesteps"])
+        self.ep_ret.copy_(sd["ep_ret"]); self.ep_len.copy_(sd["ep_len"]); self.ep_gates.copy_(sd["ep_gates"])
+        self.stats = dict(sd["stats"])
+        self.noise_seed = int(sd["noise_seed"])
+        self.lr0, self.lr_final_frac, self.total_hint = float(sd["lr0"]), float(sd["lr_final_frac"]), sd["total_hint"]
+        self._kl_first_trips = int(sd.get("kl_trips", 0))
+        e = sd["env"]
+        self.env.set_state_tensors(world=e["world"], dist=e["dist"], target=e["target"], steps=e["steps"], episode=e["episode"])
+        self.env.update_states()
+        self.obs = self.env.states_tensor.clone()
+        torch.set_rng_state(sd["rng_cpu"])
+        torch.cuda.set_rng_state(sd["rng_cuda"], self.dev)

@@ -473,7 +473,11 @@ class Quadcopter3DGates(_Base):
         if self.infos_mode == "sb3":
             if done_np.any():
                 idx = np.nonzero(done_np)[0]
-                term = self._term_obs_buf[torch.as_tensor(idx, device=self.device)].cpu().numpy()   # rows written by the step kernel
+                if self._pause_if_collision:   # no auto-reset in this mode (R:573-578): the row handed back IS the final observation
+                    term = obs_np[idx]
+                else:
+                    tb = self._term_obs_buf if self._term_obs_buf.dim() == 2 else self._term_obs_buf[0]   # qr_step writes row [0][env]
+                    term = tb[torch.as_tensor(idx, device=self.device)].cpu().numpy()   # rows written by the step kernel
                 for j, i in enumerate(idx):
                     infos[i]["terminal_observation"] = term[j]
                     infos[i]["TimeLimit.truncated"] = bool(trunc_np[i])
@@ -517,11 +521,13 @@ class Quadcopter3DGates(_Base):
         rollout_policy_device (row [k, env]).  Rows of envs that did not finish are left untouched.  This is what SB3
         bootstraps time-limit truncations from; the reference itself fills `terminal_observation` after reset_()
         (R:589-594), i.e. with the first observation of the NEXT episode."""
+        rows = 0
         if buf is not None:
             assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous() and buf.shape[-1] == self.state_len
-            assert buf.shape[-2] == self.num_envs
+            assert buf.dim() in (2, 3) and buf.shape[-2] == self.num_envs
+            rows = int(buf.shape[0]) if buf.dim() == 3 else 1   # K-step calls with K > rows are refused by the library
         self._term_obs_buf = buf   # keep it alive while the library holds the pointer
-        _lib.check(self._L.qr_set_terminal_obs(self._h, _ptr(buf)))
+        _lib.check(self._L.qr_set_terminal_obs(self._h, _ptr(buf), rows))
 
     def probe_residual(self):
         """[N, 7] device tensor (vb[3], residual thrust, residual moment[3]) of the current states (E2E + residual only)."""

@@ -30,7 +30,21 @@ def test_library_builds_and_exports_every_header_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/*.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert _lib.load().qr_abi_version() == 2
+    assert _lib.load().qr_abi_version() == 3
+
+
+def test_dynamic_symbol_table_holds_the_c_abi_only():
+    """libquadrace.so is built with -fvisibility=hidden and a linker version script: `nm -D` lists the qr_* / q3_* entry
+    points of include/*.h and nothing else (no C++ launchers, kernel handles or std:: template instantiations)."""
+    import subprocess
+
+    from optimal_quad_control_rl_amd import build
+
+    build.build_native()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", build.LIB], text=True)
+    syms = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert syms and all(s.startswith(("qr_", "q3_")) for s in syms), [s for s in syms if not s.startswith(("qr_", "q3_"))]
+    assert sorted(syms) == header_functions()
 
 
 def test_no_cpu_fallback():

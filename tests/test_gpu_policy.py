@@ -182,5 +182,5 @@ def test_ppo_native_update_learns():
     assert torch.isfinite(model._updater.theta).all()
     # the deterministic policy the kernels trained is what torch's predict() evaluates
     obs = env.reset_device()
-    a = model.predict(obs)
+    a = model.act_device(obs)
     assert a.shape == (8192, 4) and torch.isfinite(a).all() and float(a.abs().max()) <= 1.0

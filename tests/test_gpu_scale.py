@@ -319,7 +319,7 @@ def test_ppo_consumes_device_tensors_and_improves():
     assert model.num_timesteps >= 8192 * 64 * 40
     assert last["ep_len_mean"] > 1.5 * first["ep_len_mean"], (first, last)
     assert last["reward_per_step"] > first["reward_per_step"]
-    a = model.predict(env.states_tensor)
+    a = model.act_device(env.states_tensor)
     assert a.shape == (8192, 4) and float(a.abs().max()) <= 1.0
 
 

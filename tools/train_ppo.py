@@ -84,7 +84,7 @@ lap_start = torch.zeros(n_eval, device=dev)         # time of the last lap bound
 lap_sum = torch.zeros(7, device=dev); lap_cnt = torch.zeros(7, device=dev)   # laps 1..6 (index 0 unused)
 dt = 0.01
 for k in range(2000):
-    obs, rew, done, trunc = ev.step_device(model.predict(obs).contiguous())
+    obs, rew, done, trunc = ev.step_device(model.act_device(obs).contiguous())
     t = (k + 1) * dt
     g = (rew > 5).float()
     if k < 1200:
