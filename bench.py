@@ -52,6 +52,13 @@ BYTES_PER_ENV_STEP = {"e2e": lambda ga: 189 + 4 * (20 + 4 * ga), "indi": lambda 
 # obs / reward / done / trunc out: E2E 16 + 4*(20+4G) + 6 = 118 B, INDI 16 + 4*(13+4G) + 6 = 90 B at G=1 (PMC: 121.5 / 92.3 B)
 FUSED_BYTES_PER_ENV_STEP = {"e2e": lambda ga: 16 + 4 * (20 + 4 * ga) + 6, "indi": lambda ga: 16 + 4 * (13 + 4 * ga) + 6}
 MIN_TIMED_MS = 20.0
+# Numbers in the line that were NOT measured by this run: PMC counter figures collected by the builder with rocprofv3 (separate
+# --pmc passes) and committed under profiles/.  They are labelled with the file and the commit that added it.
+PMC_SOURCES = {
+    "traffic": "builder-measured, not this run: profiles/pmc_summary.json @ 333de90 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)",
+    "flop": "builder-measured, not this run: profiles/r02_pmc_compute.json @ 333de90 (rocprofv3 --pmc SQ_INSTS_VALU_* / MFMA_MOPS, tools/pmc_compute.py)",
+    "launch_floor": "builder-measured, not this run: profiles/r02_launch_floor.json @ 333de90 (tools/ubench/launch_floor.hip)",
+}
 
 
 def parse(argv=None):
@@ -151,24 +158,27 @@ class Runtime:
             dist.destroy_process_group()
 
 
-def timed_region(rt, fn, repeats, min_ms=MIN_TIMED_MS, max_reps=100000):
+def timed_region(rt, fn, repeats, min_ms=MIN_TIMED_MS, max_reps=100000, batch=1):
     """Time fn() (= EXACTLY K steps) with barrier + synchronize on both sides.  fn is repeated R times inside one bracket
     so that the bracket holds >= min_ms of work (R is derived from an all-reduced estimate: identical on every rank);
-    returns (seconds per fn() = median bracket / R, maximum over ranks; list of per-bracket seconds per fn(); R)."""
+    returns (seconds per fn() = median bracket / R, maximum over ranks; list of per-bracket seconds per fn(); R).
+    `batch` > 1: one call of fn() runs the K-step region `batch` times (a replayed graph of `batch` launches); times are still
+    reported per K-step region and R counts regions."""
     def bracket(R):
         rt.barrier()
         t0 = time.perf_counter()
-        for _ in range(R):
+        for _ in range(max(1, R // batch)):
             fn()
         rt.barrier()
-        return time.perf_counter() - t0
+        return (time.perf_counter() - t0) * (R / (batch * max(1, R // batch)))   # per R regions
 
-    R = 1
+    R = batch
     for _ in range(6):  # grow R until one bracket holds >= min_ms (decisions on the all-reduced time: same R on every rank)
         el = rt.max_over_ranks(bracket(R))
         if el >= min_ms * 1e-3 or R >= max_reps:
             break
         R = int(min(max_reps, max(R + 1, math.ceil(1.15 * R * min_ms * 1e-3 / max(el, 1e-7)))))
+        R = (R + batch - 1) // batch * batch
     for _ in range(4):
         ts = [bracket(R) / R for _ in range(max(1, repeats))]
         # the calibration bracket can be a slow outlier (first touch, a noisy host): if the MEDIAN bracket of the measurement
@@ -177,7 +187,32 @@ def timed_region(rt, fn, repeats, min_ms=MIN_TIMED_MS, max_reps=100000):
         if med * R >= min_ms * 1e-3 or R >= max_reps:
             break
         R = int(min(max_reps, max(R + 1, math.ceil(1.25 * min_ms * 1e-3 / max(med, 1e-9)))))
+        R = (R + batch - 1) // batch * batch
     return med, ts, R
+
+
+def graph_of_launches(rt, fn, batch):
+    """`batch` back-to-back calls of fn() -- each ONE K-step launch through the C ABI -- captured into a graph and replayed:
+    consecutive kernel nodes of a graph start ~1 us sooner after each other than stream launches (tools/ubench/launch_floor.hip),
+    which is what a short K-step region (the driver's --steps 20 = one 60 us kernel) otherwise loses between launches.
+    Returns (replay callable, batch) or (fn, 1) when capture is not possible (CPU stand-in, capture error)."""
+    if not rt.use_cuda or batch <= 1:
+        return fn, 1
+    import torch
+
+    try:
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(batch):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        return g.replay, batch
+    except Exception:  # pragma: no cover
+        torch.cuda.synchronize()
+        return fn, 1
 
 
 def _load_json(*path):
@@ -187,23 +222,23 @@ def _load_json(*path):
         return {}
 
 
-def exchange_probe(rt, obs, rew, done):
-    """rollout-boundary exchange (config 4): all-gather of the packed [obs | reward | done] shard"""
-    import torch
-    import torch.distributed as dist
-    from optimal_quad_control_rl_amd.sharded import pack_rollout
+def exchange_probe(rt, obs, rew, done, gather=None):
+    """rollout-boundary exchange (config 4): the rollout buffers as the kernels wrote them -- obs f32, reward f32, done u8 -- go
+    out with one all_gather_into_tensor each into receive buffers [world][K][n][...] that are allocated once
+    (optimal_quad_control_rl_amd.sharded.RolloutGather): no packing pass, no float copy of `done`, no rearranging copy."""
+    from optimal_quad_control_rl_amd.sharded import RolloutGather
 
-    packed = pack_rollout(obs, rew, done)
-    gathered = torch.empty((rt.world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(gathered, packed)
+    gather = gather or RolloutGather()
+    g = gather.gather(obs, rew, done)   # first call allocates the receive buffers
     rt.barrier()
     t0 = time.perf_counter()
-    dist.all_gather_into_tensor(gathered, packed)
+    g = gather.gather(obs, rew, done)
     rt.barrier()
     dt = rt.max_over_ranks(time.perf_counter() - t0)
-    nbytes = packed.numel() * packed.element_size()
-    return {"op": "all_gather_into_tensor", "steps": int(packed.shape[0]), "bytes_per_rank": nbytes, "ms": dt * 1e3,
-            "GBps_in_per_gpu": nbytes * (rt.world - 1) / dt / 1e9, "gathered_shape": list(gathered.shape)}
+    nbytes = sum(t.numel() * t.element_size() for t in (obs, rew, done))
+    return {"op": "3 x all_gather_into_tensor (obs f32, reward f32, done u8) into preallocated [world][K][n][...] buffers",
+            "steps": int(obs.shape[0]), "bytes_per_rank": nbytes, "ms": dt * 1e3,
+            "GBps_in_per_gpu": nbytes * (rt.world - 1) / dt / 1e9, "gathered_shape": list(g.obs.shape), "gathered_bytes": g.nbytes}
 
 
 def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
@@ -231,9 +266,25 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
     floor = _load_json("profiles", "r02_launch_floor.json").get("us_per_launch", {})
     bytes_per_step = BYTES_PER_ENV_STEP[variant](ga) * n
 
-    # (1) fused rollout: qr_step_many = ONE kernel for the K steps, env state register-resident between steps
-    fused_s, fused_ts, fused_R = timed_region(rt, lambda: env.rollout_device(actions[:K], view(K)), repeats)
-    fused_kernel_ms = env.last_rollout_ms()  # hipEvents around the last launch, on the launch stream
+    # (1) fused rollout: qr_step_many = ONE kernel for the K steps, env state register-resident between steps.  A short region
+    # (the driver's --steps 20 is one ~60 us kernel) is replayed as a graph of `gb` such launches, so that the gaps between
+    # launches do not dominate it; the library's per-call hipEvent bracket is off inside the timed region and switched back on for
+    # ONE extra launch, whose duration is the kernel time of the roofline.
+    def one_region():
+        env.rollout_device(actions[:K], view(K))
+
+    timing_knob = hasattr(env, "set_timing")
+    if timing_knob:
+        env.set_timing(False)
+    fused_fn, gb = graph_of_launches(rt, one_region, max(1, min(16, -(-320 // max(K, 1)))))
+    fused_s, fused_ts, fused_R = timed_region(rt, fused_fn, repeats, batch=gb)
+    if timing_knob:
+        env.set_timing(True)
+    kernel_ms_samples = []
+    for _ in range(5):
+        one_region()
+        kernel_ms_samples.append(env.last_rollout_ms())  # hipEvents around this launch, on the launch stream
+    fused_kernel_ms = float(np.median(kernel_ms_samples))
     launch_s = fused_kernel_ms * 1e-3
     flop = pmcc.get(f"rollout_kernel<{vidx}, {ga}>", {}).get("derived", {}).get("f32_flop_per_env_step")
     traffic = pmc.get("fused_hbm_bytes_per_step")
@@ -253,7 +304,13 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
                          "frac": None if tf is None else tf / VALU_F32_PEAK_TF, "flop_per_env_step": flop,
                          "flop_source": "PMC: 64 x (ADD + MUL + TRANS + 2 FMA f32 wave-instructions) + 512 x MFMA_MOPS_F32 per env-step, "
                                         "profiles/r02_pmc_compute.json; the larger of the two fractions names the binding roof"}}
-    res = {"value": total_steps / fused_s, "ms_per_step": fused_s * 1e3 / K, "repeats": len(fused_ts), "launches_per_bracket": fused_R,
+    roofline["frac_on_8d_bytes"] = bytes_per_step * K / launch_s / 1e9 / HBM_PEAK_GBS
+    roofline["frac_on_8d_bytes_note"] = ("SURVEY 8(d)'s %d B per env-step (state read + written every step) divided by this kernel's time: "
+                                         "NOT its traffic (the state stays in registers) -- BASELINE.md section 4's throughput yardstick only"
+                                         % BYTES_PER_ENV_STEP[variant](ga))
+    res = {"value": total_steps / fused_s, "value_kernel_only": n * K / launch_s * rt.world,
+           "launch": ("graph of %d K-step launches, replayed" % gb) if gb > 1 else "stream launches",
+           "ms_per_step": fused_s * 1e3 / K, "repeats": len(fused_ts), "launches_per_bracket": fused_R,
            "timed_ms_per_bracket": fused_s * fused_R * 1e3, "all_ms_per_step": [t * 1e3 / K for t in fused_ts], "roofline": roofline}
 
     # (2) per-step launches: K step kernels (one per env.step()), captured once into a graph by qr_step_launches and replayed
@@ -296,6 +353,7 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
             cl_ms = cl_s * 1e3   # bracket time per launch (back-to-back launches; rocprofv3's per-kernel average agrees with it,
             #                      while the hipEvent pair of a queued launch can include part of its predecessor)
             pol_flop = 2.0 * (16 * ((L + 16) // 16) * 128 + 2 * 128 * 128 + 128 * 32)   # f16 MACs x 2 as issued (padded tiles): PMC 81 920 at L = 17 / 24
+            pol_flop_useful = 2.0 * ((L + 1) * 120 + 2 * 121 * 120 + 121 * 4)           # the network's own multiply-adds (biases included)
             cl_tf = pol_flop * n * Kc / (cl_ms * 1e-3) / 1e12
             res["closed_loop"] = {
                 "what": "qr_rollout_policy: K x [obs -> policy MLP (L->120->120->120->4, f16 MFMA) -> Gaussian sample -> env.step] in "
@@ -303,7 +361,8 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
                 "steps": Kc, "ms_per_step": cl_s * 1e3 / Kc, "value": n * rt.world * Kc / cl_s, "unit": "env-steps/s",
                 "kernel_us_per_step": cl_ms * 1e3 / Kc,
                 "roofline": {"bound": "mfma", "achieved": cl_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": cl_tf / MFMA_F16_PEAK_TF,
-                             "flop_per_env_step": pol_flop,
+                             "flop_per_env_step": pol_flop, "flop_useful_per_env_step": pol_flop_useful,
+                             "frac_useful": pol_flop_useful * n * Kc / (cl_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF,
                              "traffic": None if pmc.get("closed_loop_hbm_bytes_per_step") is None else pmc["closed_loop_hbm_bytes_per_step"] * Kc,
                              "hbm": None if pmc.get("closed_loop_hbm_bytes_per_step") is None else {
                                  "achieved": pmc["closed_loop_hbm_bytes_per_step"] / (cl_ms * 1e-3 / Kc) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -432,6 +491,94 @@ def cpu_baseline(variant, n, ga, seconds):
             "value_1core": out[1][0], "host_cores": cores}
 
 
+def rccl_report(rt, local_ms_per_step):
+    """What the collectives backend saw, so that a mis-launched multi-GPU run is visible in the JSON: world size and backend from
+    the process group, the RCCL version, and every rank's OWN ms_per_step (the headline uses the maximum)."""
+    if not rt.collectives:
+        return None
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([float(local_ms_per_step), float(rt.local_rank)], device=rt.device, dtype=torch.float64)
+    allv = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(allv, t)
+    rep = {"rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(),
+           "per_rank_ms_per_step": [float(v[0]) for v in allv], "per_rank_local_rank": [int(v[1]) for v in allv]}
+    if rt.use_cuda:
+        try:
+            rep["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as ex:  # pragma: no cover
+            rep["rccl_version"] = repr(ex)
+        rep["device"] = torch.cuda.get_device_name(rt.device)
+        rep["visible_gpus"] = torch.cuda.device_count()
+    return rep
+
+
+def _short(x, n=160):
+    return x if not isinstance(x, str) or len(x) <= n else x[:n - 3] + "..."
+
+
+def headline(result):
+    """The ONE line the driver parses: the contract's fields plus a FLAT `roofline` object that carries every fraction quoted in
+    DESIGN.md section 5 (fused kernel on its own bytes, the vector-flop view, SURVEY 8(d)'s yardstick, the per-step kernel, the
+    closed loop with as-issued and useful flop) and the provenance of anything not measured by this run.  Everything else stays in
+    the full object (stderr + gpurun_out/bench_full_*.json).  Kept under 4 KB."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "value_kernel_only", "launch")
+    h = {k: result[k] for k in keep if k in result}
+    c = result["config"]
+    h["config"] = {"workload": _short(c["workload"], 220), "envs_per_gpu": c["envs_per_gpu"], "variant": c["variant"],
+                   "gates_ahead": c["gates_ahead"], "obs_len": c["obs_len"]}
+    r = result.get("roofline", {})
+    flat = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_us", "us_per_step",
+                                  "bytes_per_env_step", "frac_on_8d_bytes")}
+    flat["traffic_source"] = PMC_SOURCES["traffic"]
+    v = r.get("valu") or {}
+    flat["valu_frac"], flat["valu_flop_per_env_step"], flat["valu_flop_source"] = v.get("frac"), v.get("flop_per_env_step"), PMC_SOURCES["flop"]
+    ps = result.get("per_step_launch") or {}
+    pr = ps.get("roofline") or {}
+    flat.update({"per_step_kernel": pr.get("kernel"), "per_step_kernel_us": pr.get("kernel_us"), "per_step_frac": pr.get("frac"),
+                 "per_step_bytes_per_launch": pr.get("bytes_per_launch"), "per_step_traffic": pr.get("traffic"),
+                 "per_step_value": ps.get("value")})
+    cl = result.get("closed_loop") or {}
+    cr = cl.get("roofline") or {}
+    flat.update({"closed_loop_us_per_step": cl.get("kernel_us_per_step"), "closed_loop_value": cl.get("value"),
+                 "closed_loop_mfma_frac_as_issued": cr.get("frac"), "closed_loop_mfma_frac_useful": cr.get("frac_useful"),
+                 "closed_loop_flop_as_issued": cr.get("flop_per_env_step"), "closed_loop_flop_useful": cr.get("flop_useful_per_env_step")})
+    h["roofline"] = flat
+    cb = result.get("cpu_baseline")
+    if cb:
+        h["cpu_baseline"] = {k: _short(cb.get(k), 200) for k in ("value", "unit", "cores", "kind", "sample", "value_1core", "host_cores")}
+    o = result.get("indi") or result.get("e2e") or {}
+    if o and "error" not in o:
+        orr, ops = o.get("roofline") or {}, (o.get("per_step_launch") or {})
+        h["other_variant"] = {"variant": (o.get("config") or {}).get("variant"), "value": o.get("value"), "ms_per_step": o.get("ms_per_step"),
+                              "frac": orr.get("frac"), "us_per_step": orr.get("us_per_step"),
+                              "per_step_kernel_us": (ops.get("roofline") or {}).get("kernel_us"),
+                              "per_step_frac": (ops.get("roofline") or {}).get("frac"),
+                              "cpu_baseline_value": (o.get("cpu_baseline") or {}).get("value")}
+    pu, c5 = result.get("ppo_update") or {}, result.get("config5") or {}
+    if pu or c5:
+        h["ppo"] = {"update_us_per_16384_rows": pu.get("native_us"), "update_useful_TFLOPs": pu.get("useful_TFLOPs"),
+                    "update_mfma_frac": None if pu.get("useful_TFLOPs") is None else pu["useful_TFLOPs"] / MFMA_F16_PEAK_TF,
+                    "epoch_graph_us_per_update": pu.get("epoch_us"), "torch_us": pu.get("torch_us"),
+                    "config5_value": c5.get("value"), "config5_us_per_update": c5.get("us_per_update"),
+                    "config5_what": _short(c5.get("what"), 140)}
+    if "parity" in result:
+        h["parity"] = {k: result["parity"].get(k) for k in ("max_rel_dstate_100_steps", "tolerance", "error") if k in result["parity"]}
+    if result.get("rccl"):
+        h["rccl"] = result["rccl"]
+    for k in ("exchange", "config4"):
+        if k in result:
+            e = result[k] if k == "exchange" else dict(result[k], exchange=None)
+            h[k] = {kk: _short(vv, 120) for kk, vv in e.items() if kk not in ("what", "exchange") and not isinstance(vv, (dict, list))}
+            if k == "config4":
+                h[k]["exchange_ms"] = result[k]["exchange"]["ms"]
+                h[k]["exchange_GBps_in_per_gpu"] = result[k]["exchange"]["GBps_in_per_gpu"]
+    h["full_object"] = result.get("_full_path")
+    return h
+
+
 def workload_text(variant, n, ga):
     return (f"{n} envs/GPU, " + ("Bebop E2E (motor-cmd actions) + NNDroneModel residual MLPs + training disturbance ranges, 7-gate zigzag"
                                  if variant == "e2e" else "INDI inner-loop variant, 4-gate square (x2)")
@@ -456,6 +603,8 @@ def run(args, rt, env_factory=make_env, closed_loop=True):
         "path": "qr_step_many (fused K-step rollout kernel)",
     }
     result.update(m)
+    result["rccl"] = rccl_report(rt, float(np.median(m["all_ms_per_step"])))
+    result["provenance"] = PMC_SOURCES
 
     # --- rollout-boundary exchange: RCCL all-gather of [obs | reward | done] of this run's shard ------------------------
     if rt.collectives and not args.no_exchange:
@@ -547,7 +696,20 @@ def main():
     rt = Runtime.from_env(args.gpus)
     result = run(args, rt)
     if rt.rank == 0:
-        print(json.dumps(result))
+        # the full object: a file next to the profiles scratch (pulled back by gpurun) and stderr; stdout gets ONE compact line, last
+        full_path = None
+        try:
+            d = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(d, exist_ok=True)
+            full_path = os.path.join(d, "bench_full_n%d_%s_k%d.json" % (rt.world, args.variant, args.steps))
+            json.dump(result, open(full_path, "w"), indent=1)
+        except Exception:  # pragma: no cover
+            full_path = None
+        result["_full_path"] = None if full_path is None else os.path.relpath(full_path, ROOT)
+        print(json.dumps({k: v for k, v in result.items() if k != "_full_path"}), file=sys.stderr, flush=True)
+        line = json.dumps(headline(result))
+        assert len(line) < 4096, len(line)
+        print(line, flush=True)
     rt.finish()
 
 

@@ -163,6 +163,9 @@ int qr_set_state(qr_env* env, const float* world_dev, const float* dist_dev, con
  * qr_profile_steps: like qr_step_many, but brackets EVERY step kernel with its own hipEvent pair on the
  *   launch stream and returns the mean single-kernel duration (ms) and the whole-region time (ms). */
 int qr_last_step_many_ms(qr_env* env, float* total_ms);
+/* The hipEvent bracket behind qr_last_step_many_ms costs two marker packets per K-step call; on = 0 drops it (default: on).
+ * It is also skipped, whatever the setting, while the caller is capturing `stream` into a hipGraph. */
+int qr_set_timing(qr_env* env, int32_t on);
 int qr_profile_steps(qr_env* env, int32_t num_steps, const float* actions_dev, float* obs_out_dev,
                      float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream,
                      float* mean_kernel_ms, float* region_ms);

@@ -51,6 +51,7 @@ struct qr_env {
     float dist_scale = 1.0f;  // R:358
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_valid = false;
+    bool timing = true;         // qr_set_timing: bracket the K-step calls with hipEvents (two marker packets per call)
     // qr_step_launches: the K step-kernel launches of one call, captured once into a hipGraph and replayed while the
     // arguments stay the same (measured, tools/ubench/launch_floor.hip: back-to-back dependent launches cost 2.6 us
     // each on a stream and 1.5 us as consecutive kernel nodes of a graph)
@@ -154,6 +155,14 @@ int check_ready(const qr_env* e) {
     if (int rc = bind_device(e)) return rc;
     if (!e->has_track) return fail(QR_E_STATE, "qr_set_track has not been called");
     return QR_OK;
+}
+
+// hipEvent bracket of a K-step call: skipped when switched off (qr_set_timing) or while the caller captures `st` into a graph
+bool want_events(const qr_env* e, hipStream_t st) {
+    if (!e->timing) return false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return false;
+    return true;
 }
 
 // K-step entry points write terminal observations to row [k][env]: the registered buffer must hold K rows of N envs
@@ -409,12 +418,13 @@ int qr_step_many(qr_env* e, int32_t K, const float* actions_dev, float* obs_out_
     if (!actions_dev || !obs_out_dev || !rew_out_dev || !done_out_dev)
         return fail(QR_E_INVALID, "qr_step_many: actions/obs/rew/done buffers are required");
     hipStream_t st = (hipStream_t)stream;
-    QR_HIP(hipEventRecord(e->ev0, st));
+    const bool ev = want_events(e, st);
+    if (ev) QR_HIP(hipEventRecord(e->ev0, st));
     // one launch: the fused rollout kernel keeps the env state in registers across the K steps
     QR_HIP(qr::launch_rollout(e->cfg.variant, e->P, K, actions_dev, obs_out_dev, rew_out_dev, done_out_dev,
                               trunc_out_dev, st));
-    QR_HIP(hipEventRecord(e->ev1, st));
-    e->timing_valid = true;
+    if (ev) QR_HIP(hipEventRecord(e->ev1, st));
+    e->timing_valid = ev;
     return QR_OK;
 }
 
@@ -471,10 +481,11 @@ int qr_step_launches(qr_env* e, int32_t K, const float* actions_dev, float* obs_
         g.K = K; g.act = actions_dev; g.obs = obs_out_dev; g.rew = rew_out_dev; g.done = done_out_dev; g.trunc = trunc_out_dev;
         std::memcpy(&g.P, &e->P, sizeof(e->P));  // byte copy: compared with memcmp above
     }
-    QR_HIP(hipEventRecord(e->ev0, st));
+    const bool ev = want_events(e, st);
+    if (ev) QR_HIP(hipEventRecord(e->ev0, st));
     QR_HIP(hipGraphLaunch(g.exec, st));
-    QR_HIP(hipEventRecord(e->ev1, st));
-    e->timing_valid = true;
+    if (ev) QR_HIP(hipEventRecord(e->ev1, st));
+    e->timing_valid = ev;
     return QR_OK;
 }
 
@@ -510,11 +521,12 @@ int qr_rollout_policy(qr_env* e, qr_policy* policy, int32_t K, const float* log_
     A.step_hi = (uint32_t)(first_step >> 32);
     A.deterministic = deterministic ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    QR_HIP(hipEventRecord(e->ev0, st));
+    const bool ev = want_events(e, st);
+    if (ev) QR_HIP(hipEventRecord(e->ev0, st));
     QR_HIP(qr::launch_rollout_policy(e->cfg.variant, e->P, A, K, obs_out_dev, act_out_dev, logp_out_dev, rew_out_dev,
                                      done_out_dev, trunc_out_dev, last_obs_dev, st));
-    QR_HIP(hipEventRecord(e->ev1, st));
-    e->timing_valid = true;
+    if (ev) QR_HIP(hipEventRecord(e->ev1, st));
+    e->timing_valid = ev;
     return QR_OK;
 }
 
@@ -547,6 +559,13 @@ int qr_set_state(qr_env* e, const float* world_dev, const float* dist_dev, const
     if (int rc = check_ready(e)) return rc;  // target is reduced modulo num_gates
     QR_HIP(qr::launch_set_state(e->cfg.variant, e->P, world_dev, dist_dev, target_dev, steps_dev, episode_dev,
                                 (hipStream_t)stream));
+    return QR_OK;
+}
+
+int qr_set_timing(qr_env* e, int32_t on) {
+    if (!e) return fail(QR_E_INVALID, "qr_set_timing: null env");
+    e->timing = on != 0;
+    if (!e->timing) e->timing_valid = false;
     return QR_OK;
 }
 

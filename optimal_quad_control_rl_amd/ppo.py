@@ -243,6 +243,10 @@ class PPO:
         self.vf_coef, self.ent_coef, self.max_grad_norm = vf_coef, ent_coef, max_grad_norm
         self.target_kl, self.lr0, self.lr_final_frac, self.total_hint = target_kl, learning_rate, lr_final_frac, total_timesteps_hint
         torch.manual_seed(seed)
+        # minibatch permutations come from the trainer's OWN generator (checkpointed; independent of whatever else draws from
+        # torch's global generators in the process)
+        self._gen = torch.Generator(device=self.dev)
+        self._gen.manual_seed(int(seed))
         obs_dim = env.state_len
         self.policy = ActorCritic(obs_dim, 4, net_arch, log_std_init).to(self.dev)
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
@@ -443,7 +447,7 @@ class PPO:
         for _ in range(self.n_epochs):
             if stop:
                 break
-            perm = torch.randperm(B, device=self.dev)
+            perm = torch.randperm(B, device=self.dev, generator=self._gen)
             for s in range(0, B, self.batch_size):
                 idx = perm[s:s + self.batch_size]
                 a = adv[idx]
@@ -482,7 +486,7 @@ class PPO:
         up.stats.zero_()
         launched = 0
         for _ in range(self.n_epochs):
-            perm = torch.randperm(B, device=self.dev).to(torch.int32)
+            perm = torch.randperm(B, device=self.dev, generator=self._gen).to(torch.int32)
             up.begin_epoch(adv, perm, self.batch_size)
             for s in range(0, B, self.batch_size):
                 up.minibatch(obs, act, old_lp, adv, ret, perm[s:s + self.batch_size], lr, self.clip, self.vf_coef, self.ent_coef,
@@ -540,8 +544,8 @@ class PPO:
     @torch.no_grad()
     def state_dict(self):
         """Everything beyond the policy parameters that the next collect() / train() depends on: optimiser state, step counters,
-        episode accumulators, the env's state (positions in its reset streams included) and torch's generators (minibatch
-        permutations).  With the same env constructor arguments, load_state_dict() continues the run bit for bit."""
+        episode accumulators, the env's state (positions in its reset streams included) and the generator of the minibatch
+        permutations.  With the same env constructor arguments, load_state_dict() continues the run bit for bit."""
         if self._updater is not None:
             opt = dict(kind="mfma_adam", m=self._updater.m.clone(), v=self._updater.v.clone(), step=int(self._updater.step),
                        betas=tuple(self._updater.betas), eps=float(self._updater.eps), lr=float(self.opt.param_groups[0]["lr"]))
@@ -553,8 +557,7 @@ class PPO:
         return dict(optimizer=opt, num_timesteps=int(self.num_timesteps), ep_ret=self.ep_ret.cpu(), ep_len=self.ep_len.cpu(),
                     ep_gates=self.ep_gates.cpu(), stats=dict(self.stats), noise_seed=int(self.noise_seed),
                     lr0=float(self.lr0), lr_final_frac=float(self.lr_final_frac), total_hint=self.total_hint,
-                    kl_trips=int(getattr(self, "_kl_first_trips", 0)), env=env, rng_cpu=torch.get_rng_state(),
-                    rng_cuda=torch.cuda.get_rng_state(self.dev))
+                    kl_trips=int(getattr(self, "_kl_first_trips", 0)), env=env, rng=self._gen.get_state())
 
     @torch.no_grad()
     def load_state_dict(self, sd):
@@ -580,5 +583,4 @@ class PPO:
         self.env.set_state_tensors(world=e["world"], dist=e["dist"], target=e["target"], steps=e["steps"], episode=e["episode"])
         self.env.update_states()
         self.obs = self.env.states_tensor.clone()
-        torch.set_rng_state(sd["rng_cpu"])
-        torch.cuda.set_rng_state(sd["rng_cuda"], self.dev)
+        self._gen.set_state(sd["rng"])

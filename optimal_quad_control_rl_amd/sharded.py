@@ -1,12 +1,19 @@
-"""Multi-GPU sharding of the race environment: one process per GPU, independent env shards, and ONE
-RCCL collective at the rollout boundary (BASELINE config 4).
+"""Multi-GPU sharding of the race environment: one process per GPU, independent env shards, and the
+RCCL all-gather at the rollout boundary (BASELINE config 4).
 
 Env instances never interact (no cross-env term in R:501-595), so rank r simply simulates global envs
 [r*n_local, (r+1)*n_local): its in-kernel Philox stream is keyed by the GLOBAL env id (`env_id_base`), which
 makes the union of the shards bit-identical to one big env (tests/test_gpu_scale.py).  The only exchange is
-`gather_rollout`: an all-gather of the packed [obs | reward | done] rollout shard, issued once per rollout --
-never inside the step kernel's path.  xGMI is point-to-point (7 links x ~153 GB/s per GPU), so this direct
-all-gather is per-link bound: one large message per peer per rollout, not one per step.
+`gather_rollout`, issued once per rollout -- never inside the step kernel's path.  xGMI is point-to-point
+(7 links x ~153 GB/s per GPU), so the direct all-gather is per-link bound: one large message per peer per rollout.
+
+What is exchanged and how (round 3): the rollout buffers the kernels wrote -- obs [K][n][L] f32, reward [K][n] f32,
+done [K][n] u8 -- go out AS THEY ARE, one `all_gather_into_tensor` each, into receive buffers [world][K][n][...] that
+are allocated once and reused.  No packing pass, no float copy of `done` (a byte side channel: K n bytes instead of
+4 K n), no permute().reshape() copy of the gathered tensor: peak memory of a gather = the receive buffers themselves.
+Consumers index the rank-major result -- `GatheredRollout.rows()` (every (rank, step, env) row, which is all PPO's
+minibatch sampling needs) or `global_view()` ([K][world][n] strided views in global env order) -- instead of
+materialising a [K][N_global] copy.
 """
 import torch
 import torch.distributed as dist
@@ -19,14 +26,81 @@ def shard_range(num_envs_global, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def pack_rollout(obs, rew, done):
-    """[K,n,L] f32, [K,n] f32, [K,n] u8/bool -> one contiguous [K,n,L+2] f32 message."""
-    return torch.cat([obs, rew.unsqueeze(-1), done.to(obs.dtype).unsqueeze(-1)], dim=-1).contiguous()
+class GatheredRollout:
+    """Result of RolloutGather.gather(): obs [world][K][n][L] f32, rew [world][K][n] f32, done [world][K][n] u8 -- the
+    receive buffers themselves (valid until the next gather of the same shape).  Global env g = rank * n + i."""
+
+    __slots__ = ("obs", "rew", "done")
+
+    def __init__(self, obs, rew, done):
+        self.obs, self.rew, self.done = obs, rew, done
+
+    @property
+    def world(self):
+        return self.obs.shape[0]
+
+    @property
+    def steps(self):
+        return self.obs.shape[1]
+
+    @property
+    def envs_per_rank(self):
+        return self.obs.shape[2]
+
+    @property
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in (self.obs, self.rew, self.done))
+
+    def global_view(self):
+        """(obs [K][world][n][L], rew [K][world][n], done [K][world][n] bool) as strided VIEWS: element [k, r, i] is global
+        env r * n + i at step k.  (A contiguous [K][N_global] tensor would need a second full-size copy.)"""
+        return self.obs.permute(1, 0, 2, 3), self.rew.permute(1, 0, 2), self.done.permute(1, 0, 2).bool()
+
+    def rows(self):
+        """(obs [world K n][L], rew [world K n], done [world K n] u8): every sample of the gathered rollout as contiguous
+        views -- row index of (step k, global env g) is row_index(k, g)."""
+        L = self.obs.shape[-1]
+        return self.obs.view(-1, L), self.rew.view(-1), self.done.view(-1)
+
+    def row_index(self, k, g):
+        n = self.envs_per_rank
+        return ((g // n) * self.steps + k) * n + g % n
+
+    def step_of_env(self, k, g):
+        n = self.envs_per_rank
+        r, i = divmod(int(g), n)
+        return self.obs[r, k, i], self.rew[r, k, i], self.done[r, k, i]
 
 
-def unpack_rollout(packed):
-    """Inverse of pack_rollout on a gathered [...,L+2] tensor."""
-    return packed[..., :-2], packed[..., -2], packed[..., -1] > 0.5
+class RolloutGather:
+    """The rollout-boundary collective with its receive buffers held across calls (one set per distinct shape)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self._bufs = {}
+
+    def buffers(self, K, n, L, device, obs_dtype=torch.float32):
+        key = (int(K), int(n), int(L), str(device), obs_dtype)
+        b = self._bufs.get(key)
+        if b is None:
+            w = self.world
+            b = (torch.empty((w, K, n, L), dtype=obs_dtype, device=device), torch.empty((w, K, n), dtype=torch.float32, device=device),
+                 torch.empty((w, K, n), dtype=torch.uint8, device=device))
+            self._bufs[key] = b
+        return b
+
+    def gather(self, obs, rew, done):
+        """obs [K][n][L] f32, rew [K][n] f32, done [K][n] u8 (contiguous, as the rollout kernels write them)."""
+        assert obs.is_contiguous() and rew.is_contiguous() and done.is_contiguous()
+        assert done.dtype == torch.uint8 and rew.dtype == torch.float32
+        K, n, L = obs.shape
+        g_obs, g_rew, g_done = self.buffers(K, n, L, obs.device, obs.dtype)
+        # rank-major concatenation along dim 0 = the [world] axis of the receive buffers: nothing to rearrange afterwards
+        dist.all_gather_into_tensor(g_obs.view(self.world * K, n, L), obs, group=self.group)
+        dist.all_gather_into_tensor(g_rew.view(self.world * K, n), rew, group=self.group)
+        dist.all_gather_into_tensor(g_done.view(self.world * K, n), done, group=self.group)
+        return GatheredRollout(g_obs, g_rew, g_done)
 
 
 class ShardedRaceEnv:
@@ -46,6 +120,7 @@ class ShardedRaceEnv:
         if num_envs_global % self.world:
             raise ValueError("all_gather_into_tensor needs equal shards: num_envs_global % world_size != 0")
         self.env = env_factory(self.num_envs, self.lo)
+        self._gather = RolloutGather(group)
 
     def reset(self):
         return self.env.reset_device()
@@ -57,12 +132,5 @@ class ShardedRaceEnv:
         return self.env.rollout_device(actions_local)
 
     def gather_rollout(self, obs, rew, done):
-        """All ranks receive the full rollout: obs[K, N_global, L], rew[K, N_global], done[K, N_global]."""
-        packed = pack_rollout(obs, rew, done)  # [K, n, L+2]
-        K = packed.shape[0]
-        flat = torch.empty((self.world * K,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
-        dist.all_gather_into_tensor(flat, packed, group=self.group)  # concatenation along dim 0 (rank-major)
-        gathered = flat.view((self.world, K) + tuple(packed.shape[1:]))
-        # [world, K, n, L+2] -> [K, world*n, L+2]: rank-major = global env order
-        full = gathered.permute(1, 0, 2, 3).reshape(packed.shape[0], self.world * packed.shape[1], packed.shape[2])
-        return unpack_rollout(full)
+        """All ranks receive the full rollout as a GatheredRollout (rank-major receive buffers, reused between calls)."""
+        return self._gather.gather(obs, rew, done)

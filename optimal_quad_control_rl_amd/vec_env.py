@@ -190,6 +190,8 @@ class Quadcopter3DGates(_Base):
 
         n, dev = self.num_envs, self.device
         self._obs = torch.zeros((n, self.state_len), dtype=torch.float32, device=dev)
+        self._last_obs = self._obs      # where the current observation lives: the env's own buffer, or row K-1 of the caller's
+                                        # rollout buffer after a K-step call (a view: no copy kernel behind every rollout)
         self._rew = torch.zeros(n, dtype=torch.float32, device=dev)
         self._done = torch.zeros(n, dtype=torch.uint8, device=dev)
         self._trunc = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -361,16 +363,19 @@ class Quadcopter3DGates(_Base):
     @property
     def states(self):
         """Observation array [N, state_len] of the last reset()/step() (R:343, read by animate_policy R:803)."""
-        return self._obs.cpu().numpy()
+        return self._last_obs.cpu().numpy()
 
     @property
     def states_tensor(self):
-        return self._obs
+        """The current observation on the device.  After rollout_device / step_sequence_device this is a VIEW of the last row of
+        the rollout buffer that call wrote (valid until that buffer is overwritten); otherwise the env's own buffer."""
+        return self._last_obs
 
     # ------------------------------------------------------------------ reference methods
     def update_states(self):
         """update_states_gate (R:365-450)."""
         _lib.check(self._L.qr_observe(self._h, _ptr(self._obs), self._stream()))
+        self._last_obs = self._obs
 
     update_states_gate = update_states
 
@@ -381,6 +386,7 @@ class Quadcopter3DGates(_Base):
     def reset_(self, dones):
         mask = self._to_dev(np.asarray(dones, dtype=np.uint8), torch.uint8)
         _lib.check(self._L.qr_reset(self._h, _ptr(mask), _ptr(self._obs), self._stream()))
+        self._last_obs = self._obs
         return self.states
 
     def reset(self):
@@ -537,6 +543,7 @@ class Quadcopter3DGates(_Base):
 
     def reset_device(self):
         _lib.check(self._L.qr_reset(self._h, None, _ptr(self._obs), self._stream()))
+        self._last_obs = self._obs
         return self._obs
 
     def step_device(self, actions):
@@ -547,6 +554,8 @@ class Quadcopter3DGates(_Base):
         obs, rew, done, trunc = self._obs, self._rew, self._done, self._trunc
         _lib.check(self._L.qr_step(self._h, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(trunc),
                                    self._stream()))
+        if not self._pause:   # with pause set the kernel leaves the observation untouched (R:570-572)
+            self._last_obs = obs
         return obs, rew, done, trunc
 
     def rollout_device(self, actions, out=None):
@@ -564,7 +573,7 @@ class Quadcopter3DGates(_Base):
         _lib.check(self._L.qr_step_many(self._h, int(K), _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(trunc),
                                         self._stream()))
         if not self._pause:
-            self._obs.copy_(obs[K - 1])
+            self._last_obs = obs[K - 1]
         return out
 
     def step_sequence_device(self, actions, out):
@@ -575,7 +584,7 @@ class Quadcopter3DGates(_Base):
         _lib.check(self._L.qr_step_launches(self._h, int(K), _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done),
                                             _ptr(trunc), self._stream()))
         if not self._pause:
-            self._obs.copy_(obs[K - 1])
+            self._last_obs = obs[K - 1]
         return out
 
     def rollout_policy_device(self, policy, num_steps, log_std, noise_seed=0, first_step=0, deterministic=False, out=None):
@@ -596,6 +605,7 @@ class Quadcopter3DGates(_Base):
         _lib.check(self._L.qr_rollout_policy(self._h, policy._h, K, _f32p(ls), int(noise_seed), int(first_step),
                                              int(bool(deterministic)), _ptr(obs), _ptr(act), _ptr(logp), _ptr(rew),
                                              _ptr(done), _ptr(trunc), _ptr(self._obs), self._stream()))
+        self._last_obs = self._obs
         return obs, act, logp, rew, done, trunc, self._obs
 
     def profile_rollout(self, actions, out):
@@ -607,6 +617,10 @@ class Quadcopter3DGates(_Base):
         _lib.check(self._L.qr_profile_steps(self._h, int(K), _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done),
                                             _ptr(trunc), self._stream(), C.byref(mean_ms), C.byref(region_ms)))
         return float(mean_ms.value), float(region_ms.value)
+
+    def set_timing(self, on):
+        """hipEvent bracket around every K-step call (read back by last_rollout_ms()); off = two marker packets fewer per call"""
+        _lib.check(self._L.qr_set_timing(self._h, int(bool(on))))
 
     def last_rollout_ms(self):
         ms = C.c_float()

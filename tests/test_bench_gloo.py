@@ -98,10 +98,27 @@ def _worker(rank, world, port, tmp):
         assert res["n_gpus"] == world and res["steps"] == 6 and res["scaling"] == "weak"
         assert abs(res["value"] - 64 * world * 6 / (res["ms_per_step"] * 1e-3 * 6)) < 1e-6 * res["value"]
         assert res["timed_ms_per_bracket"] >= 0.9 * bench.MIN_TIMED_MS
-        ex = res["exchange"]
-        assert ex["gathered_shape"] == [world * 6, 64, 17 + 2] and ex["bytes_per_rank"] == 6 * 64 * 19 * 4
+        ex = res["exchange"]   # obs f32 + reward f32 + done u8, gathered into [world][K][n][...] receive buffers
+        assert ex["gathered_shape"] == [world, 6, 64, 17] and ex["bytes_per_rank"] == 6 * 64 * (17 * 4 + 4 + 1)
+        assert ex["gathered_bytes"] == world * ex["bytes_per_rank"]
         c4 = res["config4"]
-        assert c4["envs_total"] == 64 * world and c4["exchange"]["gathered_shape"][0] == world * c4["steps"]
+        assert c4["envs_total"] == 64 * world and c4["exchange"]["gathered_shape"][:2] == [world, c4["steps"]]
+        # the line says what the collectives backend saw: world size from the process group and every rank's own time
+        rc = res["rccl"]
+        assert rc["rccl_world_size"] == world and rc["backend"] == "gloo" and len(rc["per_rank_ms_per_step"]) == world
+        assert max(rc["per_rank_ms_per_step"]) <= res["ms_per_step"] * 1.5 and min(rc["per_rank_ms_per_step"]) > 0
+        # the compact headline: one line under 4 KB with the contract's fields and a flat roofline object
+        res["_full_path"] = None
+        line = json.dumps(bench.headline(res))
+        assert len(line) < 4096
+        h = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline"):
+            assert k in h, k
+        assert all(not isinstance(v, (dict, list)) for v in h["roofline"].values())
+        for k in ("frac", "frac_on_8d_bytes", "per_step_frac", "per_step_kernel_us", "valu_frac", "traffic_source"):
+            assert k in h["roofline"], k
+        assert h["rccl"]["rccl_world_size"] == world and "exchange_ms" in h["config4"]
         assert res["per_step_launch"]["roofline"]["bound"] == "hbm" and res["roofline"]["bound"] == "hbm" and res["roofline"]["frac"] < 1.0
         open(os.path.join(tmp, "ok"), "w").write("ok")
     rt.finish()

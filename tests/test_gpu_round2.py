@@ -421,13 +421,19 @@ def test_bench_collectives_over_rccl_on_one_rank():
            "--envs", "32768", "--repeats", "2", "--no-cpu-baseline", "--no-parity"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    j = json.loads(line)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096, "stdout carries ONE compact JSON line"
+    j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["value"] > 1e9
-    ex = j["exchange"]
-    assert ex["op"] == "all_gather_into_tensor" and ex["gathered_shape"][0] == ex["steps"] and ex["ms"] > 0
-    c4 = j["config4"]
-    assert c4["envs_per_gpu"] == 32768 and c4["exchange"]["bytes_per_rank"] > 0 and c4["value_incl_exchange"] > 0
+    assert j["rccl"]["rccl_world_size"] == 1 and j["rccl"]["backend"] == "nccl" and j["rccl"]["rccl_version"][0].isdigit()
+    assert len(j["rccl"]["per_rank_ms_per_step"]) == 1
+    assert j["exchange"]["ms"] > 0 and j["config4"]["envs_per_gpu"] == 32768 and j["config4"]["exchange_ms"] > 0
+    # the full object goes to stderr (and to gpurun_out/bench_full_*.json)
+    full = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith("{")][-1])
+    ex = full["exchange"]
+    assert ex["gathered_shape"][:2] == [1, ex["steps"]] and ex["gathered_bytes"] == ex["bytes_per_rank"]
+    c4 = full["config4"]
+    assert c4["exchange"]["bytes_per_rank"] > 0 and c4["value_incl_exchange"] > 0
 
 
 def test_data_parallel_training_over_rccl_on_one_rank():

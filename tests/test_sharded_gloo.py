@@ -60,18 +60,31 @@ def _worker(rank, world, port, n_global, K, tmp):
     g = torch.Generator().manual_seed(0)
     acts_global = torch.rand((K, n_global, 4), generator=g) * 2 - 1  # same on every rank
     obs, rew, done, trunc = env.rollout(acts_global[:, env.lo:env.hi].contiguous())
-    full_obs, full_rew, full_done = env.gather_rollout(obs, rew, done)
-    assert full_obs.shape == (K, n_global, obs.shape[-1]) and full_done.dtype == torch.bool
+    g = env.gather_rollout(obs, rew, done.to(torch.uint8))
+    assert g.obs.shape == (world, K, env.num_envs, obs.shape[-1]) and g.done.dtype == torch.uint8
+    full_obs, full_rew, full_done = g.global_view()       # strided views [K][world][n]: no second copy of the gathered rollout
+    assert full_obs.shape == (K, world, env.num_envs, obs.shape[-1]) and full_done.dtype == torch.bool
+    assert full_obs.data_ptr() == g.obs.data_ptr()
     # own shard is found at its global position
-    assert torch.equal(full_obs[:, env.lo:env.hi], obs) and torch.equal(full_rew[:, env.lo:env.hi], rew)
+    assert torch.equal(full_obs[:, rank], obs) and torch.equal(full_rew[:, rank], rew)
+    # the receive buffers are reused: a second gather lands in the same memory
+    g2 = env.gather_rollout(obs, rew, done.to(torch.uint8))
+    assert g2.obs.data_ptr() == g.obs.data_ptr() and g2.done.data_ptr() == g.done.data_ptr()
     if rank == 0:
         # the gathered rollout equals ONE unsharded env over all global ids (same global-id keyed reset stream)
         ref = CpuStandInEnv(n_global, 0)
         ref.reset_device()
         r_obs, r_rew, r_done, _ = ref.rollout_device(acts_global)
-        assert torch.equal(full_obs, r_obs) and torch.equal(full_rew, r_rew)
-        assert torch.equal(full_done, r_done.bool())
+        n = env.num_envs
+        assert torch.equal(full_obs.reshape(K, n_global, -1), r_obs) and torch.equal(full_rew.reshape(K, n_global), r_rew)
+        assert torch.equal(full_done.reshape(K, n_global), r_done.bool())
         assert r_done.sum() > 0
+        # flat row view: row_index(k, g) addresses (step k, global env g)
+        rows_obs, rows_rew, rows_done = g.rows()
+        for k, ge in ((0, 0), (K - 1, n_global - 1), (7, n + 3)):
+            assert torch.equal(rows_obs[g.row_index(k, ge)], r_obs[k, ge]) and rows_rew[g.row_index(k, ge)] == r_rew[k, ge]
+            o1, r1, d1 = g.step_of_env(k, ge)
+            assert torch.equal(o1, r_obs[k, ge]) and bool(d1) == bool(r_done[k, ge])
         open(os.path.join(tmp, "ok"), "w").write("ok")
     dist.barrier()
     dist.destroy_process_group()
@@ -92,15 +105,6 @@ def test_shard_range_partition():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
-
-
-def test_pack_unpack_roundtrip():
-    from optimal_quad_control_rl_amd.sharded import pack_rollout, unpack_rollout
-
-    obs, rew = torch.randn(3, 5, 17), torch.randn(3, 5)
-    done = torch.rand(3, 5) > 0.5
-    o, r, d = unpack_rollout(pack_rollout(obs, rew, done.to(torch.uint8)))
-    assert torch.equal(o, obs) and torch.equal(r, rew) and torch.equal(d, done)
 
 
 def _ddp_worker(rank, world, port, tmp):
