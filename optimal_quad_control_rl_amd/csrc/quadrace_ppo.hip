@@ -191,9 +191,14 @@ struct PpoBatch {
 };
 
 #ifdef QR_PHASE_TIMING
+#ifdef QR_PHASE_TIMING_NODRAIN   /* stamps without draining the queues: where the waves ARE, not what a stage costs in isolation */
+#define PPO_TICK_DRAIN() asm volatile("" ::: "memory")
+#else
+#define PPO_TICK_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#endif
 #define PPO_TICK(a, slot)                                                                                       \
     do {                                                                                                        \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                             \
+        PPO_TICK_DRAIN();                                                                                       \
         if ((a).ticks && (threadIdx.x & 63) == 0)                                                               \
             (a).ticks[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6)) * 16 + (slot)] = clock64(); \
     } while (0)
@@ -867,7 +872,7 @@ __device__ __forceinline__ void store_dw_tile(const f32x16p& acc, float* __restr
 }
 
 template <int L>
-__global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __restrict__ partial, int num_params) {
+__global__ void __launch_bounds__(256, 1) ppo_grad4_kernel(PpoBatch a, float* __restrict__ partial, int num_params) {
     using D = PpoDims<L>;
     using P = PolicyDims<L>;
     constexpr int KS1 = P::kSteps1;
@@ -1132,6 +1137,328 @@ __global__ void __launch_bounds__(256, 1) ppo_grad_kernel(PpoBatch a, float* __r
         }
         PPO_TICK(a, 15);
         // (the barrier at the top of the next pass separates these reads from its writes)
+    }
+}
+
+// ---- the same computation with the workgroup's two jobs on different waves (round 3) ------------------------------------------
+// ppo_grad4_kernel above walks ONE dependent chain per wave: forward, loss, then per layer [exchange d_l / h_(l-1) through LDS,
+// weight gradient dW_l (transposed reads + MFMAs + 64 f32 stores per lane), backward to d_(l-1)].  Its in-wave profile
+// (profiles/r02_ppo_phase_timing.txt) puts the weight-gradient half -- exchange, barriers, dW, stores: 22 k of 44 k cycles -- on the
+// critical path although nothing downstream needs dW.  Here a workgroup has EIGHT waves, two per SIMD:
+//   chain waves 0-3   one 32-sample tile each: gather, forward, loss, d3, d2, d1 -- and they publish (d_l, h_(l-1)) to the exchange
+//                     area as soon as d_l exists;
+//   dW waves 4-7      dW_l = d_l^T h_(l-1) over the workgroup's 128 samples (the 2 x 2 tile blocks of the 4-wave kernel) and the
+//                     partial stores, WHILE the chain waves are already in the next backward layer; their stores drain while they
+//                     wait for the next operands.
+// One exchange area (no room for two beside the 80 KB image), so per layer: chain writes -> barrier -> dW reads || chain computes the
+// next delta -> barrier -> chain writes ...  Same barrier count per pass as before (8), same arithmetic, same partial layout, same
+// results bit for bit (tests/test_gpu_ppo_kernel.py compares the two kernels); 512 threads, 256 VGPRs per wave.  In a later pass of
+// a large minibatch the chain waves' gather flies while the dW waves finish the previous pass.
+template <int L>
+__global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, float* __restrict__ partial, int num_params) {
+    using D = PpoDims<L>;
+    using P = PolicyDims<L>;
+    constexpr int KS1 = P::kSteps1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8* W = reinterpret_cast<half8*>(smem);
+    half8* E = W + D::kImage;
+    const unsigned lds_base = (unsigned)(size_t)smem;
+    const int net = blockIdx.y;
+    const int stop_flag = *a.stop;
+    PPO_TICK(a, 0);
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = wave8 >> 2;          // 0: chain wave, 1: dW wave (wave-uniform: every branch on it is whole-wave)
+    const int wave = wave8 & 3;           // chain: the wave's 32-sample tile; dW: its 2 x 2 block of weight tiles
+    const int et = wave & 1;
+    const int O = net == 0 ? 4 : 1;
+    const NetOff o = net_off(L, O);
+    float* gn = partial + (size_t)blockIdx.x * num_params + (net == 0 ? 0 : net_off(L, 4).total);
+    const float scale = 1.0f / (float)a.B;
+    const int pairs = (a.G + 1) / 2;   // passes of 2 sample groups = 128 samples
+    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int kImgLoads = (D::kImage + 255) / 256;   // 16-byte loads per dW-wave thread (the four dW waves = 256 threads)
+    // The pass loop is written out per role (loop unswitching by hand): inside ONE loop the dW waves' persistent accumulators would be
+    // live through the chain waves' branch as well (the compiler does not know that a wave never changes its role) and spill.
+    if (role == 0) {
+    for (int pair = blockIdx.x, pass = 0; pair < pairs; pair += gridDim.x, ++pass) {
+        // Everything derived from the lane index is formed INSIDE the pass loop, behind an opaque copy: as loop invariants the image
+        // addresses, identity operands and lane constants were hoisted in front of the loop and kept alive through the whole kernel
+        // (89 spilled registers and a scratch segment, i.e. the runtime's scratch set-up on every launch).
+        int lane = (int)(threadIdx.x & 63), tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(lane), "+v"(tid));
+        const int c = lane & 31, h = lane >> 5;
+        const unsigned ex_lane0 = lds_base + 16u * (unsigned)D::kImage + ex_lane_const(lane, 0);   // exchange area + lane
+        const unsigned ex_lane1 = lds_base + 16u * (unsigned)D::kImage + ex_lane_const(lane, 1);   // constants (two reads)
+        float* stash = reinterpret_cast<float*>(E + kExHalf8) + wave * 32 + c;
+            // =========================================== chain waves ===========================================================
+            const int g = 2 * pair + (wave >> 1);
+            const bool live = g < a.G;   // whole wave; a wave without samples runs on row 0 with zero deltas (it shares the barriers)
+            const int b = a.idx[(live ? g : a.G - 1) * 64 + 32 * et + c];
+            float xin[KS1][8];
+            {
+                const float* row = a.obs + (size_t)b * L;
+#pragma unroll
+                for (int s = 0; s < KS1; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 16 * s + 8 * h + j;
+                        xin[s][j] = row[k < L ? k : L - 1];
+                    }
+            }
+            const float4 act_v = net == 0 ? reinterpret_cast<const float4*>(a.act)[b] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float old_logp_in = a.old_logp[b], adv_in = a.adv[b], ret_in = a.ret[b];
+            const double acc_s1 = a.acc[0], acc_s2 = a.acc[1];
+            float log_std_v[4];
+            {
+                const float* log_std = a.theta + net_off(L, 4).total + net_off(L, 1).total;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) log_std_v[k] = log_std[k];
+            }
+            __syncthreads();   // [S0] image staged by the dW waves (first pass) / they have finished with the exchange area
+            if (stop_flag) return;   // uniform over the grid
+            PPO_TICK(a, 1);
+            if (h == 0) {
+                stash[0 * kStashRows] = act_v.x;
+                stash[1 * kStashRows] = act_v.y;
+                stash[2 * kStashRows] = act_v.z;
+                stash[3 * kStashRows] = act_v.w;
+                stash[4 * kStashRows] = old_logp_in;
+                stash[5 * kStashRows] = adv_in;
+                stash[6 * kStashRows] = ret_in;
+            }
+            half8 in[KS1];
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * s + 8 * h + j;
+                    v[j] = k < L ? xin[s][j] : (k == L ? 1.0f : 0.0f);
+                }
+                in[s] = sat_pack(v);
+            }
+            const bool valid = h == 0 && live;
+            // ---- forward: the activations stay in registers until they have been published for their layer's weight gradient
+            uint32_t m1[2], m2[2], m3[2];
+            half8 h1[8], h2[8], h3[8];
+            mlp_layer<KS1, false, true>(W, lane, in, h1, m1);
+            PPO_TICK(a, 2);
+            mlp_layer<8, false, true>(W + P::kOff2, lane, h1, h2, m2);
+            PPO_TICK(a, 3);
+            mlp_layer<8, false, true>(W + P::kOff3, lane, h2, h3, m3);
+            PPO_TICK(a, 4);
+            half8 w4[8], w4t[4];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) w4[s] = W[P::kOff4 + s * 64 + (lane ^ ((h | ((s & 1) << 1)) << 2))];
+            {
+                const unsigned a40 = lds_base + tr_lane_out(lane, 0, true) + 16u * (unsigned)P::kOff4;
+                const unsigned a41 = lds_base + tr_lane_out(lane, 1, true) + 16u * (unsigned)P::kOff4;
+                w4t[0] = lds_tr_pair2<16 * 128 * 0>(a40, a41);
+                w4t[1] = lds_tr_pair2<16 * 128 * 1>(a40, a41);
+                w4t[2] = lds_tr_pair2<16 * 128 * 2>(a40, a41);
+                w4t[3] = lds_tr_pair2<16 * 128 * 3>(a40, a41);
+            }
+            float out4[4];
+            {
+                f32x16p acc = zero;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4[s], h3[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out4[r] = acc[r];
+            }
+            // ---- per-sample loss gradients (x B; the 1/B of the batch means is applied when the tiles are stored)
+            float wsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            const float* st_ = stash;
+            float dout[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (net == 0) {
+                const float act[4] = {st_[0 * kStashRows], st_[1 * kStashRows], st_[2 * kStashRows], st_[3 * kStashRows]};
+                const float old_logp_v = st_[4 * kStashRows], adv_v = st_[5 * kStashRows];
+                float z[4], inv_std[4], logp = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float ls = log_std_v[k];
+                    inv_std[k] = __expf(-ls);
+                    z[k] = (act[k] - out4[k]) * inv_std[k];
+                    logp += -0.5f * z[k] * z[k] - ls - 0.9189385332046727f;
+                }
+                const float log_ratio = valid ? logp - old_logp_v : 0.0f;
+                const float ratio = __expf(log_ratio);
+                const double amean = acc_s1 / a.B;
+                const double avar = fmax((acc_s2 - a.B * amean * amean) / (a.B > 1 ? a.B - 1 : 1), 0.0);
+                const float A = valid ? (adv_v - (float)amean) * (float)(1.0 / (sqrt(avar) + 1e-8)) : 0.0f;
+                const bool flows = A >= 0.0f ? (ratio <= 1.0f + a.clip) : (ratio >= 1.0f - a.clip);
+                const float gl = (flows && valid) ? -A * ratio : 0.0f;
+                float dls[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    dout[k] = gl * z[k] * inv_std[k];
+                    dls[k] = gl * (z[k] * z[k] - 1.0f);
+                }
+                const float clipped_ratio = fminf(fmaxf(ratio, 1.0f - a.clip), 1.0f + a.clip);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wsum[k] = wave_sum(dls[k]) * scale;
+                wsum[4] = wave_sum(valid ? -fminf(A * ratio, A * clipped_ratio) : 0.0f);
+                wsum[5] = wave_sum(valid ? (ratio - 1.0f) - log_ratio : 0.0f);
+                wsum[6] = wave_sum(valid && fabsf(ratio - 1.0f) > a.clip ? 1.0f : 0.0f);
+            } else {
+                const float err = valid ? out4[0] - st_[6 * kStashRows] : 0.0f;
+                dout[0] = a.vf_coef * 2.0f * err;
+                wsum[4] = wave_sum(err * err);
+            }
+            if (live && lane == 0) {
+                float4* wo = reinterpret_cast<float4*>(a.wave_out + (((size_t)net * a.G + g) * 2 + et) * 8);
+                wo[0] = make_float4(wsum[0], wsum[1], wsum[2], wsum[3]);
+                wo[1] = make_float4(wsum[4], wsum[5], wsum[6], wsum[7]);
+            }
+            PPO_TICK(a, 5);
+            // ---- layer 4 operands: d4 (k-slot (h, j) = output unit 8 h + j) transposed by the identity MFMA, h3 as natural packs
+            half8 d4;
+            {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (j < 4 && valid) ? dout[j < 4 ? j : 0] : 0.0f;
+                d4 = sat_pack(v);
+                half8 id;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) id[j] = (8 * h + j == c) ? (_Float16)1.0f : (_Float16)0.0f;
+                const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(d4, id, zero, 0, 0, 0);
+                E[(0 * 8 + 2 * wave) * 64 + lane] = plain_pack(acc, 0);
+                E[(0 * 8 + 2 * wave + 1) * 64 + lane] = plain_pack(acc, 1);
+            }
+            packs_to_lds(h3, E + 4 * 8 * 64, wave, lane);
+            __syncthreads();   // [S1] layer-4 operands published
+            PPO_TICK(a, 6);
+            // d3 = (W4^T d4) * relu'(z3) -- registers and the image only, while the dW waves form dW4
+            half8 dA[8], dB[8];
+            lds_tr_wait<0>(w4t[0], w4t[1]);
+            lds_tr_wait<0>(w4t[2], w4t[3]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4t[t], d4, zero, 0, 0, 0);
+                dA[2 * t] = mask_pack(acc, m3[t >> 1], t, 0);
+                dA[2 * t + 1] = mask_pack(acc, m3[t >> 1], t, 1);
+            }
+            PPO_TICK(a, 7);
+            __syncthreads();   // [S2] the dW waves are done reading the layer-4 operands
+            packs_to_lds(dA, E, wave, lane);
+            packs_to_lds(h2, E + 4 * 8 * 64, wave, lane);
+            __syncthreads();   // [S3] layer-3 operands published
+            PPO_TICK(a, 8);
+            mlp_layer_bwd<P::kOff3>(lds_base + tr_lane_hidden(lane, 0, true), lds_base + tr_lane_hidden(lane, 1, true), dA, dB, m2);   // d2
+            PPO_TICK(a, 9);
+            __syncthreads();   // [S4]
+            packs_to_lds(dB, E, wave, lane);
+            packs_to_lds(h1, E + 4 * 8 * 64, wave, lane);
+            __syncthreads();   // [S5] layer-2 operands published
+            PPO_TICK(a, 10);
+            mlp_layer_bwd<P::kOff2>(lds_base + tr_lane_hidden(lane, 0, true), lds_base + tr_lane_hidden(lane, 1, true), dB, dA, m1);   // d1
+            PPO_TICK(a, 11);
+            __syncthreads();   // [S6]
+            // ---- layer 1 operands: d1 as natural packs, x0 transposed by the identity MFMA (column unit = input index)
+            packs_to_lds(dA, E, wave, lane);
+#pragma unroll
+            for (int ut = 0; ut < D::kIT; ++ut) {
+                f32x16p acc = zero;
+#pragma unroll
+                for (int s = 0; s < KS1; ++s) {
+                    half8 id;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) id[j] = (16 * s + 8 * h + j == 32 * ut + c) ? (_Float16)1.0f : (_Float16)0.0f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(in[s], id, acc, 0, 0, 0);
+                }
+                E[((4 + ut) * 8 + 2 * wave) * 64 + lane] = plain_pack(acc, 0);
+                E[((4 + ut) * 8 + 2 * wave + 1) * 64 + lane] = plain_pack(acc, 1);
+            }
+            __syncthreads();   // [S7] layer-1 operands published
+            PPO_TICK(a, 12);
+            // (a later pass: this wave's next gather is issued while the dW waves finish; [S0] keeps the exchange area and the stash)
+        }
+    } else {
+        // The operand image (80 KB) is staged by THESE four waves -- they have nothing else to do until the first operands are
+        // published and nothing else live in their registers -- while the chain waves' gather is in flight: ONE burst of
+        // kImgLoads x 16 bytes per thread (two half-bursts were two exposed round trips: the chain waited 19 k cycles at [S0]).
+        // Every workgroup walks the image in a different rotation: all workgroups of a network read the SAME 80 KB, and in the
+        // same order they would all be queueing on one L2 channel at a time.
+    {
+            const f32x4p* src = reinterpret_cast<const f32x4p*>(a.images + (size_t)net * D::kImage);
+            f32x4p* dst = reinterpret_cast<f32x4p*>(W);
+            const int t256 = (int)(threadIdx.x & 255);
+            const int rot = (int)(blockIdx.x % kImgLoads);
+            f32x4p img[kImgLoads];
+#pragma unroll
+            for (int q = 0; q < kImgLoads; ++q) {
+                const int i = ((q + rot) % kImgLoads) * 256 + t256;
+                img[q] = src[i < D::kImage ? i : 0];
+            }
+#pragma unroll
+            for (int q = 0; q < kImgLoads; ++q) {
+                const int i = ((q + rot) % kImgLoads) * 256 + t256;
+                if (i < D::kImage) dst[i ^ (((i >> 5) & 3) << 2)] = img[q];   // chunk swizzle: conflict-free transposed reads
+            }
+        }
+        // weight-gradient accumulators, live across the passes (initialised AFTER the staging burst: its 80 registers are free again)
+        f32x16p dw4 = zero, dw3[2][2] = {{zero, zero}, {zero, zero}}, dw2[2][2] = {{zero, zero}, {zero, zero}}, dw1[2][2] = {{zero, zero}, {zero, zero}};
+    for (int pair = blockIdx.x, pass = 0; pair < pairs; pair += gridDim.x, ++pass) {
+        // Everything derived from the lane index is formed INSIDE the pass loop, behind an opaque copy: as loop invariants the image
+        // addresses, identity operands and lane constants were hoisted in front of the loop and kept alive through the whole kernel
+        // (89 spilled registers and a scratch segment, i.e. the runtime's scratch set-up on every launch).
+        int lane = (int)(threadIdx.x & 63), tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(lane), "+v"(tid));
+        const int c = lane & 31, h = lane >> 5;
+        const unsigned ex_lane0 = lds_base + 16u * (unsigned)D::kImage + ex_lane_const(lane, 0);   // exchange area + lane
+        const unsigned ex_lane1 = lds_base + 16u * (unsigned)D::kImage + ex_lane_const(lane, 1);   // constants (two reads)
+        float* stash = reinterpret_cast<float*>(E + kExHalf8) + wave * 32 + c;
+            // ============================================= dW waves ============================================================
+            __syncthreads();   // [S0]
+            if (stop_flag) return;
+            // The weight-gradient accumulators of ALL four layers live in this wave's registers across the passes of a large
+            // minibatch (16 + 64 + 64 + 16 kIT VGPRs): a later pass accumulates on the matrix core instead of reading its partial
+            // back and adding (round 2: a read-modify-write of 126 KB per workgroup and pass), and the partial leaves ONCE.  In the
+            // last pass every layer is stored one stage late, behind the MFMAs of the next layer: the 64 stores per lane of a hidden
+            // layer queue behind the fabric's write bandwidth (all 256 workgroups burst together: ~9 k cycles per layer, measured),
+            // and a wave stuck in store issue must not be the one the chain waves wait for at the next barrier.
+            const bool last = pair + (int)gridDim.x >= pairs;
+            const int to0 = 2 * (wave >> 1), ti0 = 2 * (wave & 1);
+            __syncthreads();   // [S1]
+            PPO_TICK(a, 6);
+            dw_tile_old_tr_half<0>(E, ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, lane, dw4);   // tile (0, wave)
+            dw_tile_old_tr_half<4>(E, ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, lane, dw4);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();   // [S2] operands consumed (the MFMAs have them in registers): the chain may overwrite them
+            PPO_TICK(a, 7);
+            __syncthreads();   // [S3]
+            PPO_TICK(a, 8);
+            dw_block_tr(ex_lane0 + 2048u * (unsigned)to0, ex_lane1 + 2048u * (unsigned)to0, ex_lane0 + 2048u * (unsigned)ti0, ex_lane1 + 2048u * (unsigned)ti0, dw3);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();   // [S4]
+            if (last) store_dw_tile<kH>(dw4, gn + o.w4, gn + o.b4, O, 0, wave, lane, scale, false);   // 1 tile: cheap
+            PPO_TICK(a, 9);
+            __syncthreads();   // [S5]
+            PPO_TICK(a, 10);
+            dw_block_tr(ex_lane0 + 2048u * (unsigned)to0, ex_lane1 + 2048u * (unsigned)to0, ex_lane0 + 2048u * (unsigned)ti0, ex_lane1 + 2048u * (unsigned)ti0, dw2);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();   // [S6]
+            PPO_TICK(a, 11);
+            __syncthreads();   // [S7] (arrive BEFORE the layer-3 stores: the chain waves are released to their next gather at once)
+            PPO_TICK(a, 12);
+            dw_tiles_tr_old_half<D::kIT, 0>(ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw1);   // tiles (wave, 0..kIT-1)
+            dw_tiles_tr_old_half<D::kIT, 4>(ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (last) {
+#pragma unroll
+                for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                    for (int bi = 0; bi < 2; ++bi) store_dw_tile<kH>(dw3[bt][bi], gn + o.w3, gn + o.b3, kH, to0 + bt, ti0 + bi, lane, scale, false);
+#pragma unroll
+                for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                    for (int bi = 0; bi < 2; ++bi) store_dw_tile<kH>(dw2[bt][bi], gn + o.w2, gn + o.b2, kH, to0 + bt, ti0 + bi, lane, scale, false);
+#pragma unroll
+                for (int bi = 0; bi < D::kIT; ++bi) store_dw_tile<L>(dw1[0][bi], gn + o.w1, gn + o.b1, kH, wave, bi, lane, scale, false);
+            }
+            PPO_TICK(a, 13);
+            // ([S0] of the next pass separates these reads from the chain waves' next writes)
+        }
     }
 }
 
@@ -1557,6 +1884,7 @@ struct qr_ppo {
     int image_half8 = 0, slots = 0, max_chunks = 32;  // chunks = split of the minibatch's sample groups in phase B
     static constexpr int kFusedChunks = 128;          // workgroups (= partials) per network of the fused gradient kernel
     bool fused = true;                                // QR_PPO_SPLIT=1: the two-kernel form (phase A + phase B through scratch)
+    bool grad4 = false;                               // QR_PPO_GRAD4=1: fused gradient kernel in its 4-wave form (round 2)
     qr::half8* d_images = nullptr;
     qr::half8* d_tbuf = nullptr;
     float* d_partial = nullptr;  // [max_chunks][num_params] phase-B outputs
@@ -1627,11 +1955,16 @@ struct PpoOps {
         if (int rc = adv_stats(p, b, st)) return rc;
         if (p->fused) {   // one kernel: forward, backward and the weight gradients of 128 samples per workgroup and pass
             const size_t lds_f = ((size_t)D::kImage + qr::kExHalf8) * 16 + 7 * qr::kStashRows * sizeof(float);
-            static unsigned long long configured_f = 0;   // per device ordinal
-            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad_kernel<L>), lds_f, configured_f));
+            static unsigned long long configured_f = 0, configured_f4 = 0;   // per device ordinal
             const int pairs = (b.G + 1) / 2;
             const int wgs = pairs < qr_ppo::kFusedChunks ? pairs : qr_ppo::kFusedChunks;
-            hipLaunchKernelGGL((qr::ppo_grad_kernel<L>), dim3(wgs, 2), dim3(256), lds_f, st, b, p->d_partial, p->num_params);
+            if (p->grad4) {   // QR_PPO_GRAD4=1: the 4-wave form (one dependent chain per wave), kept for comparison
+                PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad4_kernel<L>), lds_f, configured_f4));
+                hipLaunchKernelGGL((qr::ppo_grad4_kernel<L>), dim3(wgs, 2), dim3(256), lds_f, st, b, p->d_partial, p->num_params);
+            } else {
+                PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad_kernel<L>), lds_f, configured_f));
+                hipLaunchKernelGGL((qr::ppo_grad_kernel<L>), dim3(wgs, 2), dim3(512), lds_f, st, b, p->d_partial, p->num_params);
+            }
             PPO_HIP(hipGetLastError());
             *chunks_out = wgs;
             return QR_OK;
@@ -1737,6 +2070,8 @@ int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo
     {
         const char* split = getenv("QR_PPO_SPLIT");
         p->fused = !(split && split[0] == '1');
+        const char* g4 = getenv("QR_PPO_GRAD4");
+        p->grad4 = g4 && g4[0] == '1';
     }
     PPO_HIP(hipSetDevice(device));
     const size_t tbytes = (size_t)2 * p->slots * (max_minibatch / 64) * 256 * 16;

@@ -368,6 +368,37 @@ def test_fused_gradient_kernel_equals_split_form(L, B, monkeypatch):
     up_fused.close(); up_split.close()
 
 
+@pytest.mark.parametrize("L,B", [(17, 1024), (24, 16384), (13, 192), (36, 1024), (36, 40000 // 64 * 64), (17, 65536), (24, 16384 + 128)])
+def test_role_split_gradient_kernel_vs_four_wave_and_split_forms(L, B, monkeypatch):
+    """Round 3: the gradient kernel runs its workgroup as four chain waves (gather, forward, loss, backward) + four dW waves
+    (weight gradients on accumulators that stay in registers across the passes of a large minibatch; partial stores once, at the
+    end).  Against the round-2 kernels on the same rows: the two-kernel split form (QR_PPO_SPLIT=1) and the 4-wave fused form
+    (QR_PPO_GRAD4=1) -- same sums in different orders, so agreement to f32 summation noise, single- and multi-pass, and identical
+    minibatch statistics (the forward / loss arithmetic is the same code)."""
+    from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
+
+    pol, ref, up8, obs, act, old_lp, adv, ret = _setup(L, rows=max(B, 4096) * 2, seed=7, max_minibatch=B)
+    monkeypatch.setenv("QR_PPO_GRAD4", "1")
+    up4 = MfmaPpoUpdater(pol, L, obs.device, max_minibatch=B)
+    monkeypatch.delenv("QR_PPO_GRAD4")
+    monkeypatch.setenv("QR_PPO_SPLIT", "1")
+    ups = MfmaPpoUpdater(pol, L, obs.device, max_minibatch=B)
+    monkeypatch.delenv("QR_PPO_SPLIT")
+    idx = torch.randperm(obs.shape[0], device=obs.device)[:B].to(torch.int32)
+    G = lambda u: u.grad(obs, act, old_lp, adv, ret, idx, clip=0.2, vf_coef=0.5, ent_coef=0.01, stats=True).clone()   # noqa: E731
+    g8, g8b, g4, gs = G(up8), G(up8), G(up4), G(ups)
+    torch.cuda.synchronize()
+    n = g8.numel() - 4
+    assert torch.isfinite(g8).all() and float(g8[:n].abs().max()) > 0
+    assert torch.equal(g8, g8b)                                       # deterministic (no atomics)
+    scale = float(gs[:n].abs().max())
+    assert float((g8[:n] - gs[:n]).abs().max()) <= 4e-6 * scale + 1e-7, (float((g8[:n] - gs[:n]).abs().max()), scale)
+    assert float((g8[:n] - g4[:n]).abs().max()) <= 4e-6 * scale + 1e-7
+    assert torch.allclose(g8[n:], gs[n:], rtol=1e-5, atol=1e-6) and torch.allclose(g8[n:], g4[n:], rtol=1e-5, atol=1e-6)
+    for u in (up8, up4, ups):
+        u.close()
+
+
 def test_fused_gradient_is_deterministic_and_stateless_across_minibatch_sizes():
     """No atomics anywhere in the update: the same minibatch gives the same bits twice; and a call does not see leftovers of an
     earlier, larger call in the partial / per-wave buffers (fewer workgroups write fewer partial rows than the previous launch)."""

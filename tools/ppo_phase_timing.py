@@ -6,12 +6,13 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from optimal_quad_control_rl_amd import build as B
-dbg = os.path.join(ROOT, "optimal_quad_control_rl_amd", "_dbg", "libquadrace_dbg.so")   # travels with the snapshot (git-ignored)
+nodrain = os.environ.get("QR_TICK_NODRAIN") == "1"
+dbg = os.path.join(ROOT, "optimal_quad_control_rl_amd", "_dbg", "libquadrace_dbg%s.so" % ("_nodrain" if nodrain else ""))   # travels with the snapshot (git-ignored)
 os.makedirs(os.path.dirname(dbg), exist_ok=True)
 srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES]
 if "--build-only" in sys.argv or not os.path.exists(dbg) or os.path.getmtime(dbg) < max(os.path.getmtime(f) for f in srcs):
     flags = [f for f in B.FLAGS if f not in ("-mllvm", "-amdgpu-mfma-vgpr-form")]
-    subprocess.check_call([B._hipcc(), *flags, "-DQR_PHASE_TIMING", "-o", dbg] + srcs)
+    subprocess.check_call([B._hipcc(), *flags, "-DQR_PHASE_TIMING", *(["-DQR_PHASE_TIMING_NODRAIN"] if nodrain else []), "-o", dbg] + srcs)
 if "--build-only" in sys.argv:
     sys.exit(0)
 B.LIB = dbg
@@ -27,7 +28,8 @@ pol = ActorCritic(L_, 4).to(dev)
 up = MfmaPpoUpdater(pol, L_, dev, Bn)
 lib = _lib.load()
 lib.qr_ppo_debug_set_ticks.argtypes = [C.c_void_p, C.c_void_p]
-waves = 2 * (Bn // 64) * 2    # two nets x groups x two 32-sample tiles (one wave each)
+grad4 = os.environ.get("QR_PPO_GRAD4") == "1" or os.environ.get("QR_PPO_SPLIT") == "1"
+waves = 2 * (Bn // 64) * 2 * (1 if grad4 else 2)    # two nets x groups x two 32-sample tiles (one chain wave each) [+ as many dW waves]
 ticks = torch.zeros((waves, 16), dtype=torch.int64, device=dev)
 for k in range(5):
     up.minibatch(obs, act, old_lp, adv, ret, perm[k * Bn:(k + 1) * Bn], 3e-4)
@@ -44,6 +46,24 @@ if split:
              "h2^T store", "fwd layer 3", "h3^T store", "output layer + loss gradient", "d4, d4^T store, d3", "d3^T store", "d2", "d2^T store",
              "d1", "d1^T store"]
     print("phase A of one wave (one 32-sample tile through forward, loss and backward; QR_PPO_SPLIT=1):")
+elif not grad4:
+    t8 = t.reshape(t.shape[0], -1, 8, 16)           # [rep][workgroup][wave][slot]
+    ch, dw = t8[:, :, :4, :], t8[:, :, 4:, :]
+    cn = ["entry", "gather issue, barrier S0 (image staged by the dW waves)", "fwd layer 1", "fwd layer 2", "fwd layer 3",
+          "output layer + loss gradient", "d4^T, h3 -> LDS, barrier S1", "d3", "barrier S2, d3, h2 -> LDS, barrier S3",
+          "d2 (transposed reads)", "barrier S4, d2, h1 -> LDS, barrier S5", "d1 (transposed reads)", "barrier S6, d1, x0^T -> LDS, barrier S7"]
+    print("role-split gradient kernel, CHAIN wave (one 32-sample tile; queues drained at every stamp):")
+    for s_ in range(1, 13):
+        print(f"  {s_:2d} {cn[s_]:62s} {np.median(ch[..., s_] - ch[..., s_ - 1]):8.0f} cycles")
+    print(f"  chain total {np.median(ch[..., 12] - ch[..., 0]):8.0f} cycles")
+    dn = {7: "dW4 (reads + MFMA) + barrier S2 + stores", 8: "wait S3", 9: "dW3 + barrier S4 + stores", 10: "wait S5",
+          11: "dW2 + barrier S6 + stores", 12: "wait S7", 13: "dW1 + stores"}
+    print("dW wave (slot 6 = released by S1):")
+    print(f"     {'image staging + idle until S1':62s} {np.median(dw[..., 6] - dw[..., 0]):8.0f} cycles")
+    for s_ in range(7, 14):
+        print(f"  {s_:2d} {dn[s_]:62s} {np.median(dw[..., s_] - dw[..., s_ - 1]):8.0f} cycles")
+    print(f"  workgroup: first entry -> last dW exit {np.median(dw[..., 13].max(-1) - t8[..., 0].min(-1)):8.0f} cycles")
+    sys.exit(0)
 else:
     names = ["entry", "gather issue, image -> LDS, barrier", "fwd layer 1", "fwd layer 2", "fwd layer 3", "output layer + loss gradient",
              "d4^T, h3^T -> LDS, barrier", "dW4 + stores, d3", "barrier, d3^T, h2^T -> LDS, barrier", "dW3 (2 x 2 tiles) + stores", "d2 (transposed reads)",
