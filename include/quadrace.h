@@ -222,7 +222,10 @@ int qr_ppo_pack(qr_ppo* ppo, const float* theta_dev, void* stream);
 int qr_ppo_grad(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const float* act_dev,
                 const float* old_logp_dev, const float* adv_dev, const float* ret_dev, const int32_t* idx_dev, int32_t B,
                 float clip, float vf_coef, float ent_coef, float* grad_out_dev, float* stats_dev, void* stream);
-/* one complete minibatch update of theta (and the Adam moments); adam_step = 1, 2, ... counts updates.  Two launches:
+/* one complete minibatch update of theta (and the Adam moments).  adam_step = 1, 2, ...: the caller counts the updates; adam_step = 0:
+ * the library's device-resident count of optimiser steps REALLY taken is used and advanced (launches turned into no-ops by the
+ * early stop or a non-finite gradient norm do not count, like torch.optim.Adam under SB3) -- see qr_ppo_adam_step.  lr >= 0.
+ * Two launches:
  * ONE gradient kernel (forward, loss, backward and the weight gradients of 128 samples per workgroup and pass; per-workgroup
  * f32 partials) and ONE kernel that reduces the partials, takes the global norm across a grid-wide barrier, clips, applies
  * Adam and re-packs the f16 operand images.  (Environment QR_PPO_SPLIT=1 at qr_ppo_create: the earlier three-launch form,
@@ -237,6 +240,25 @@ int qr_ppo_minibatch(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* ad
  * (otherwise each minibatch call spends a launch on its own).  Optional. */
 int qr_ppo_epoch_begin(qr_ppo* ppo, const float* adv_dev, const int32_t* idx_dev, int32_t B, int32_t num_minibatches,
                        void* stream);
+/* num_epochs whole epochs: per epoch num_minibatches consecutive qr_ppo_minibatch updates on the rows perm_dev[k B .. (k + 1) B),
+ * preceded by the qr_ppo_epoch_begin statistics launch -- enqueued as ONE replayed hipGraph (dependent nodes of a graph start
+ * sooner after each other than dependent stream launches, and the host issues one launch instead of 2 num_minibatches + 1 per
+ * epoch).  The graph is captured on first use and re-captured when an argument changes.  Uses the device-resident Adam step count
+ * (adam_step = 0 semantics) and hands `lr` to the kernels through device memory, so a learning-rate schedule does not force a
+ * re-capture.  perm_dev [num_minibatches * B] int32:
+ *   device_shuffle == 0: the caller's permutation (num_epochs must be 1; rewrite its CONTENT in place between calls);
+ *   device_shuffle != 0: the buffer is FILLED at the start of every epoch with a fresh pseudo-random permutation of
+ *     [0, num_minibatches * B) -- a keyed 8-round Feistel bijection, cycle-walked, O(1) per element instead of the radix sort behind
+ *     torch.randperm -- keyed by (seed, number of epochs shuffled so far), see qr_ppo_shuffle_state. */
+int qr_ppo_epoch(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* adam_v_dev, const float* obs_dev, const float* act_dev,
+                 const float* old_logp_dev, const float* adv_dev, const float* ret_dev, int32_t* perm_dev, int32_t B,
+                 int32_t num_minibatches, int32_t num_epochs, int32_t device_shuffle, float clip, float vf_coef, float ent_coef,
+                 float max_grad_norm, float lr, float beta1, float beta2, float eps, float* stats_dev, void* stream);
+/* state2[0] = seed of the on-device permutations, state2[1] = epochs shuffled so far; set == 0 reads, set != 0 writes.  Blocks. */
+int qr_ppo_shuffle_state(qr_ppo* ppo, uint64_t* state2, int32_t set, void* stream);
+/* device-resident optimiser step count: set == 0 reads it into *value (for a checkpoint), set != 0 writes *value (after loading
+ * one).  Blocks. */
+int qr_ppo_adam_step(qr_ppo* ppo, int32_t* value, int32_t set, void* stream);
 /* SB3's `target_kl` early stop, decided on the device: before an optimiser step is taken the update kernel compares the
  * minibatch's mean approx-KL with 1.5 * target_kl; if it is larger the step is NOT taken and a sticky stop flag makes every
  * later qr_ppo_minibatch / qr_ppo_apply launch a no-op, until qr_ppo_control(..., clear != 0) (call it at the start of
@@ -260,7 +282,8 @@ int qr_ppo_gae(qr_ppo* ppo, int32_t T, int32_t N, const float* rew_dev, const fl
 /* data-parallel training (one process per GPU): each rank computes qr_ppo_grad on its own rows, the caller averages the
  * [num_params + 4] vector across ranks (a single all-reduce of ~250 KB over RCCL: gradient AND minibatch statistics), then
  * every rank applies the identical update: global-norm clip, Adam, operand re-pack -- and takes the identical target-KL
- * decision, because the KL sum travelled with the gradient.  B = rows per rank of this minibatch.  stats_dev as above. */
+ * decision, because the KL sum travelled with the gradient.  B = rows per rank of this minibatch.  stats_dev as above.
+ * adam_step as in qr_ppo_minibatch (0 = the device-resident count). */
 int qr_ppo_apply(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* adam_v_dev, float* grad_dev, int32_t B,
                  float max_grad_norm, float lr, float beta1, float beta2, float eps, int32_t adam_step, float* stats_dev,
                  void* stream);

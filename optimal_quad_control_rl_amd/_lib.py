@@ -68,6 +68,9 @@ SIGNATURES = {
     "qr_ppo_gae": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float] + [_vp] * 7),
     "qr_ppo_apply": (C.c_int, [_vp] * 5 + [C.c_int32] + [C.c_float] * 5 + [C.c_int32, _vp, _vp]),
     "qr_ppo_epoch_begin": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
+    "qr_ppo_epoch": (C.c_int, [_vp] * 10 + [C.c_int32] * 4 + [C.c_float] * 8 + [_vp, _vp]),
+    "qr_ppo_shuffle_state": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int32, _vp]),
+    "qr_ppo_adam_step": (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32, _vp]),
     "qr_ppo_control": (C.c_int, [_vp, C.c_float, C.c_int32, _vp]),
     "qr_ppo_status": (C.c_int, [_vp, C.POINTER(C.c_int32), _vp]),
     # include/quad3d.h (predecessor environments of "3D quad.ipynb")

@@ -137,9 +137,51 @@ __device__ __forceinline__ void block_sum2_f64(double& a, double& b) {
     }
 }
 
+// ---- epoch permutation on the device: a keyed bijection instead of a sort ---------------------------------------------------------
+// SB3 draws np.random.permutation(rows) per epoch; torch.randperm on the GPU is a radix sort of random keys (0.24 ms for 2 Mi rows:
+// 5 % of an epoch of matrix-core updates).  perm[i] = E_k(i) with E_k an 8-round alternating (unbalanced) Feistel network over
+// ceil(log2 n) bits, cycle-walked into [0, n): every round XORs one half with a keyed hash of the other, so E_k is a bijection for
+// ANY key; the key is (seed, epoch count) -- the count lives on the device (PpoCtrl::shuffle_count, bumped by the statistics kernel
+// that follows in the same graph), so a replayed graph shuffles differently every epoch.  O(1) per element, no scratch, 20 us.
+__device__ __forceinline__ uint32_t shuffle_mix(uint32_t x, uint32_t k) {
+    uint32_t h = x * 0x9E3779B1u + k;
+    h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13; h *= 0xC2B2AE3Du; h ^= h >> 16;
+    return h;
+}
+__global__ void __launch_bounds__(256) ppo_shuffle_kernel(int* __restrict__ perm, unsigned int n, unsigned long long seed,
+                                                          const unsigned long long* __restrict__ count) {
+    const unsigned int i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long c = *count;
+    unsigned int bits = 2;
+    while ((1ull << bits) < n) ++bits;
+    const unsigned int lb = bits >> 1, rb = bits - lb;
+    const unsigned int lmask = (1u << lb) - 1u, rmask = (1u << rb) - 1u;
+    uint32_t key[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {   // round keys: SplitMix64-style finaliser of (seed, epoch count, round)
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (c * 8ull + (unsigned long long)r + 1ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        key[r] = (uint32_t)(z ^ (z >> 31));
+    }
+    unsigned int x = i;
+    do {   // cycle walking: the image of a value < n is revisited until it lands below n again (expected < 2 iterations)
+        unsigned int l = x >> rb, r_ = x & rmask;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            l ^= shuffle_mix(r_, key[r]) & lmask;
+            r_ ^= shuffle_mix(l, key[r + 1]) & rmask;
+        }
+        x = (l << rb) | r_;
+    } while (x >= n);
+    perm[i] = (int)x;
+}
+
 // (same-address f64 atomics serialise at ~15 ns each: one pair per 1024-thread block, not one per wave)
 __global__ void __launch_bounds__(1024) ppo_adv_stats_kernel(const float* __restrict__ adv, const int* __restrict__ idx, int B,
-                                                             double* __restrict__ table) {
+                                                             double* __restrict__ table, unsigned long long* __restrict__ bump) {
+    if (bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1ull;   // the shuffle kernel BEFORE this launch has read it
     const int i = blockIdx.x * 1024 + threadIdx.x;
     const double x = i < B ? (double)adv[idx[(size_t)blockIdx.y * B + i]] : 0.0;
     double s1 = x, s2 = x * x;
@@ -164,6 +206,12 @@ struct PpoCtrl {
     int applied;                  // optimiser steps taken since the last qr_ppo_control
     int skipped_nonfinite;        // updates dropped because the gradient norm was not finite
     int barrier_timeouts;         // must stay 0
+    // Device-resident optimiser state for launches whose arguments must not change between replays of a captured graph
+    // (qr_ppo_epoch) -- and so that the Adam step count advances only when a step was really TAKEN (a launch turned into a no-op by
+    // the early stop or a non-finite norm does not count: torch.optim.Adam / SB3 count real steps).
+    int adam_t;                   // optimiser steps taken over the life of the parameters (bias correction uses adam_t + 1)
+    float lr;                     // learning rate of launches that pass lr < 0 ("read it from the device")
+    unsigned long long shuffle_count;   // epochs shuffled on the device so far (ppo_shuffle_kernel's stream position)
 };
 constexpr unsigned int kGoStop = 0x40000000u, kGoNonFinite = 0x80000000u, kGoGenMask = 0x3FFFFFFFu;
 
@@ -1584,6 +1632,8 @@ struct ApplyArgs {
     float max_norm, lr, beta1, beta2, eps, bc1, bc2_sqrt;
     float kl_limit;           // 1.5 * target_kl * B (threshold on the minibatch's KL SUM); <= 0: no early stop
     int take_step;            // 0: reduce only (qr_ppo_grad)
+    int device_step;          // 1: bias corrections from PpoCtrl::adam_t + 1 (computed here) instead of bc1 / bc2_sqrt
+    int device_lr;            // 1: learning rate = PpoCtrl::lr
 };
 
 // gradient element i and, in the block(s) that own the log_std entries, the per-wave sums of phase A:
@@ -1617,11 +1667,12 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
         }
     }
     float g = 0.0f;
-    constexpr int kMaxChunks = 32;
+    // ALL chunk partials of this element are requested before the first add (up to 128 x 4 bytes per thread in flight: the kernel
+    // has the registers, one wave per SIMD).  Four batches of 32 were four dependent round trips through the fabric for data the
+    // previous kernel had just written (32 MB per minibatch: this read is most of the kernel's time).
+    constexpr int kMaxChunks = 128;
     float gs[kMaxChunks];
     if (i < n - 4) {  // weights and biases: the partials of the gradient kernel (one per workgroup / sample chunk)
-        // the first 32 chunk loads are issued before the first add: one memory round trip instead of four
-        // (the partials were written by the previous kernel, so they come from HBM / the memory-side cache)
 #pragma unroll
         for (int q = 0; q < kMaxChunks; ++q) gs[q] = a.partial[(size_t)(q < a.chunks ? q : 0) * n + i];  // unconditional loads
     }
@@ -1657,6 +1708,8 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
         __syncthreads();
     }
     if (i < n - 4) {
+        // fixed-shape tree over the 128 slots (slots past the chunk count hold zeros): the summation order depends on nothing but
+        // the chunk index -> bitwise reproducible
 #pragma unroll
         for (int q = 0; q < kMaxChunks; ++q) gs[q] = q < a.chunks ? gs[q] : 0.0f;
 #pragma unroll
@@ -1664,17 +1717,6 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
 #pragma unroll
             for (int q = 0; q < w; ++q) gs[q] += gs[q + w];
         g = gs[0];
-        for (int base = kMaxChunks; base < a.chunks; base += kMaxChunks) {   // further batches of 32 (the fused kernel writes up to 128)
-#pragma unroll
-            for (int q = 0; q < kMaxChunks; ++q) gs[q] = a.partial[(size_t)(base + q < a.chunks ? base + q : 0) * n + i];
-#pragma unroll
-            for (int q = 0; q < kMaxChunks; ++q) gs[q] = base + q < a.chunks ? gs[q] : 0.0f;
-#pragma unroll
-            for (int w = kMaxChunks / 2; w >= 1; w >>= 1)
-#pragma unroll
-                for (int q = 0; q < w; ++q) gs[q] += gs[q + w];
-            g += gs[0];
-        }
     } else if (i < n) {  // log_std; entropy = sum(log_std) + const
         g = red[i - (n - 4)] - a.ent_coef;
     }
@@ -1727,6 +1769,8 @@ __global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
     PpoCtrl* c = a.ctrl;
     const int stop_flag = c->stop;       // set by an EARLIER launch: uniform over the grid; tested after the reduction below
     const unsigned int gen = c->gen;
+    const int adam_t = c->adam_t;        // like `gen`: read by everybody before anybody arrives at the barrier, bumped by the master after it
+    const float lr_dev = c->lr;
     const int n = a.n;
     const int i = blockIdx.x * kApplyThreads + threadIdx.x;
     const bool last_block = blockIdx.x == gridDim.x - 1;
@@ -1813,7 +1857,12 @@ __global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
         const float vi = a.beta2 * v_in + (1.0f - a.beta2) * gc * gc;
         a.m[i] = mi;
         a.v[i] = vi;
-        const float th = th_in - (a.lr / a.bc1) * mi / (sqrtf(vi) / a.bc2_sqrt + a.eps);  // torch.optim.Adam
+        // bias corrections: host-computed for a caller-counted step, or from the device's own count of steps really taken (the
+        // same float expressions as adam_constants())
+        const float bc1 = a.device_step ? 1.0f - powf(a.beta1, (float)(adam_t + 1)) : a.bc1;
+        const float bc2_sqrt = a.device_step ? sqrtf(1.0f - powf(a.beta2, (float)(adam_t + 1))) : a.bc2_sqrt;
+        const float lr = a.device_lr ? lr_dev : a.lr;
+        const float th = th_in - (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + a.eps);  // torch.optim.Adam
         a.theta[i] = th;
         // operand images of the next minibatch: this parameter's f16 copies (log_std has none)
         const int n4 = net_off(L, 4).total, n1 = net_off(L, 1).total;
@@ -1824,7 +1873,7 @@ __global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
         if (a.stats)
             for (int k = 0; k < 4; ++k) a.stats[k] += red[4 + k];
         if (stop_now) c->stop = 1;
-        else if (finite) c->applied += 1;
+        else if (finite) { c->applied += 1; c->adam_t = adam_t + 1; }
         else c->skipped_nonfinite += 1;
     }
 }
@@ -1901,6 +1950,20 @@ struct qr_ppo {
     int epoch_B = 0, epoch_count = 0, epoch_cursor = 0;
     float target_kl = 0.0f;        // <= 0: no early stop
     const float* packed_theta = nullptr;   // parameter vector the operand images were last built from (pack / apply)
+    // qr_ppo_epoch: one epoch's launches (advantage statistics + num_minibatches x (gradient, apply)) captured once into a hipGraph
+    // and replayed while the arguments stay the same -- everything that changes between epochs lives in device memory (the
+    // permutation's CONTENT, the Adam step count, the learning rate, the stop flag)
+    struct EpochGraph {
+        hipGraphExec_t exec = nullptr;
+        const void *theta = nullptr, *m = nullptr, *v = nullptr, *obs = nullptr, *act = nullptr, *old_logp = nullptr, *adv = nullptr,
+                   *ret = nullptr, *perm = nullptr, *stats = nullptr;
+        int B = 0, M = 0, E = 0, shuffle = 0;
+        unsigned long long seed = 0;
+        float clip = 0, vf_coef = 0, ent_coef = 0, max_grad_norm = 0, beta1 = 0, beta2 = 0, eps = 0, target_kl = 0;
+    } eg;
+    hipStream_t capture_stream = nullptr;
+    float lr_host = 0.0f;          // source of the asynchronous copy into PpoCtrl::lr (must outlive the call)
+    unsigned long long shuffle_seed = 0;   // key of the on-device epoch permutations (qr_ppo_shuffle_state)
 };
 
 namespace qr {
@@ -1940,31 +2003,39 @@ struct PpoOps {
         p->epoch_idx = nullptr;
         double* slot = p->d_mbstats + 2 * qr_ppo::kMaxEpochMinibatches;
         PPO_HIP(hipMemsetAsync(slot, 0, 2 * sizeof(double), st));
-        hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((b.B + 1023) / 1024, 1), dim3(1024), 0, st, b.adv, b.idx, b.B, slot);
+        hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((b.B + 1023) / 1024, 1), dim3(1024), 0, st, b.adv, b.idx, b.B, slot,
+                           (unsigned long long*)nullptr);
         b.acc = slot;
+        return QR_OK;
+    }
+    static constexpr size_t kLdsSplit = (size_t)D::kImage * 16 + 7 * qr::kStashRows * sizeof(float);   // operand images + per-sample stash
+    static constexpr size_t kLdsFused = ((size_t)D::kImage + qr::kExHalf8) * 16 + 7 * qr::kStashRows * sizeof(float);
+    // dynamic-LDS limits of the gradient kernels on the CURRENT device (idempotent; not a stream operation, so it also runs
+    // before a graph capture instead of inside it)
+    static int configure(qr_ppo* p) {
+        static unsigned long long configured_a = 0, configured_a8 = 0, configured_f = 0, configured_f4 = 0;   // per device ordinal
+        if (!p->fused) {
+            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 256>), kLdsSplit, configured_a));
+            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 512>), kLdsSplit, configured_a8));
+        } else if (p->grad4) {
+            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad4_kernel<L>), kLdsFused, configured_f4));
+        } else {
+            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad_kernel<L>), kLdsFused, configured_f));
+        }
         return QR_OK;
     }
     // phase A + phase B: per-sample-chunk partial gradients in d_partial, per-wave sums in d_wave; returns the chunk count
     static int grad(qr_ppo* p, qr::PpoBatch b, hipStream_t st, int* chunks_out) {
-        const size_t lds = (size_t)D::kImage * 16 + 7 * qr::kStashRows * sizeof(float);  // operand images + per-sample stash
-        static unsigned long long configured_a = 0, configured_a8 = 0;   // per device ordinal
-        if (!p->fused) {
-            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 256>), lds, configured_a));
-            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 512>), lds, configured_a8));
-        }
+        constexpr size_t lds = kLdsSplit, lds_f = kLdsFused;
+        if (int rc = configure(p)) return rc;
         if (int rc = adv_stats(p, b, st)) return rc;
         if (p->fused) {   // one kernel: forward, backward and the weight gradients of 128 samples per workgroup and pass
-            const size_t lds_f = ((size_t)D::kImage + qr::kExHalf8) * 16 + 7 * qr::kStashRows * sizeof(float);
-            static unsigned long long configured_f = 0, configured_f4 = 0;   // per device ordinal
             const int pairs = (b.G + 1) / 2;
             const int wgs = pairs < qr_ppo::kFusedChunks ? pairs : qr_ppo::kFusedChunks;
-            if (p->grad4) {   // QR_PPO_GRAD4=1: the 4-wave form (one dependent chain per wave), kept for comparison
-                PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad4_kernel<L>), lds_f, configured_f4));
+            if (p->grad4)   // QR_PPO_GRAD4=1: the 4-wave form (one dependent chain per wave), kept for comparison
                 hipLaunchKernelGGL((qr::ppo_grad4_kernel<L>), dim3(wgs, 2), dim3(256), lds_f, st, b, p->d_partial, p->num_params);
-            } else {
-                PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad_kernel<L>), lds_f, configured_f));
+            else
                 hipLaunchKernelGGL((qr::ppo_grad_kernel<L>), dim3(wgs, 2), dim3(512), lds_f, st, b, p->d_partial, p->num_params);
-            }
             PPO_HIP(hipGetLastError());
             *chunks_out = wgs;
             return QR_OK;
@@ -2037,10 +2108,15 @@ int fill_batch(qr_ppo* p, qr::PpoBatch& b, const float* theta, const float* obs,
     return QR_OK;
 }
 
+// adam_step >= 1: the caller counts the steps (bias corrections computed here); adam_step == 0: the device's own count of steps
+// really taken (PpoCtrl::adam_t).  lr >= 0: this value; lr < 0: PpoCtrl::lr (set by qr_ppo_epoch / qr_ppo_set_lr).
 void adam_constants(qr::ApplyArgs& a, float max_grad_norm, float lr, float beta1, float beta2, float eps, int adam_step) {
     a.max_norm = max_grad_norm; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-    a.bc1 = 1.0f - powf(beta1, (float)adam_step);
-    a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)adam_step));
+    a.device_step = adam_step == 0;
+    a.device_lr = lr < 0.0f;
+    const int t = adam_step > 0 ? adam_step : 1;
+    a.bc1 = 1.0f - powf(beta1, (float)t);
+    a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)t));
 }
 
 }  // namespace
@@ -2102,6 +2178,8 @@ int qr_ppo_destroy(qr_ppo* p) {
     (void)hipFree(p->d_wave);
     (void)hipFree(p->d_ctrl);
     (void)hipFree(p->d_mbstats);
+    if (p->eg.exec) (void)hipGraphExecDestroy(p->eg.exec);
+    if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     delete p;
     return QR_OK;
 }
@@ -2137,7 +2215,13 @@ int qr_ppo_status(qr_ppo* p, int32_t* out4, void* stream) {
     return QR_OK;
 }
 
+static int epoch_begin_impl(qr_ppo* p, const float* adv_dev, const int32_t* idx_dev, int32_t B, int32_t num_minibatches, void* stream,
+                            unsigned long long* bump);
 int qr_ppo_epoch_begin(qr_ppo* p, const float* adv_dev, const int32_t* idx_dev, int32_t B, int32_t num_minibatches, void* stream) {
+    return epoch_begin_impl(p, adv_dev, idx_dev, B, num_minibatches, stream, nullptr);
+}
+static int epoch_begin_impl(qr_ppo* p, const float* adv_dev, const int32_t* idx_dev, int32_t B, int32_t num_minibatches, void* stream,
+                            unsigned long long* bump) {
     if (!p || !adv_dev || !idx_dev) return ppofail(QR_E_INVALID, "qr_ppo_epoch_begin: null argument");
     if (B < 64 || B % 64 != 0 || B > p->max_B || num_minibatches < 1 || num_minibatches > qr_ppo::kMaxEpochMinibatches)
         return ppofail(QR_E_INVALID, "qr_ppo_epoch_begin: bad minibatch size / count");
@@ -2145,7 +2229,7 @@ int qr_ppo_epoch_begin(qr_ppo* p, const float* adv_dev, const int32_t* idx_dev, 
     hipStream_t st = (hipStream_t)stream;
     PPO_HIP(hipMemsetAsync(p->d_mbstats, 0, (size_t)num_minibatches * 2 * sizeof(double), st));
     hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((B + 1023) / 1024, num_minibatches), dim3(1024), 0, st, adv_dev, idx_dev, B,
-                       p->d_mbstats);
+                       p->d_mbstats, bump);
     PPO_HIP(hipGetLastError());
     p->epoch_idx = idx_dev;
     p->epoch_B = B;
@@ -2191,7 +2275,7 @@ int qr_ppo_minibatch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam
     qr::PpoBatch b;
     if (int rc = fill_batch(p, b, theta_dev, obs_dev, act_dev, old_logp_dev, adv_dev, ret_dev, idx_dev, B, clip, vf_coef, ent_coef, stats_dev))
         return rc;
-    if (!adam_m_dev || !adam_v_dev || adam_step < 1) return ppofail(QR_E_INVALID, "qr_ppo_minibatch: bad Adam state");
+    if (!adam_m_dev || !adam_v_dev || adam_step < 0) return ppofail(QR_E_INVALID, "qr_ppo_minibatch: bad Adam state");
     PPO_HIP(hipSetDevice(p->device));
     p->packed_theta = theta_dev;   // the apply kernel keeps the images in step with this vector
     hipStream_t st = (hipStream_t)stream;
@@ -2217,7 +2301,7 @@ int qr_ppo_minibatch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam
 // including the same target-KL decision, because the KL sum travels with the gradient.
 int qr_ppo_apply(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_dev, float* grad_dev, int32_t B, float max_grad_norm,
                  float lr, float beta1, float beta2, float eps, int32_t adam_step, float* stats_dev, void* stream) {
-    if (!p || !theta_dev || !adam_m_dev || !adam_v_dev || !grad_dev || adam_step < 1 || B < 1)
+    if (!p || !theta_dev || !adam_m_dev || !adam_v_dev || !grad_dev || adam_step < 0 || B < 1)
         return ppofail(QR_E_INVALID, "qr_ppo_apply: bad argument");
     PPO_HIP(hipSetDevice(p->device));
     p->packed_theta = theta_dev;
@@ -2233,6 +2317,115 @@ int qr_ppo_apply(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_d
         adam_constants(a, max_grad_norm, lr, beta1, beta2, eps, adam_step);
         return PpoOps<L>::apply(p, a, st);
     });
+}
+
+// Device-resident optimiser step count (see PpoCtrl::adam_t): read it for a checkpoint, set it when one is loaded.
+int qr_ppo_adam_step(qr_ppo* p, int32_t* value, int32_t set, void* stream) {
+    if (!p || !value) return ppofail(QR_E_INVALID, "qr_ppo_adam_step: null argument");
+    if (set && *value < 0) return ppofail(QR_E_INVALID, "qr_ppo_adam_step: negative step count");
+    PPO_HIP(hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (set) PPO_HIP(hipMemcpyAsync(&p->d_ctrl->adam_t, value, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    else PPO_HIP(hipMemcpyAsync(value, &p->d_ctrl->adam_t, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PPO_HIP(hipStreamSynchronize(st));
+    return QR_OK;
+}
+
+// On-device epoch permutations (qr_ppo_epoch with device_shuffle): state[0] = seed, state[1] = epochs shuffled so far.
+// set == 0 reads both (for a checkpoint), set != 0 writes both.  Blocks.
+int qr_ppo_shuffle_state(qr_ppo* p, uint64_t* state2, int32_t set, void* stream) {
+    if (!p || !state2) return ppofail(QR_E_INVALID, "qr_ppo_shuffle_state: null argument");
+    PPO_HIP(hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (set) {
+        p->shuffle_seed = state2[0];
+        PPO_HIP(hipMemcpyAsync(&p->d_ctrl->shuffle_count, &state2[1], sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    } else {
+        state2[0] = p->shuffle_seed;
+        PPO_HIP(hipMemcpyAsync(&state2[1], &p->d_ctrl->shuffle_count, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    }
+    PPO_HIP(hipStreamSynchronize(st));
+    return QR_OK;
+}
+
+// One whole epoch: the advantage statistics of every minibatch, then num_minibatches x (gradient kernel, apply kernel) on the rows
+// perm[k B .. (k + 1) B), k = 0 .. num_minibatches - 1 -- enqueued as ONE replayed hipGraph.  Dependent kernel nodes of a graph start
+// ~1 us sooner after each other than dependent stream launches (tools/ubench/launch_floor.hip), and there are 2 x 128 of them per
+// epoch at the config-5 shape; the host issues one graph launch instead of 257 kernel launches.  Replays are valid because nothing a
+// node's arguments name changes: the permutation is rewritten IN PLACE by the caller, the Adam step count and the learning rate
+// are read from device memory, the early-stop flag is sticky on the device.  The graph is re-captured when any argument changes.
+int qr_ppo_epoch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_dev, const float* obs_dev, const float* act_dev,
+                 const float* old_logp_dev, const float* adv_dev, const float* ret_dev, int32_t* perm_dev, int32_t B,
+                 int32_t num_minibatches, int32_t num_epochs, int32_t device_shuffle, float clip, float vf_coef, float ent_coef,
+                 float max_grad_norm, float lr, float beta1, float beta2, float eps, float* stats_dev, void* stream) {
+    if (!p || !theta_dev || !adam_m_dev || !adam_v_dev || !obs_dev || !act_dev || !old_logp_dev || !adv_dev || !ret_dev || !perm_dev)
+        return ppofail(QR_E_INVALID, "qr_ppo_epoch: null argument");
+    if (B < 64 || B % 64 != 0 || B > p->max_B || num_minibatches < 1 || num_minibatches > qr_ppo::kMaxEpochMinibatches || lr < 0.0f)
+        return ppofail(QR_E_INVALID, "qr_ppo_epoch: bad minibatch size / count / learning rate");
+    if (num_epochs < 1 || num_epochs > 64 || (num_epochs > 1 && !device_shuffle))
+        return ppofail(QR_E_INVALID, "qr_ppo_epoch: num_epochs > 1 needs device_shuffle (the caller cannot rewrite the permutation in between)");
+    PPO_HIP(hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool caller_captures = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    // the learning rate travels through device memory (it may follow a schedule; the captured nodes read PpoCtrl::lr)
+    p->lr_host = lr;
+    PPO_HIP(hipMemcpyAsync(&p->d_ctrl->lr, &p->lr_host, sizeof(float), hipMemcpyHostToDevice, st));
+    p->packed_theta = theta_dev;
+    // per-device kernel attributes are set outside the capture (not a stream operation)
+    if (int rc = dispatch_L(p->L, [&](auto Lc) { return PpoOps<decltype(Lc)::value>::configure(p); })) return rc;
+    const unsigned int rows = (unsigned int)B * (unsigned int)num_minibatches;
+    auto enqueue = [&](hipStream_t s) -> int {
+        for (int e = 0; e < num_epochs; ++e) {
+            if (device_shuffle) {   // perm = keyed bijection of [0, rows) for (seed, device-resident epoch count)
+                hipLaunchKernelGGL(qr::ppo_shuffle_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, perm_dev, rows, p->shuffle_seed,
+                                   &p->d_ctrl->shuffle_count);
+                PPO_HIP(hipGetLastError());
+            }
+            if (int rc = epoch_begin_impl(p, adv_dev, perm_dev, B, num_minibatches, s, device_shuffle ? &p->d_ctrl->shuffle_count : nullptr))
+                return rc;
+            for (int k = 0; k < num_minibatches; ++k)
+                if (int rc = qr_ppo_minibatch(p, theta_dev, adam_m_dev, adam_v_dev, obs_dev, act_dev, old_logp_dev, adv_dev, ret_dev,
+                                              perm_dev + (size_t)k * B, B, clip, vf_coef, ent_coef, max_grad_norm, -1.0f, beta1, beta2,
+                                              eps, 0, stats_dev, s))
+                    return rc;
+        }
+        return QR_OK;
+    };
+    if (caller_captures) return enqueue(st);   // a graph launch cannot be captured: plain nodes into the caller's graph
+    qr_ppo::EpochGraph& g = p->eg;
+    const bool hit = g.exec && g.theta == theta_dev && g.m == adam_m_dev && g.v == adam_v_dev && g.obs == obs_dev && g.act == act_dev &&
+                     g.old_logp == old_logp_dev && g.adv == adv_dev && g.ret == ret_dev && g.perm == perm_dev && g.stats == stats_dev &&
+                     g.B == B && g.M == num_minibatches && g.E == num_epochs && g.shuffle == device_shuffle && g.seed == p->shuffle_seed &&
+                     g.clip == clip && g.vf_coef == vf_coef && g.ent_coef == ent_coef &&
+                     g.max_grad_norm == max_grad_norm && g.beta1 == beta1 && g.beta2 == beta2 && g.eps == eps && g.target_kl == p->target_kl;
+    if (!hit) {
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+        if (!p->capture_stream) PPO_HIP(hipStreamCreateWithFlags(&p->capture_stream, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        PPO_HIP(hipStreamBeginCapture(p->capture_stream, hipStreamCaptureModeRelaxed));
+        const int rc = enqueue(p->capture_stream);
+        const hipError_t end = hipStreamEndCapture(p->capture_stream, &graph);
+        if (rc != QR_OK || end != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc != QR_OK ? rc : ppofail(QR_E_HIP, std::string("qr_ppo_epoch: graph capture failed: ") + hipGetErrorString(end));
+        }
+        const hipError_t inst = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (inst != hipSuccess) {
+            g.exec = nullptr;
+            return ppofail(QR_E_HIP, std::string("qr_ppo_epoch: hipGraphInstantiate: ") + hipGetErrorString(inst));
+        }
+        g.theta = theta_dev; g.m = adam_m_dev; g.v = adam_v_dev; g.obs = obs_dev; g.act = act_dev; g.old_logp = old_logp_dev;
+        g.adv = adv_dev; g.ret = ret_dev; g.perm = perm_dev; g.stats = stats_dev; g.B = B; g.M = num_minibatches;
+        g.E = num_epochs; g.shuffle = device_shuffle; g.seed = p->shuffle_seed;
+        g.clip = clip; g.vf_coef = vf_coef; g.ent_coef = ent_coef; g.max_grad_norm = max_grad_norm; g.beta1 = beta1; g.beta2 = beta2;
+        g.eps = eps; g.target_kl = p->target_kl;
+    }
+    // the capture consumed the epoch table's host-side cursor; a replay does not run that host code, so leave it disarmed
+    p->epoch_idx = nullptr;
+    PPO_HIP(hipGraphLaunch(g.exec, st));
+    return QR_OK;
 }
 
 // Forward pass of one of the two networks with the operand images of the last pack (0 = policy means, 1 = value in column 0):

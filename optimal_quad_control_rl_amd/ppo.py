@@ -101,7 +101,7 @@ class MfmaPpoUpdater:
         self.m = torch.zeros_like(self.theta)
         self.v = torch.zeros_like(self.theta)
         self.stats = torch.zeros(4, dtype=torch.float32, device=device)
-        self.betas, self.eps, self.step = betas, eps, 0
+        self.betas, self.eps = betas, eps
         off = 0
         params = []
         for net in (policy.pi, policy.vf):
@@ -130,6 +130,19 @@ class MfmaPpoUpdater:
 
     def _p(self, t):
         return self._C.c_void_p(t.data_ptr()) if t is not None else None
+
+    @property
+    def step(self):
+        """Optimiser steps really taken (device-resident count: launches turned into no-ops by the early stop or a non-finite
+        gradient norm do not advance it, like torch.optim.Adam under SB3).  Reading it synchronises."""
+        v = self._C.c_int32(0)
+        self._lib.check(self._L.qr_ppo_adam_step(self._h, self._C.byref(v), 0, self._stream()))
+        return int(v.value)
+
+    @step.setter
+    def step(self, value):
+        v = self._C.c_int32(int(value))
+        self._lib.check(self._L.qr_ppo_adam_step(self._h, self._C.byref(v), 1, self._stream()))
 
     def _stream(self):
         return self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -176,14 +189,14 @@ class MfmaPpoUpdater:
         self._lib.check(self._L.qr_ppo_forward(self._h, int(net), int(obs.shape[0]), self._p(obs), self._p(out), self._stream()))
         return out if net == 0 else out[:, 0]
 
-    def gae(self, rew, done, val, last_val, gamma, lam, ep_state=None, fin=None, term_val=None):
+    def gae(self, rew, done, val, last_val, gamma, lam, ep_state=None, fin=None, term_val=None, out=None):
         """GAE(lambda) over a rollout [T, N] in one kernel -> (advantages, returns); `term_val` [T, N] = V(terminal obs) at
         time-limit truncations (0 elsewhere; SB3's bootstrap); `ep_state` = (ep_ret, ep_len, ep_gates) running per-env episode
         statistics (updated in place), sums over finished episodes accumulate into `fin` [4]."""
         T, N = rew.shape
         for t in (rew, done, val, last_val) + ((term_val,) if term_val is not None else ()):
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
-        adv, ret = torch.empty_like(rew), torch.empty_like(rew)
+        adv, ret = out if out is not None else (torch.empty_like(rew), torch.empty_like(rew))
         er, el, eg = ep_state if ep_state is not None else (None, None, None)
         self._lib.check(self._L.qr_ppo_gae(self._h, T, N, self._p(rew), self._p(done), self._p(val), self._p(last_val),
                                            self._p(term_val), gamma, lam, self._p(adv), self._p(ret), self._p(er), self._p(el),
@@ -212,9 +225,8 @@ class MfmaPpoUpdater:
         Adam step -- the second half of a data-parallel update: `g = up.grad(...); dist.all_reduce(g); g /= world;
         up.apply(g, lr, B)`.  The target-KL decision uses the (averaged) KL sum carried in g."""
         assert grad.is_cuda and grad.dtype == torch.float32 and grad.is_contiguous() and grad.numel() == self.theta.numel() + 4
-        self.step += 1
         self._lib.check(self._L.qr_ppo_apply(self._h, self._p(self.theta), self._p(self.m), self._p(self.v), self._p(grad), int(B),
-                                             max_grad_norm, lr, self.betas[0], self.betas[1], self.eps, self.step,
+                                             max_grad_norm, lr, self.betas[0], self.betas[1], self.eps, 0,   # 0: device step count
                                              self._p(self.stats) if stats else None, self._stream()))
 
     def minibatch(self, obs, act, old_lp, adv, ret, idx, lr, clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5):
@@ -223,11 +235,33 @@ class MfmaPpoUpdater:
             # statistics that ride behind it: every rank then takes the same target-KL decision)
             g = self.grad(obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef, stats=False)
             return self.apply(average_across_ranks(g), lr, int(idx.numel()), max_grad_norm)
-        self.step += 1
         self._lib.check(self._L.qr_ppo_minibatch(self._h, self._p(self.theta), self._p(self.m), self._p(self.v), self._p(obs),
                                                  self._p(act), self._p(old_lp), self._p(adv), self._p(ret), self._p(idx),
                                                  int(idx.numel()), clip, vf_coef, ent_coef, max_grad_norm, lr, self.betas[0],
-                                                 self.betas[1], self.eps, self.step, self._p(self.stats), self._stream()))
+                                                 self.betas[1], self.eps, 0, self._p(self.stats), self._stream()))
+
+    def epoch(self, obs, act, old_lp, adv, ret, perm, B, lr, clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, num_epochs=1,
+              device_shuffle=False):
+        """`num_epochs` whole epochs -- every minibatch perm[k B:(k + 1) B] in order -- as ONE replayed graph launch
+        (qr_ppo_epoch).  `perm` must be the SAME int32 CUDA tensor from call to call: the graph's nodes address it.  Without
+        `device_shuffle` the caller rewrites its content in place with a new permutation per epoch (num_epochs = 1); with it the
+        library fills it with a fresh keyed permutation at the start of every epoch (set_shuffle / shuffle_state)."""
+        self._check(obs, act, old_lp, adv, ret, perm)
+        assert perm.numel() % int(B) == 0
+        self._lib.check(self._L.qr_ppo_epoch(self._h, self._p(self.theta), self._p(self.m), self._p(self.v), self._p(obs), self._p(act),
+                                             self._p(old_lp), self._p(adv), self._p(ret), self._p(perm), int(B), perm.numel() // int(B),
+                                             int(num_epochs), int(bool(device_shuffle)), clip, vf_coef, ent_coef, max_grad_norm,
+                                             float(lr), self.betas[0], self.betas[1], self.eps, self._p(self.stats), self._stream()))
+
+    def shuffle_state(self):
+        """(seed, epochs shuffled so far) of the on-device permutations; synchronises."""
+        st = (self._C.c_uint64 * 2)()
+        self._lib.check(self._L.qr_ppo_shuffle_state(self._h, st, 0, self._stream()))
+        return int(st[0]), int(st[1])
+
+    def set_shuffle(self, seed, count=0):
+        st = (self._C.c_uint64 * 2)(int(seed) & (2 ** 64 - 1), int(count))
+        self._lib.check(self._L.qr_ppo_shuffle_state(self._h, st, 1, self._stream()))
 
 
 class PPO:
@@ -281,6 +315,7 @@ class PPO:
             assert tuple(net_arch) == (120, 120, 120), "the matrix-core update is built for the reference's 3 x 120 networks"
             assert self.batch_size % 64 == 0 and (T * N) % self.batch_size == 0
             self._updater = MfmaPpoUpdater(self.policy, obs_dim, self.dev, self.batch_size)
+            self._updater.set_shuffle(0x5EED0000 + int(seed))   # on-device epoch permutations (single-process native update)
         self.fused_collect = fused_collect
         self.noise_seed = seed
         self._mfma = None
@@ -415,9 +450,11 @@ class PPO:
     def _gae_native(self):
         fin = torch.zeros(4, dtype=torch.float32, device=self.dev)
         pending = getattr(self, "_stats_pending", False)
+        if getattr(self, "_adv_ret", None) is None:   # persistent: the epoch graph's nodes address these buffers
+            self._adv_ret = (torch.empty_like(self.buf_rew), torch.empty_like(self.buf_rew))
         adv, ret = self._updater.gae(self.buf_rew, self.buf_done, self.buf_val, self.last_val, self.gamma, self.lam,
                                      (self.ep_ret, self.ep_len, self.ep_gates) if pending else None, fin if pending else None,
-                                     term_val=self.buf_term_val)
+                                     term_val=self.buf_term_val, out=self._adv_ret)
         if pending:
             self._stats_pending = False
             f = fin.tolist() + [float(self.buf_rew.mean())]
@@ -484,18 +521,32 @@ class PPO:
         # later launch of this train() into a no-op -- no host synchronisation inside the loop, identical on every rank
         up.control(self.target_kl if kl_stop else None, clear=True)
         up.stats.zero_()
-        launched = 0
-        for _ in range(self.n_epochs):
-            perm = torch.randperm(B, device=self.dev, generator=self._gen).to(torch.int32)
-            up.begin_epoch(adv, perm, self.batch_size)
-            for s in range(0, B, self.batch_size):
-                up.minibatch(obs, act, old_lp, adv, ret, perm[s:s + self.batch_size], lr, self.clip, self.vf_coef, self.ent_coef,
-                             self.max_grad_norm)
-                launched += 1
-            # after the stop every further launch is a no-op; one status read per EPOCH (a ~50 us synchronisation) saves
-            # launching them (and, data-parallel, their all-reduces); the flag is identical on every rank
-            if kl_stop and up.status()[0]:
-                break
+        # Single process: an epoch = ONE replayed graph (qr_ppo_epoch: statistics launch + gradient / apply kernels of every
+        # minibatch); the permutation is rewritten in place in a buffer the graph's nodes address.  Data-parallel: the all-reduce
+        # between gradient and apply keeps the launches on the stream.
+        if getattr(self, "_perm_buf", None) is None or self._perm_buf.numel() != B:
+            self._perm_buf = torch.empty(B, dtype=torch.int32, device=self.dev)
+        perm = self._perm_buf
+        if not up.data_parallel():
+            # the permutations are drawn on the device too (a keyed bijection per epoch, no sort); without the early stop ALL
+            # epochs of this train() are one graph launch, with it one launch per epoch and one status read in between
+            hp = (self.batch_size, lr, self.clip, self.vf_coef, self.ent_coef, self.max_grad_norm)
+            if not kl_stop:
+                up.epoch(obs, act, old_lp, adv, ret, perm, *hp, num_epochs=self.n_epochs, device_shuffle=True)
+            else:
+                for _ in range(self.n_epochs):
+                    up.epoch(obs, act, old_lp, adv, ret, perm, *hp, num_epochs=1, device_shuffle=True)
+                    if up.status()[0]:   # after the stop every further launch is a no-op: one ~50 us read per epoch saves them
+                        break
+        else:
+            for _ in range(self.n_epochs):
+                perm.copy_(torch.randperm(B, device=self.dev, generator=self._gen))
+                up.begin_epoch(adv, perm, self.batch_size)
+                for s in range(0, B, self.batch_size):
+                    up.minibatch(obs, act, old_lp, adv, ret, perm[s:s + self.batch_size], lr, self.clip, self.vf_coef, self.ent_coef,
+                                 self.max_grad_norm)
+                if kl_stop and up.status()[0]:   # identical on every rank: the KL sum travels with the all-reduced gradient
+                    break
         stopped, applied, skipped, timeouts = up.status()
         assert timeouts == 0, "grid barrier of the update kernel timed out"
         st = up.stats.tolist()
@@ -548,6 +599,7 @@ class PPO:
         permutations.  With the same env constructor arguments, load_state_dict() continues the run bit for bit."""
         if self._updater is not None:
             opt = dict(kind="mfma_adam", m=self._updater.m.clone(), v=self._updater.v.clone(), step=int(self._updater.step),
+                       shuffle=self._updater.shuffle_state(),
                        betas=tuple(self._updater.betas), eps=float(self._updater.eps), lr=float(self.opt.param_groups[0]["lr"]))
         else:
             opt = dict(kind="torch_adam", state=self.opt.state_dict())
@@ -567,6 +619,8 @@ class PPO:
             self._updater.m.copy_(opt["m"])
             self._updater.v.copy_(opt["v"])
             self._updater.step = int(opt["step"])
+            if "shuffle" in opt:
+                self._updater.set_shuffle(*opt["shuffle"])
             for g in self.opt.param_groups:
                 g["lr"] = float(opt["lr"])
             self._updater.pack()

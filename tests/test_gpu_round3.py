@@ -353,3 +353,88 @@ def test_f16_operand_gradient_vs_f32_autograd_on_real_rollout_rows():
         assert 0.9 < float(got.norm() / ref.norm()) < 1.1
     assert off == g.numel() and math.isfinite(worst)
     env.close()
+
+
+def test_epoch_graph_equals_minibatch_launches_and_counts_real_steps():
+    """qr_ppo_epoch (one replayed hipGraph per epoch) against the same updates as stream launches (qr_ppo_epoch_begin + M x
+    qr_ppo_minibatch): identical parameters and Adam moments bit for bit over two epochs with different permutations (the second
+    epoch REPLAYS the graph captured by the first: the permutation buffer is rewritten in place, the Adam step count and the
+    learning rate live on the device).  And the device-resident step count advances only for steps really taken:
+    with a tiny target_kl the first epoch stops early, and `step` equals `applied`, not the number of launches."""
+    from test_gpu_ppo_kernel import _setup
+    from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
+
+    L, B, M = 24, 4096, 6
+    pol, ref, up_a, obs, act, old_lp, adv, ret = _setup(L, rows=B * M, seed=11, max_minibatch=B)
+    up_b = MfmaPpoUpdater(pol, L, obs.device, max_minibatch=B)
+    up_b.theta.copy_(up_a.theta); up_b.pack()
+    dev = obs.device
+    perm_buf = torch.empty(B * M, dtype=torch.int32, device=dev)
+    for ep, lr in enumerate((3e-4, 1e-4)):
+        perm = torch.randperm(B * M, device=dev, generator=torch.Generator(device=dev).manual_seed(ep)).to(torch.int32)
+        perm_buf.copy_(perm)
+        up_a.control(None, clear=True); up_b.control(None, clear=True)
+        up_a.epoch(obs, act, old_lp, adv, ret, perm_buf, B, lr)
+        up_b.begin_epoch(adv, perm, B)
+        for k in range(M):
+            up_b.minibatch(obs, act, old_lp, adv, ret, perm[k * B:(k + 1) * B], lr)
+        torch.cuda.synchronize()
+        assert torch.equal(up_a.theta, up_b.theta) and torch.equal(up_a.m, up_b.m) and torch.equal(up_a.v, up_b.v), ep
+        assert up_a.status()[1] == M and up_a.step == up_b.step == M * (ep + 1)
+    # SB3's early stop: KL limit far below what one step moves -> the epoch stops after its first step or two
+    before = up_a.step
+    up_a.control(1e-9, clear=True)
+    up_a.epoch(obs, act, old_lp, adv, ret, perm_buf, B, 3e-4)
+    stopped, applied, skipped, timeouts = up_a.status()
+    assert stopped and applied < M and timeouts == 0
+    assert up_a.step == before + applied          # launches that became no-ops did not advance the bias-correction count
+    up_a.step = 1234                              # checkpoint restore path
+    assert up_a.step == 1234
+    up_a.close(); up_b.close()
+
+
+def test_device_shuffle_is_a_fresh_permutation_every_epoch_and_is_checkpointable():
+    """qr_ppo_epoch(device_shuffle): the permutation buffer is filled by a keyed Feistel bijection per epoch.  Every epoch's buffer
+    is a permutation of [0, rows) (also for a row count that is not a power of two: cycle walking), consecutive epochs differ, the
+    sequence is a function of (seed, epoch count) -- restoring the state replays it -- and it looks uniform (position / value
+    correlation and fixed points like a random permutation's).  num_epochs epochs in one graph == the same epochs launched singly."""
+    from test_gpu_ppo_kernel import _setup
+    from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
+
+    for B, M in ((4096, 8), (192, 5)):
+        L = 17
+        pol, ref, up_a, obs, act, old_lp, adv, ret = _setup(L, rows=B * M, seed=3, max_minibatch=B)
+        up_b = MfmaPpoUpdater(pol, L, obs.device, max_minibatch=B)
+        up_b.theta.copy_(up_a.theta); up_b.pack()
+        rows = B * M
+        pa = torch.empty(rows, dtype=torch.int32, device=obs.device)
+        pb = torch.empty(rows, dtype=torch.int32, device=obs.device)
+        up_a.set_shuffle(1234, 0); up_b.set_shuffle(1234, 0)
+        seen = []
+        for ep in range(3):
+            up_a.epoch(obs, act, old_lp, adv, ret, pa, B, 3e-4, device_shuffle=True)
+            torch.cuda.synchronize()
+            q = pa.cpu().long()
+            assert torch.equal(torch.sort(q).values, torch.arange(rows)), (B, M, ep)
+            seen.append(q)
+            assert up_a.shuffle_state() == (1234, ep + 1)
+        assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+        if rows > 10000:
+            pos = torch.arange(rows, dtype=torch.float64)
+            for q in seen:
+                r = torch.corrcoef(torch.stack([pos, q.double()]))[0, 1]
+                assert abs(float(r)) < 0.02 and int((q == torch.arange(rows)).sum()) <= 8
+                # minibatch k draws its rows from the whole buffer, not from a neighbourhood
+                first = q[:B].double()
+                assert abs(float(first.mean()) / rows - 0.5) < 0.02 and float(first.std()) / rows > 0.27
+        # three epochs in ONE graph from the same state: same permutations (last one left in the buffer), same parameters
+        up_b.epoch(obs, act, old_lp, adv, ret, pb, B, 3e-4, num_epochs=3, device_shuffle=True)
+        torch.cuda.synchronize()
+        assert torch.equal(pb.cpu().long(), seen[2]) and up_b.shuffle_state() == (1234, 3)
+        assert torch.equal(up_a.theta, up_b.theta) and torch.equal(up_a.m, up_b.m) and up_a.step == up_b.step == 3 * M
+        # restoring (seed, count) replays the sequence
+        up_a.set_shuffle(1234, 1)
+        up_a.epoch(obs, act, old_lp, adv, ret, pa, B, 3e-4, device_shuffle=True)
+        torch.cuda.synchronize()
+        assert torch.equal(pa.cpu().long(), seen[1])
+        up_a.close(); up_b.close()

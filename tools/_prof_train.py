@@ -1,0 +1,25 @@
+import sys, os, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from optimal_quad_control_rl_amd import Quadcopter3DGates, TRAIN_DISTURBANCE_RANGES, square_track
+from optimal_quad_control_rl_amd.ppo import PPO
+n = 65536
+env = Quadcopter3DGates(n, *square_track(), gates_ahead=1, infos_mode="none", seed=1)
+env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+m = PPO(env, seed=0, gamma=0.999, n_steps=32, n_epochs=10, batch_size=16384, learning_rate=3e-4, target_kl=None, fused_collect=True, native_update=True)
+m.collect(); m.train(); m.collect(); m.train()
+def T(fn, reps=5):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): r = fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
+B = n * 32
+print("collect ms", T(m.collect, 3))
+print("sanitise ms", T(m._sanitise_buffers))
+print("gae ms", T(m._gae_native))
+print("randperm+copy ms", T(lambda: m._perm_buf.copy_(torch.randperm(B, device=m.dev, generator=m._gen))))
+adv, ret = m._gae_native()
+obs = m.buf_obs.view(B, -1); act = m.buf_act.view(B, 4); old_lp = m.buf_lp.view(B)
+up = m._updater
+up.control(None, clear=True)
+print("epoch graph ms", T(lambda: up.epoch(obs, act, old_lp, adv.view(B), ret.view(B), m._perm_buf, 16384, 3e-4)), "-> us/update", T(lambda: up.epoch(obs, act, old_lp, adv.view(B), ret.view(B), m._perm_buf, 16384, 3e-4)) / 128 * 1e3)
+print("status ms", T(up.status))
+print("train ms", T(m.train, 3))

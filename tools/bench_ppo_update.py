@@ -18,7 +18,7 @@ def measure(L=17, B=16384, R=65536 * 8, iters=100, with_torch=True):
     perm = (torch.arange(R, device=dev) if os.environ.get("QR_BENCH_SEQUENTIAL_ROWS") else torch.randperm(R, device=dev)).to(torch.int32)
 
     def timed(fn, n):
-        for k in range(10):
+        for k in range(min(10, n)):
             fn(k)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -37,10 +37,19 @@ def measure(L=17, B=16384, R=65536 * 8, iters=100, with_torch=True):
         up.minibatch(obs, act, old_lp, adv, ret, perm[(k % nb) * B:(k % nb + 1) * B], 3e-4)
 
     t_native = timed(native_step, iters)
+
+    # the same updates as ONE replayed graph per epoch (qr_ppo_epoch: what PPO.train() calls), nb minibatches per epoch
+    perm_dev = perm[:nb * B].clone()
+
+    def epoch_step(k):
+        up.epoch(obs, act, old_lp, adv, ret, perm_dev, B, 3e-4, device_shuffle=True)
+
+    t_epoch = timed(epoch_step, max(3, iters // nb)) / nb
     flops = 2 * B * 3 * 2 * (L * 120 + 2 * 120 * 120 + 2.5 * 120)   # 2 nets x (fwd + 2 bwd GEMMs) x 2 flop/MAC, useful MACs only
     out = {"what": "one PPO minibatch update (both 3x120 networks: forward, loss, backward, grad-norm clip, Adam): qr_ppo_minibatch "
                    "vs torch autograd + torch.optim.Adam on the same rows", "obs_len": L, "minibatch": B,
-           "native_us": t_native * 1e6, "native_samples_per_s": B / t_native, "useful_TFLOPs": flops / t_native / 1e12}
+           "native_us": t_native * 1e6, "native_samples_per_s": B / t_native, "useful_TFLOPs": flops / t_native / 1e12,
+           "epoch_us": t_epoch * 1e6, "epoch_minibatches": nb, "epoch_useful_TFLOPs": flops / t_epoch / 1e12}
     up.close()
     if with_torch:
         ref = ActorCritic(L, 4).to(dev)

@@ -30,6 +30,8 @@ ap.add_argument("--ent-coef", type=float, default=0.0)
 ap.add_argument("--gamma", type=float, default=0.999)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--no-trunc-bootstrap", action="store_true", help="round-1 behaviour: a time-limit truncation is a termination")
+ap.add_argument("--eval-final", action="store_true", help="evaluate the FINAL policy (no best-by-training-statistic checkpoint)")
+ap.add_argument("--save", default="", help="save an SB3-shaped checkpoint (optimal_quad_control_rl_amd.sb3 format) of the final model here")
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 
@@ -63,8 +65,8 @@ def keep_best(m):
         best["gates"] = g
         best["state"] = {k: v.clone() for k, v in m.policy.state_dict().items()}
 t0 = time.perf_counter()
-model.learn(int(a.steps) // world, log_every=20, callback=keep_best)   # --steps counts env-steps of the whole job
-if best["state"] is not None:
+model.learn(int(a.steps) // world, log_every=20, callback=None if a.eval_final else keep_best)   # --steps counts env-steps of the whole job
+if best["state"] is not None and not a.eval_final:
     model.policy.load_state_dict(best["state"])  # evaluate the best checkpoint (the reference saves one every 10 rollouts, R:823)
 torch.cuda.synchronize()
 train_s = time.perf_counter() - t0
@@ -101,7 +103,8 @@ for k in range(2000):
     passed = torch.where(d, torch.zeros_like(passed), passed)
     lap_start = torch.where(d, torch.full_like(lap_start, t), lap_start)
 laps = (lap_sum / lap_cnt.clamp(min=1)).tolist()
-res = dict(world_size=world, fused_collect=a.fused, native_update=a.native_update, variant=a.variant, track=a.track, envs=a.envs,
+res = dict(evaluated="final policy" if a.eval_final else "best checkpoint by training statistic", lr_final_frac=a.lr_final,
+           world_size=world, fused_collect=a.fused, native_update=a.native_update, variant=a.variant, track=a.track, envs=a.envs,
            gamma=a.gamma, seed=a.seed, n_steps=a.n_steps, epochs=a.epochs, minibatches=a.minibatches, lr=a.lr, target_kl=a.target_kl,
            truncation_bootstrap=not a.no_trunc_bootstrap,
            train_steps=model.num_timesteps * world, train_seconds=train_s,
