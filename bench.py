@@ -204,7 +204,8 @@ def graph_of_launches(rt, fn, batch):
         fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: other threads of the process (e.g. the RCCL watchdog of a multi-rank run) may keep calling the runtime
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             for _ in range(batch):
                 fn()
         g.replay()
@@ -281,9 +282,10 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
     if timing_knob:
         env.set_timing(True)
     kernel_ms_samples = []
-    for _ in range(5):
-        one_region()
-        kernel_ms_samples.append(env.last_rollout_ms())  # hipEvents around this launch, on the launch stream
+    for _ in range(3):       # hipEvents around the LAST of a few back-to-back launches, on the launch stream (a launch measured in
+        for _ in range(3):   # isolation, after a host synchronisation, runs ~7 percent slower: clocks / cold caches)
+            one_region()
+        kernel_ms_samples.append(env.last_rollout_ms())
     fused_kernel_ms = float(np.median(kernel_ms_samples))
     launch_s = fused_kernel_ms * 1e-3
     flop = pmcc.get(f"rollout_kernel<{vidx}, {ga}>", {}).get("derived", {}).get("f32_flop_per_env_step")
@@ -417,22 +419,25 @@ def host_path_probe(variant, n, ga):
             "ms_per_step": dt * 1e3, "value": n / dt, "unit": "env-steps/s"}
 
 
-def config5_probe(n, iters=3):
+def config5_probe(n, iters=3, mb=16384):
     """BASELINE config 5 as a whole loop, short: PPO on the 4-gate square track with the E2E model (residual MLPs +
-    disturbances), reference hyper-parameters where they are the reference's (gamma 0.999, 10 epochs, 3 x 120 ReLU nets, R:784-795;
-    SB3's time-limit bootstrap) and this build's rollout shape (n envs x 32 steps, 16 384-row minibatches).  Collect =
-    qr_rollout_policy, GAE = qr_ppo_gae, update = qr_ppo_minibatch; `target_kl = None` like the reference, i.e. every one of
-    the epochs x minibatches updates runs.  Reports end-to-end env-steps/s of collect + update."""
+    disturbances), reference hyper-parameters where they are the reference's (gamma 0.999, 10 epochs, constant lr 3e-4, target_kl
+    None, 3 x 120 ReLU nets, R:784-795; SB3's time-limit bootstrap) and this build's rollout shape (n envs x 32 steps).  Collect =
+    qr_rollout_policy, GAE = qr_ppo_gae, update = qr_ppo_epoch (all epochs of a train() as one replayed graph, permutations drawn on
+    the device); every one of the epochs x minibatches updates runs.  `mb` rows per minibatch: 16 384 (128 minibatches per epoch,
+    the round-2 recipe) or 65 536 (32 per epoch -- closer to the reference's 20 per epoch, R:792).  Reports end-to-end env-steps/s."""
     import torch
     from optimal_quad_control_rl_amd import Quadcopter3DGates, TRAIN_DISTURBANCE_RANGES, square_track
     from optimal_quad_control_rl_amd.ppo import PPO
 
     env = Quadcopter3DGates(n, *square_track(), gates_ahead=1, infos_mode="none", seed=1)
     env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
-    n_steps, mb = 32, 16384
-    model = PPO(env, seed=0, gamma=0.999, n_steps=n_steps, n_epochs=10, batch_size=min(mb, n * n_steps), learning_rate=3e-4,
+    n_steps = 32
+    mb = min(mb, n * n_steps)
+    model = PPO(env, seed=0, gamma=0.999, n_steps=n_steps, n_epochs=10, batch_size=mb, learning_rate=3e-4,
                 target_kl=None, fused_collect=True, native_update=True)
-    model.collect(); model.train()   # warm-up iteration
+    model.collect(); model.train()   # warm-up iteration (captures the epoch graph)
+    model.collect(); model.train()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tc = 0.0
@@ -445,10 +450,11 @@ def config5_probe(n, iters=3):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     steps = iters * n * n_steps
-    updates = iters * 10 * ((n * n_steps) // min(mb, n * n_steps))
+    updates = iters * 10 * ((n * n_steps) // mb)
     env.close()
-    return {"what": "config 5, whole loop (fused collect + GAE + all %d updates per rollout, no early stop), %d iterations" % (updates // iters, iters),
-            "envs": n, "n_steps": n_steps, "minibatch": min(mb, n * n_steps), "epochs": 10, "value": steps / dt, "unit": "env-steps/s",
+    return {"what": "config 5, whole loop (fused collect + GAE + all %d updates per rollout of %d rows each, constant lr, no early stop), "
+                    "%d iterations" % (updates // iters, mb, iters),
+            "envs": n, "n_steps": n_steps, "minibatch": mb, "epochs": 10, "value": steps / dt, "unit": "env-steps/s",
             "collect_ms_per_rollout": tc / iters * 1e3, "update_ms_per_rollout": (dt - tc) / iters * 1e3,
             "us_per_update": (dt - tc) / updates * 1e6}
 
@@ -532,6 +538,7 @@ def headline(result):
     r = result.get("roofline", {})
     flat = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_us", "us_per_step",
                                   "bytes_per_env_step", "frac_on_8d_bytes")}
+    flat["frac_on_8d_bytes_is"] = "throughput yardstick of BASELINE.md section 4 (SURVEY 8(d) bytes / this kernel's time), NOT traffic: the state stays in registers"
     flat["traffic_source"] = PMC_SOURCES["traffic"]
     v = r.get("valu") or {}
     flat["valu_frac"], flat["valu_flop_per_env_step"], flat["valu_flop_source"] = v.get("frac"), v.get("flop_per_env_step"), PMC_SOURCES["flop"]
@@ -557,13 +564,15 @@ def headline(result):
                               "per_step_kernel_us": (ops.get("roofline") or {}).get("kernel_us"),
                               "per_step_frac": (ops.get("roofline") or {}).get("frac"),
                               "cpu_baseline_value": (o.get("cpu_baseline") or {}).get("value")}
-    pu, c5 = result.get("ppo_update") or {}, result.get("config5") or {}
+    pu, c5, c5b = result.get("ppo_update") or {}, result.get("config5") or {}, result.get("config5_mb65536") or {}
     if pu or c5:
-        h["ppo"] = {"update_us_per_16384_rows": pu.get("native_us"), "update_useful_TFLOPs": pu.get("useful_TFLOPs"),
-                    "update_mfma_frac": None if pu.get("useful_TFLOPs") is None else pu["useful_TFLOPs"] / MFMA_F16_PEAK_TF,
-                    "epoch_graph_us_per_update": pu.get("epoch_us"), "torch_us": pu.get("torch_us"),
+        h["ppo"] = {"update_us_per_16384_rows": pu.get("epoch_us"), "update_useful_TFLOPs": pu.get("epoch_useful_TFLOPs"),
+                    "update_mfma_frac": None if pu.get("epoch_useful_TFLOPs") is None else pu["epoch_useful_TFLOPs"] / MFMA_F16_PEAK_TF,
+                    "update_launch": "qr_ppo_epoch: one replayed graph per epoch (what training calls)",
+                    "stream_launch_us_per_update": pu.get("native_us"), "torch_us": pu.get("torch_us"),
                     "config5_value": c5.get("value"), "config5_us_per_update": c5.get("us_per_update"),
-                    "config5_what": _short(c5.get("what"), 140)}
+                    "config5_what": _short(c5.get("what"), 150),
+                    "config5_mb65536_value": c5b.get("value"), "config5_mb65536_us_per_update": c5b.get("us_per_update")}
     if "parity" in result:
         h["parity"] = {k: result["parity"].get(k) for k in ("max_rel_dstate_100_steps", "tolerance", "error") if k in result["parity"]}
     if result.get("rccl"):
@@ -673,6 +682,7 @@ def run(args, rt, env_factory=make_env, closed_loop=True):
                 result["ppo_update"] = {"error": repr(ex)}
             try:
                 result["config5"] = config5_probe(n)
+                result["config5_mb65536"] = config5_probe(n, mb=65536)
             except Exception as ex:  # pragma: no cover
                 result["config5"] = {"error": repr(ex)}
             try:

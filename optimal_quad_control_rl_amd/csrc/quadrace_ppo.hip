@@ -1444,6 +1444,7 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, float* __r
                 if (i < D::kImage) dst[i ^ (((i >> 5) & 3) << 2)] = img[q];   // chunk swizzle: conflict-free transposed reads
             }
         }
+        PPO_TICK(a, 1);   // (profiling build) image staged: compare with the chain waves' release from [S0]
         // weight-gradient accumulators, live across the passes (initialised AFTER the staging burst: its 80 registers are free again)
         f32x16p dw4 = zero, dw3[2][2] = {{zero, zero}, {zero, zero}}, dw2[2][2] = {{zero, zero}, {zero, zero}}, dw1[2][2] = {{zero, zero}, {zero, zero}};
     for (int pair = blockIdx.x, pass = 0; pair < pairs; pair += gridDim.x, ++pass) {

@@ -299,6 +299,7 @@ class PPO:
         self._done_u8 = torch.empty((T, N), dtype=torch.uint8, device=self.dev)
         self._trunc_u8 = torch.empty((T, N), dtype=torch.uint8, device=self.dev)
         self.num_timesteps = 0
+        self._kl_first_trips, self._kl_lr_scale = 0, 1.0
         self.obs = env.reset_device().clone()
         # on-device episode statistics (what VecMonitor provides in the reference, R:769)
         self.ep_ret = torch.zeros(N, **f32)
@@ -474,10 +475,11 @@ class PPO:
         act = self.buf_act.view(B, 4)
         old_lp, adv, ret = self.buf_lp.view(B), adv.view(B), ret.view(B)
         losses = []
-        if self.total_hint:  # linear learning-rate decay (SB3: learning_rate may be a schedule)
-            frac = min(1.0, self.num_timesteps / float(self.total_hint))
-            for g in self.opt.param_groups:
-                g["lr"] = self.lr0 * (1.0 - (1.0 - self.lr_final_frac) * frac)
+        # learning rate: SB3's `learning_rate` may be a schedule (linear decay when total_timesteps_hint is given); on top of it the
+        # target-KL guard below may have halved it
+        frac = min(1.0, self.num_timesteps / float(self.total_hint)) if self.total_hint else 0.0
+        for g in self.opt.param_groups:
+            g["lr"] = self.lr0 * (1.0 - (1.0 - self.lr_final_frac) * frac) * getattr(self, "_kl_lr_scale", 1.0)
         if self.native_update:
             return self._train_native(obs, act, old_lp.contiguous(), adv.contiguous(), ret.contiguous(), B)
         stop = False
@@ -507,10 +509,26 @@ class PPO:
                 nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
                 self.opt.step()
                 losses.append(loss.detach())
+        self._kl_guard(self.target_kl is not None, stop and len(losses) <= 1)
         if losses:
             self.stats["loss"] = float(torch.stack(losses).mean())
         self.stats["updates"] = self.stats.get("updates", 0) + len(losses)
         self.stats["std"] = float(self.policy.log_std.detach().exp().mean())
+
+    def _kl_guard(self, armed, first_minibatch_tripped, patience=3):
+        """SB3's target_kl rule checks the approximate KL BEFORE a minibatch's step, i.e. from the second minibatch on it measures
+        what the steps already taken did.  If one step at the current learning rate moves the policy by more than 1.5 target_kl, the
+        rule stops every rollout after its FIRST step and the run never recovers (seen once in round 2: profiles/
+        r02_ppo_6e9_seed3_stall_trace.txt).  Guard: when a whole train() took at most ONE step because the rule tripped on its
+        second minibatch -- or none at all -- `patience` rollouts in a row, the learning rate is halved (down to lr / 64) until
+        steps fit under the limit again.  (The reference itself runs with target_kl = None; this only exists for the speed option.)"""
+        if not armed:
+            return
+        self._kl_first_trips = self._kl_first_trips + 1 if first_minibatch_tripped else 0
+        if self._kl_first_trips >= patience and getattr(self, "_kl_lr_scale", 1.0) > 1.0 / 64.0:
+            self._kl_lr_scale = getattr(self, "_kl_lr_scale", 1.0) * 0.5
+            self._kl_first_trips = 0
+            self.stats["kl_lr_halvings"] = self.stats.get("kl_lr_halvings", 0) + 1
 
     def _train_native(self, obs, act, old_lp, adv, ret, B):
         up = self._updater
@@ -556,6 +574,7 @@ class PPO:
         self.stats["clip_fraction"] = st[3] / seen
         self.stats["updates"] = self.stats.get("updates", 0) + applied
         self.stats["early_stop"] = bool(stopped)
+        self._kl_guard(kl_stop, bool(stopped) and applied <= 1)
         self.stats["skipped_nonfinite"] = self.stats.get("skipped_nonfinite", 0) + skipped
         self.stats["std"] = float(self.policy.log_std.detach().exp().mean())
 
@@ -609,7 +628,7 @@ class PPO:
         return dict(optimizer=opt, num_timesteps=int(self.num_timesteps), ep_ret=self.ep_ret.cpu(), ep_len=self.ep_len.cpu(),
                     ep_gates=self.ep_gates.cpu(), stats=dict(self.stats), noise_seed=int(self.noise_seed),
                     lr0=float(self.lr0), lr_final_frac=float(self.lr_final_frac), total_hint=self.total_hint,
-                    kl_trips=int(getattr(self, "_kl_first_trips", 0)), env=env, rng=self._gen.get_state())
+                    kl_trips=int(getattr(self, "_kl_first_trips", 0)), kl_lr_scale=float(getattr(self, "_kl_lr_scale", 1.0)), env=env, rng=self._gen.get_state())
 
     @torch.no_grad()
     def load_state_dict(self, sd):
@@ -633,6 +652,7 @@ class PPO:
         self.noise_seed = int(sd["noise_seed"])
         self.lr0, self.lr_final_frac, self.total_hint = float(sd["lr0"]), float(sd["lr_final_frac"]), sd["total_hint"]
         self._kl_first_trips = int(sd.get("kl_trips", 0))
+        self._kl_lr_scale = float(sd.get("kl_lr_scale", 1.0))
         e = sd["env"]
         self.env.set_state_tensors(world=e["world"], dist=e["dist"], target=e["target"], steps=e["steps"], episode=e["episode"])
         self.env.update_states()

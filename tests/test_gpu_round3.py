@@ -438,3 +438,27 @@ def test_device_shuffle_is_a_fresh_permutation_every_epoch_and_is_checkpointable
         torch.cuda.synchronize()
         assert torch.equal(pa.cpu().long(), seen[1])
         up_a.close(); up_b.close()
+
+
+def test_target_kl_guard_halves_the_learning_rate_instead_of_stalling():
+    """VERDICT r02 item 6 / the seed-3 stall of round 2: when SB3's target_kl rule ends `patience` consecutive train() calls after
+    at most one optimiser step, the learning rate is halved (and keeps being halved) rather than leaving the run stuck at one
+    step per rollout for ever.  A limit far below what a single step moves forces the situation."""
+    from optimal_quad_control_rl_amd import Quadcopter3DGatesINDI, square_track
+    from optimal_quad_control_rl_amd.ppo import PPO as Trainer
+
+    env = Quadcopter3DGatesINDI(4096, *square_track(), gates_ahead=1, infos_mode="none", seed=4)
+    tr = Trainer(env, n_steps=8, batch_size=4096, n_epochs=3, gamma=0.999, seed=0, target_kl=1e-9, fused_collect=True, native_update=True)
+    lrs = []
+    for _ in range(8):
+        tr.collect(); tr.train()
+        lrs.append(tr.opt.param_groups[0]["lr"])
+        assert tr.stats["early_stop"]
+    assert tr._kl_lr_scale <= 0.25 and tr.stats["kl_lr_halvings"] >= 2, (tr._kl_lr_scale, tr.stats)
+    assert lrs[-1] < lrs[0] and lrs[0] == pytest.approx(3e-4)
+    # and an unarmed trainer (the reference's target_kl = None) never touches the learning rate
+    tr2 = Trainer(env, n_steps=8, batch_size=4096, n_epochs=2, gamma=0.999, seed=0, target_kl=None, fused_collect=True, native_update=True)
+    for _ in range(4):
+        tr2.collect(); tr2.train()
+    assert tr2._kl_lr_scale == 1.0 and "kl_lr_halvings" not in tr2.stats and tr2.stats["updates"] == 4 * 2 * (8 * 4096 // 4096)
+    env.close()
