@@ -1224,7 +1224,6 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, float* __r
     const float scale = 1.0f / (float)a.B;
     const int pairs = (a.G + 1) / 2;   // passes of 2 sample groups = 128 samples
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    constexpr int kImgLoads = (D::kImage + 255) / 256;   // 16-byte loads per dW-wave thread (the four dW waves = 256 threads)
     // The pass loop is written out per role (loop unswitching by hand): inside ONE loop the dW waves' persistent accumulators would be
     // live through the chain waves' branch as well (the compiler does not know that a wave never changes its role) and spill.
     if (role == 0) {
@@ -1262,7 +1261,10 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, float* __r
 #pragma unroll
                 for (int k = 0; k < 4; ++k) log_std_v[k] = log_std[k];
             }
-            __syncthreads();   // [S0] image staged by the dW waves (first pass) / they have finished with the exchange area
+            // Pass 0: the dW waves stage the operand image layer by layer and release one barrier per layer ([A] W1, [B] W2, [C] W3,
+            // [S0] W4): the forward pass starts as soon as W1 is in LDS and runs while the other 72 KB arrive (staging the whole
+            // image before the first layer was the long pole of the prologue: 8.2 k of 9.7 k cycles).  Later passes: [S0] only.
+            __syncthreads();   // pass 0: [A] W1 staged / later passes: [S0] the dW waves have finished with the exchange area
             if (stop_flag) return;   // uniform over the grid
             PPO_TICK(a, 1);
             if (h == 0) {
@@ -1291,10 +1293,13 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, float* __r
             half8 h1[8], h2[8], h3[8];
             mlp_layer<KS1, false, true>(W, lane, in, h1, m1);
             PPO_TICK(a, 2);
+            if (pass == 0) __syncthreads();   // [B] W2 staged
             mlp_layer<8, false, true>(W + P::kOff2, lane, h1, h2, m2);
             PPO_TICK(a, 3);
+            if (pass == 0) __syncthreads();   // [C] W3 staged
             mlp_layer<8, false, true>(W + P::kOff3, lane, h2, h3, m3);
             PPO_TICK(a, 4);
+            if (pass == 0) __syncthreads();   // [S0] W4 staged
             half8 w4[8], w4t[4];
 #pragma unroll
             for (int s = 0; s < 8; ++s) w4[s] = W[P::kOff4 + s * 64 + (lane ^ ((h | ((s & 1) << 1)) << 2))];
@@ -1423,26 +1428,40 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, float* __r
         }
     } else {
         // The operand image (80 KB) is staged by THESE four waves -- they have nothing else to do until the first operands are
-        // published and nothing else live in their registers -- while the chain waves' gather is in flight: ONE burst of
-        // kImgLoads x 16 bytes per thread (two half-bursts were two exposed round trips: the chain waited 19 k cycles at [S0]).
-        // Every workgroup walks the image in a different rotation: all workgroups of a network read the SAME 80 KB, and in the
-        // same order they would all be queueing on one L2 channel at a time.
-    {
+        // published and nothing else live in their registers -- while the chain waves' gather is in flight.  ALL loads are issued
+        // up front in layer order (one burst of kImgLoads x 16 bytes per thread; loads return in order), then each layer is written
+        // to LDS and released with its own barrier, so that the chain waves' forward pass overlaps the rest of the staging.
+        // Every workgroup walks a layer's chunks in a different rotation: all workgroups of a network read the SAME 80 KB, and in
+        // the same order they would all be queueing on one L2 channel at a time.
+        {
             const f32x4p* src = reinterpret_cast<const f32x4p*>(a.images + (size_t)net * D::kImage);
             f32x4p* dst = reinterpret_cast<f32x4p*>(W);
             const int t256 = (int)(threadIdx.x & 255);
-            const int rot = (int)(blockIdx.x % kImgLoads);
-            f32x4p img[kImgLoads];
+            constexpr int n1 = P::kOff2 / 256, n2 = (P::kOff3 - P::kOff2) / 256, n3 = (P::kOff4 - P::kOff3) / 256, n4 = (D::kImage - P::kOff4) / 256;
+            static_assert(P::kOff2 % 256 == 0 && P::kOff3 % 256 == 0 && P::kOff4 % 256 == 0 && D::kImage % 256 == 0, "image layers are whole 256-chunk blocks");
+            const int rot = (int)blockIdx.x;
+            f32x4p i1[n1], i2[n2], i3[n3], i4[n4];
 #pragma unroll
-            for (int q = 0; q < kImgLoads; ++q) {
-                const int i = ((q + rot) % kImgLoads) * 256 + t256;
-                img[q] = src[i < D::kImage ? i : 0];
-            }
+            for (int q = 0; q < n1; ++q) i1[q] = src[((q + rot) % n1) * 256 + t256];
 #pragma unroll
-            for (int q = 0; q < kImgLoads; ++q) {
-                const int i = ((q + rot) % kImgLoads) * 256 + t256;
-                if (i < D::kImage) dst[i ^ (((i >> 5) & 3) << 2)] = img[q];   // chunk swizzle: conflict-free transposed reads
-            }
+            for (int q = 0; q < n2; ++q) i2[q] = src[P::kOff2 + ((q + rot) % n2) * 256 + t256];
+#pragma unroll
+            for (int q = 0; q < n3; ++q) i3[q] = src[P::kOff3 + ((q + rot) % n3) * 256 + t256];
+#pragma unroll
+            for (int q = 0; q < n4; ++q) i4[q] = src[P::kOff4 + ((q + rot) % n4) * 256 + t256];
+            auto put = [&](int i, const f32x4p& v) { dst[i ^ (((i >> 5) & 3) << 2)] = v; };   // chunk swizzle: conflict-free transposed reads
+#pragma unroll
+            for (int q = 0; q < n1; ++q) put(((q + rot) % n1) * 256 + t256, i1[q]);
+            __syncthreads();   // [A] W1 staged
+            if (stop_flag) return;   // uniform over the grid (the chain waves leave at the same barrier)
+#pragma unroll
+            for (int q = 0; q < n2; ++q) put(P::kOff2 + ((q + rot) % n2) * 256 + t256, i2[q]);
+            __syncthreads();   // [B] W2 staged
+#pragma unroll
+            for (int q = 0; q < n3; ++q) put(P::kOff3 + ((q + rot) % n3) * 256 + t256, i3[q]);
+            __syncthreads();   // [C] W3 staged
+#pragma unroll
+            for (int q = 0; q < n4; ++q) put(P::kOff4 + ((q + rot) % n4) * 256 + t256, i4[q]);
         }
         PPO_TICK(a, 1);   // (profiling build) image staged: compare with the chain waves' release from [S0]
         // weight-gradient accumulators, live across the passes (initialised AFTER the staging burst: its 80 registers are free again)
