@@ -333,8 +333,9 @@ int qr_set_residual(qr_env* e, const float* blob, size_t n_floats) {
     for (int h = 0; h < 2; ++h)
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            T[qr::kOffTabW2 + 64 * h + r] = tW2[row];
-            for (int m = 0; m < 3; ++m) T[qr::kOffTabW2 + 64 * h + 16 + 16 * m + r] = mW2[m * 32 + row];
+            // x 2^40 (exact): the kernels' ReLU leaves max(x, 0) * 2^-40, see relu2_scaled() in quadrace_device.hpp
+            T[qr::kOffTabW2 + 64 * h + r] = tW2[row] * qr::kReluUp;
+            for (int m = 0; m < 3; ++m) T[qr::kOffTabW2 + 64 * h + 16 + 16 * m + r] = mW2[m * 32 + row] * qr::kReluUp;
         }
     T[qr::kOffB2 + 0] = tb2[0];
     for (int o = 0; o < 3; ++o) T[qr::kOffB2 + 1 + o] = mb2[o];

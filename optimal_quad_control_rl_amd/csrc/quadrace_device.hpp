@@ -38,8 +38,8 @@ constexpr int kFlagPauseIfCollision = 4;
 //   tabA [10][64]  layer-1 A operands of v_mfma_f32_32x32x2_f32, one float per lane per K-step:
 //                  t = 0..3  thrust tile,  k = 2t + (lane>>5):      k < 7 ? W1t[lane&31][k] : (k == 7  ? b1t[lane&31] : 0)
 //                  t = 4..9  moment tile,  k = 2(t-4) + (lane>>5):  k < 10 ? W1m[lane&31][k] : (k == 10 ? b1m[lane&31] : 0)
-//   tabW2 [2][64]  layer-2 weights seen by the lanes of wave half h = lane>>5; accumulator register r holds hidden
-//                  row(r,h) = (r&3) + 8*(r>>2) + 4h:   [r] = W2t[0][row]   [16 + 16m + r] = W2m[m][row], m = 0..2
+//   tabW2 [2][64]  layer-2 weights x 2^40 (see relu2_scaled) seen by the lanes of wave half h = lane>>5; accumulator register
+//                  r holds hidden row(r,h) = (r&3) + 8*(r>>2) + 4h:   [r] = W2t[0][row]   [16 + 16m + r] = W2m[m][row], m = 0..2
 //   b2 [4]         output biases (thrust, moment x/y/z)
 constexpr int kOffTabA = 0, kOffTabW2 = 640, kOffB2 = 768;
 constexpr int kMlpTableFloats = 784;  // 772 used, padded to a multiple of 16
@@ -342,29 +342,21 @@ __device__ __forceinline__ void pair_to_tiles(float a, float b, float& lo, float
     hi = __uint_as_float(r.y);
 }
 
-// sum over this lane's 16 hidden rows: dot(w[0..15], relu(acc[0..15])), four independent chains
-__device__ __forceinline__ float relu_dot16(const float* w, const f32x16& acc) {
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; r += 4) {
-        s0 = fmaf(w[r + 0], fmaxf(acc[r + 0], 0.0f), s0);
-        s1 = fmaf(w[r + 1], fmaxf(acc[r + 1], 0.0f), s1);
-        s2 = fmaf(w[r + 2], fmaxf(acc[r + 2], 0.0f), s2);
-        s3 = fmaf(w[r + 3], fmaxf(acc[r + 3], 0.0f), s3);
-    }
-    return (s0 + s1) + (s2 + s3);
-}
-
-// max(x, 0) as ONE v_max_f32.  fmaxf() costs two: LLVM first canonicalises an operand it cannot prove quiet
-// (v_max_f32 x, x, x) -- matrix-core results never are signalling NaNs, and v_max_f32 itself returns the non-NaN operand,
-// so relu0(NaN) = 0 = fmaxf(NaN, 0): identical results, 128 fewer VALU instructions per env step.  Inline asm also keeps
-// the operation where the source puts it (between the MFMAs of the next accumulator, see residual_mlp).
+// ReLU of TWO accumulator rows in ONE instruction: v_pk_mul_f32 with the CLAMP modifier, clamp(x * 2^-40) in [0, 1].  For
+// |x| < 2^40 the upper clamp never acts and the power-of-two scaling is exact, so the result is max(x, 0) * 2^-40 exactly; the
+// output-layer weights are stored pre-multiplied by 2^40 (host side, exact), and the fused multiply-add rounds w' * t + s =
+// w * max(x, 0) + s once -- bit for bit what fmaf(w, max(x, 0), s) gives.  (A hidden pre-activation of 1e12 does not occur: inputs
+// are motor commands in [-1, 1], body velocities and rates the out-of-bounds guard keeps below 1000; NaN clamps to 0 like the
+// v_max form.)  There is no v_pk_max_f32 on gfx950: the v_max form cost 64 single-lane-pair instructions per env step, this
+// costs 32.  fmaxf() would cost two each: LLVM first canonicalises an operand it cannot prove quiet.
 // MFMA -> VALU read hazards: the wait states after a matrix instruction are inserted by the compiler's hazard recogniser,
 // which does not look inside inline asm.  `ready` is the result of acc_ready(): a compiler-visible VALU read of the same
-// accumulator (so the wait states are inserted before IT), and passing it in orders every relu0 of that accumulator behind it.
-__device__ __forceinline__ float relu0(float x, uint32_t ready) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x), "s"(ready));
+// accumulator (so the wait states are inserted before IT), and passing it in orders every relu2 of that accumulator behind it.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+constexpr float kReluDown = 0x1p-40f, kReluUp = 0x1p40f;   // tabW2 holds W2 * kReluUp
+__device__ __forceinline__ f32x2v relu2_scaled(f32x2v x, f32x2v down, uint32_t ready) {
+    f32x2v r;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "v"(down), "s"(ready));
     return r;
 }
 template <class Acc>
@@ -372,17 +364,18 @@ __device__ __forceinline__ uint32_t acc_ready(const Acc& acc) {
     return (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(acc[0]));
 }
 
-// dot(w[0..15], relu(acc[0..15])) over this lane's 16 hidden rows as four independent chains, cut into 4-row chunks
-// so that the chunks can be placed between MFMAs
+// dot(w[0..15], relu(acc[0..15])) over this lane's 16 hidden rows as four independent chains (two packed pairs), cut into 4-row
+// chunks so that the chunks can be placed between MFMAs
 struct DotAcc {
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    __device__ __forceinline__ float sum() const { return (s0 + s1) + (s2 + s3); }
+    f32x2v s01 = {0.0f, 0.0f}, s23 = {0.0f, 0.0f};
+    __device__ __forceinline__ float sum() const { return (s01.x + s01.y) + (s23.x + s23.y); }
 };
 __device__ __forceinline__ void dot_chunk(const float* w, const f32x16& acc, int r, DotAcc& d, uint32_t ready) {
-    d.s0 = fmaf(w[r + 0], relu0(acc[r + 0], ready), d.s0);
-    d.s1 = fmaf(w[r + 1], relu0(acc[r + 1], ready), d.s1);
-    d.s2 = fmaf(w[r + 2], relu0(acc[r + 2], ready), d.s2);
-    d.s3 = fmaf(w[r + 3], relu0(acc[r + 3], ready), d.s3);
+    const f32x2v down = {kReluDown, kReluDown};
+    const f32x2v a01 = {acc[r + 0], acc[r + 1]}, a23 = {acc[r + 2], acc[r + 3]};
+    const f32x2v w01 = {w[r + 0], w[r + 1]}, w23 = {w[r + 2], w[r + 3]};
+    d.s01 = __builtin_elementwise_fma(w01, relu2_scaled(a01, down, ready), d.s01);
+    d.s23 = __builtin_elementwise_fma(w23, relu2_scaled(a23, down, ready), d.s23);
 }
 
 __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const float x[10], float& thrust,
