@@ -148,18 +148,15 @@ __device__ __forceinline__ uint32_t shuffle_mix(uint32_t x, uint32_t k) {
     h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13; h *= 0xC2B2AE3Du; h ^= h >> 16;
     return h;
 }
-__global__ void __launch_bounds__(256) ppo_shuffle_kernel(int* __restrict__ perm, unsigned int n, unsigned long long seed,
-                                                          const unsigned long long* __restrict__ count) {
-    const unsigned int i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long c = *count;
+// element i of the permutation of [0, n) keyed by (seed, c)
+__device__ __forceinline__ unsigned int shuffle_index(unsigned int i, unsigned int n, unsigned long long seed, unsigned long long c) {
     unsigned int bits = 2;
     while ((1ull << bits) < n) ++bits;
     const unsigned int lb = bits >> 1, rb = bits - lb;
     const unsigned int lmask = (1u << lb) - 1u, rmask = (1u << rb) - 1u;
     uint32_t key[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {   // round keys: SplitMix64-style finaliser of (seed, epoch count, round)
+    for (int r = 0; r < 8; ++r) {   // round keys: SplitMix64-style finaliser of (seed, epoch count, round) -- wave-uniform: scalar code
         unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (c * 8ull + (unsigned long long)r + 1ull);
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -175,7 +172,13 @@ __global__ void __launch_bounds__(256) ppo_shuffle_kernel(int* __restrict__ perm
         }
         x = (l << rb) | r_;
     } while (x >= n);
-    perm[i] = (int)x;
+    return x;
+}
+__global__ void __launch_bounds__(256) ppo_shuffle_kernel(int* __restrict__ perm, unsigned int n, unsigned long long seed,
+                                                          const unsigned long long* __restrict__ count) {
+    const unsigned int i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    perm[i] = (int)shuffle_index(i, n, seed, *count);
 }
 
 // (same-address f64 atomics serialise at ~15 ns each: one pair per 1024-thread block, not one per wave)
@@ -1240,7 +1243,15 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, float* __r
             // =========================================== chain waves ===========================================================
             const int g = 2 * pair + (wave >> 1);
             const bool live = g < a.G;   // whole wave; a wave without samples runs on row 0 with zero deltas (it shares the barriers)
+            // (Measured and dropped: under qr_ppo_epoch's device shuffle the row index is a computable bijection of the position, so
+            // the kernel could form it instead of loading it -- one dependent round trip less, 3.4 k of the prologue's 7.7 k cycles
+            // in a probe that skipped the index.  The 8-round Feistel + key derivation in front of the gather cost as much as the
+            // trip saved: epoch graph 38.4 -> 39.4 us per update at 16 384 rows, 70 -> 75 us at 65 536.  -DQR_EXP_NOIDX keeps the probe.)
+#ifdef QR_EXP_NOIDX
+            const int b = (live ? g : a.G - 1) * 64 + 32 * et + c;
+#else
             const int b = a.idx[(live ? g : a.G - 1) * 64 + 32 * et + c];
+#endif
             float xin[KS1][8];
             {
                 const float* row = a.obs + (size_t)b * L;

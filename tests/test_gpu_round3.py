@@ -409,6 +409,8 @@ def test_device_shuffle_is_a_fresh_permutation_every_epoch_and_is_checkpointable
         rows = B * M
         pa = torch.empty(rows, dtype=torch.int32, device=obs.device)
         pb = torch.empty(rows, dtype=torch.int32, device=obs.device)
+        up_c = MfmaPpoUpdater(pol, L, obs.device, max_minibatch=B)   # replays the permutations through LOADED indices
+        up_c.theta.copy_(up_a.theta); up_c.pack()
         up_a.set_shuffle(1234, 0); up_b.set_shuffle(1234, 0)
         seen = []
         for ep in range(3):
@@ -418,6 +420,13 @@ def test_device_shuffle_is_a_fresh_permutation_every_epoch_and_is_checkpointable
             assert torch.equal(torch.sort(q).values, torch.arange(rows)), (B, M, ep)
             seen.append(q)
             assert up_a.shuffle_state() == (1234, ep + 1)
+            # the epoch graph and the same rows fed through stream launches, minibatch by minibatch: same parameters bit for bit
+            pc = pa.clone()
+            up_c.begin_epoch(adv, pc, B)
+            for k in range(M):
+                up_c.minibatch(obs, act, old_lp, adv, ret, pc[k * B:(k + 1) * B], 3e-4)
+            torch.cuda.synchronize()
+            assert torch.equal(up_a.theta, up_c.theta) and torch.equal(up_a.v, up_c.v), (B, M, ep)
         assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
         if rows > 10000:
             pos = torch.arange(rows, dtype=torch.float64)
@@ -437,7 +446,7 @@ def test_device_shuffle_is_a_fresh_permutation_every_epoch_and_is_checkpointable
         up_a.epoch(obs, act, old_lp, adv, ret, pa, B, 3e-4, device_shuffle=True)
         torch.cuda.synchronize()
         assert torch.equal(pa.cpu().long(), seen[1])
-        up_a.close(); up_b.close()
+        up_a.close(); up_b.close(); up_c.close()
 
 
 def test_target_kl_guard_halves_the_learning_rate_instead_of_stalling():

@@ -7,12 +7,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from optimal_quad_control_rl_amd import build as B
 nodrain = os.environ.get("QR_TICK_NODRAIN") == "1"
-dbg = os.path.join(ROOT, "optimal_quad_control_rl_amd", "_dbg", "libquadrace_dbg%s.so" % ("_nodrain" if nodrain else ""))   # travels with the snapshot (git-ignored)
+extra = os.environ.get("QR_TICK_EXTRA_FLAGS", "").split()
+dbg = os.path.join(ROOT, "optimal_quad_control_rl_amd", "_dbg", "libquadrace_dbg%s%s.so" % ("_nodrain" if nodrain else "", "_x" if extra else ""))   # travels with the snapshot (git-ignored)
 os.makedirs(os.path.dirname(dbg), exist_ok=True)
 srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES]
 if "--build-only" in sys.argv or not os.path.exists(dbg) or os.path.getmtime(dbg) < max(os.path.getmtime(f) for f in srcs):
     flags = [f for f in B.FLAGS if f not in ("-mllvm", "-amdgpu-mfma-vgpr-form")]
-    subprocess.check_call([B._hipcc(), *flags, "-DQR_PHASE_TIMING", *(["-DQR_PHASE_TIMING_NODRAIN"] if nodrain else []), "-o", dbg] + srcs)
+    subprocess.check_call([B._hipcc(), *flags, "-DQR_PHASE_TIMING", *(["-DQR_PHASE_TIMING_NODRAIN"] if nodrain else []), *extra, "-o", dbg] + srcs)
 if "--build-only" in sys.argv:
     sys.exit(0)
 B.LIB = dbg
@@ -52,7 +53,7 @@ elif not grad4:
     cn = ["entry", "gather issue, barrier S0 (image staged by the dW waves)", "fwd layer 1", "fwd layer 2", "fwd layer 3",
           "output layer + loss gradient", "d4^T, h3 -> LDS, barrier S1", "d3", "barrier S2, d3, h2 -> LDS, barrier S3",
           "d2 (transposed reads)", "barrier S4, d2, h1 -> LDS, barrier S5", "d1 (transposed reads)", "barrier S6, d1, x0^T -> LDS, barrier S7"]
-    print("role-split gradient kernel, CHAIN wave (one 32-sample tile; queues drained at every stamp):")
+    print("role-split gradient kernel, CHAIN wave (one 32-sample tile; %s):" % ("stamps WITHOUT draining the queues: where the waves are" if nodrain else "queues drained at every stamp"))
     for s_ in range(1, 13):
         print(f"  {s_:2d} {cn[s_]:62s} {np.median(ch[..., s_] - ch[..., s_ - 1]):8.0f} cycles")
     print(f"  chain total {np.median(ch[..., 12] - ch[..., 0]):8.0f} cycles")
