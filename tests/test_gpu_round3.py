@@ -471,3 +471,28 @@ def test_target_kl_guard_halves_the_learning_rate_instead_of_stalling():
         tr2.collect(); tr2.train()
     assert tr2._kl_lr_scale == 1.0 and "kl_lr_halvings" not in tr2.stats and tr2.stats["updates"] == 4 * 2 * (8 * 4096 // 4096)
     env.close()
+
+
+def test_sb3_infos_under_pause_if_collision_hand_back_the_frozen_observation():
+    """ADVICE r02: with pause_if_collision there is no auto-reset (R:573-578), so the kernels write no terminal-observation row;
+    `infos_mode="sb3"` must hand back the observation of the frozen env itself (what the reference's `self.states[i]` is in that
+    mode), not a stale row of the terminal-observation buffer."""
+    from optimal_quad_control_rl_amd import Quadcopter3DGatesINDI, square_track
+
+    n = 256
+    env = Quadcopter3DGatesINDI(n, *square_track(), gates_ahead=1, pause_if_collision=True, infos_mode="sb3", seed=9)
+    env.reset()
+    env.max_steps = 30
+    rng = np.random.default_rng(0)
+    seen = 0
+    for k in range(40):
+        obs, rew, done, infos = env.step(rng.uniform(-1, 1, size=(n, 4)).astype(np.float32))
+        assert len(infos) == n
+        for i in np.nonzero(done)[0]:
+            np.testing.assert_array_equal(infos[i]["terminal_observation"], obs[i])
+            assert infos[i]["TimeLimit.truncated"] in (True, False)
+            seen += 1
+        for i in np.nonzero(~done)[0][:4]:
+            assert infos[i] == {}
+    assert seen > 0
+    env.close()
