@@ -181,6 +181,14 @@ __global__ void __launch_bounds__(256) ppo_shuffle_kernel(int* __restrict__ perm
     perm[i] = (int)shuffle_index(i, n, seed, *count);
 }
 
+// Clears the advantage-sum table ahead of ppo_adv_stats_kernel.  A KERNEL, not hipMemsetAsync: inside qr_ppo_epoch's captured graph
+// a memset node was seen to lose its ordering against the kernel nodes around it on REPLAY (ROCm 7.2: whole epochs whose sums
+// were cleared mid-accumulation -> non-finite gradients, every update of the epoch skipped; tests/test_gpu_round2.py config-5 loop).
+__global__ void __launch_bounds__(256) ppo_zero_table_kernel(double* __restrict__ table, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) table[i] = 0.0;
+}
+
 // (same-address f64 atomics serialise at ~15 ns each: one pair per 1024-thread block, not one per wave)
 __global__ void __launch_bounds__(1024) ppo_adv_stats_kernel(const float* __restrict__ adv, const int* __restrict__ idx, int B,
                                                              double* __restrict__ table, unsigned long long* __restrict__ bump) {
@@ -1965,6 +1973,7 @@ struct qr_ppo {
     static constexpr int kFusedChunks = 128;          // workgroups (= partials) per network of the fused gradient kernel
     bool fused = true;                                // QR_PPO_SPLIT=1: the two-kernel form (phase A + phase B through scratch)
     bool grad4 = false;                               // QR_PPO_GRAD4=1: fused gradient kernel in its 4-wave form (round 2)
+    bool epoch_graph = true;                          // QR_PPO_EPOCH_GRAPH=0: qr_ppo_epoch enqueues its launches on the stream
     qr::half8* d_images = nullptr;
     qr::half8* d_tbuf = nullptr;
     float* d_partial = nullptr;  // [max_chunks][num_params] phase-B outputs
@@ -2033,7 +2042,7 @@ struct PpoOps {
         }
         p->epoch_idx = nullptr;
         double* slot = p->d_mbstats + 2 * qr_ppo::kMaxEpochMinibatches;
-        PPO_HIP(hipMemsetAsync(slot, 0, 2 * sizeof(double), st));
+        hipLaunchKernelGGL(qr::ppo_zero_table_kernel, dim3(1), dim3(256), 0, st, slot, 2);
         hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((b.B + 1023) / 1024, 1), dim3(1024), 0, st, b.adv, b.idx, b.B, slot,
                            (unsigned long long*)nullptr);
         b.acc = slot;
@@ -2179,6 +2188,8 @@ int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo
         p->fused = !(split && split[0] == '1');
         const char* g4 = getenv("QR_PPO_GRAD4");
         p->grad4 = g4 && g4[0] == '1';
+        const char* eg = getenv("QR_PPO_EPOCH_GRAPH");
+        p->epoch_graph = !(eg && eg[0] == '0');
     }
     PPO_HIP(hipSetDevice(device));
     const size_t tbytes = (size_t)2 * p->slots * (max_minibatch / 64) * 256 * 16;
@@ -2258,7 +2269,7 @@ static int epoch_begin_impl(qr_ppo* p, const float* adv_dev, const int32_t* idx_
         return ppofail(QR_E_INVALID, "qr_ppo_epoch_begin: bad minibatch size / count");
     PPO_HIP(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
-    PPO_HIP(hipMemsetAsync(p->d_mbstats, 0, (size_t)num_minibatches * 2 * sizeof(double), st));
+    hipLaunchKernelGGL(qr::ppo_zero_table_kernel, dim3((2 * num_minibatches + 255) / 256), dim3(256), 0, st, p->d_mbstats, 2 * num_minibatches);
     hipLaunchKernelGGL(qr::ppo_adv_stats_kernel, dim3((B + 1023) / 1024, num_minibatches), dim3(1024), 0, st, adv_dev, idx_dev, B,
                        p->d_mbstats, bump);
     PPO_HIP(hipGetLastError());
@@ -2423,7 +2434,7 @@ int qr_ppo_epoch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_d
         }
         return QR_OK;
     };
-    if (caller_captures) return enqueue(st);   // a graph launch cannot be captured: plain nodes into the caller's graph
+    if (caller_captures || !p->epoch_graph) return enqueue(st);   // a graph launch cannot be captured: plain nodes into the caller's graph
     qr_ppo::EpochGraph& g = p->eg;
     const bool hit = g.exec && g.theta == theta_dev && g.m == adam_m_dev && g.v == adam_v_dev && g.obs == obs_dev && g.act == act_dev &&
                      g.old_logp == old_logp_dev && g.adv == adv_dev && g.ret == ret_dev && g.perm == perm_dev && g.stats == stats_dev &&

@@ -496,3 +496,62 @@ def test_sb3_infos_under_pause_if_collision_hand_back_the_frozen_observation():
             assert infos[i] == {}
     assert seen > 0
     env.close()
+
+
+def _shuffle_reference(n, seed, count):
+    """NumPy restatement of ppo_shuffle_kernel (csrc/quadrace_ppo.hip): keyed 8-round alternating Feistel network over
+    ceil(log2 n) bits (at least 2), cycle-walked into [0, n); round keys = SplitMix64 finaliser of (seed, count, round)."""
+    M64 = (1 << 64) - 1
+    bits = 2
+    while (1 << bits) < n:
+        bits += 1
+    lb = bits >> 1
+    rb = bits - lb
+    lmask, rmask = np.uint32((1 << lb) - 1), np.uint32((1 << rb) - 1)
+    keys = []
+    for r in range(8):
+        z = (seed + 0x9E3779B97F4A7C15 * ((count * 8 + r + 1) & M64)) & M64
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+        keys.append(np.uint32((z ^ (z >> 31)) & 0xFFFFFFFF))
+
+    def mix(x, k):
+        with np.errstate(over="ignore"):
+            h = x * np.uint32(0x9E3779B1) + k
+            h ^= h >> np.uint32(15); h = h * np.uint32(0x85EBCA77)
+            h ^= h >> np.uint32(13); h = h * np.uint32(0xC2B2AE3D)
+            h ^= h >> np.uint32(16)
+        return h
+
+    x = np.arange(n, dtype=np.uint32)
+    todo = np.ones(n, dtype=bool)
+    first = True
+    while todo.any():
+        xs = x[todo]
+        l, r_ = xs >> np.uint32(rb), xs & rmask
+        for r in range(0, 8, 2):
+            l = l ^ (mix(r_, keys[r]) & lmask)
+            r_ = r_ ^ (mix(l, keys[r + 1]) & rmask)
+        x[todo] = (l << np.uint32(rb)) | r_
+        todo = x >= n if first else (todo & (x >= n))
+        first = False
+        todo = x >= n
+    return x.astype(np.int64)
+
+
+@pytest.mark.parametrize("B,M,seed", [(4096, 8, 1234), (192, 5, 7), (64, 1, 2 ** 40 + 3)])
+def test_device_shuffle_equals_its_numpy_restatement(B, M, seed):
+    """The on-device epoch permutation against an independent NumPy restatement of the same keyed bijection, for a power-of-two
+    row count, one that needs cycle walking, and the smallest minibatch: identical permutations for consecutive epochs."""
+    from test_gpu_ppo_kernel import _setup
+
+    L = 17
+    pol, ref, up, obs, act, old_lp, adv, ret = _setup(L, rows=B * M, seed=3, max_minibatch=B)
+    rows = B * M
+    perm = torch.empty(rows, dtype=torch.int32, device=obs.device)
+    up.set_shuffle(seed, 0)
+    for ep in range(3):
+        up.epoch(obs, act, old_lp, adv, ret, perm, B, 3e-4, device_shuffle=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(perm.cpu().numpy().astype(np.int64), _shuffle_reference(rows, seed, ep))
+    up.close()
