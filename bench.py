@@ -439,6 +439,7 @@ def config5_probe(n, iters=3, mb=16384):
     model.collect(); model.train()   # warm-up iteration (captures the epoch graph)
     model.collect(); model.train()
     torch.cuda.synchronize()
+    applied0, skipped0 = model.stats["updates"], model.stats["skipped_nonfinite"]
     t0 = time.perf_counter()
     tc = 0.0
     for _ in range(iters):
@@ -451,12 +452,16 @@ def config5_probe(n, iters=3, mb=16384):
     dt = time.perf_counter() - t0
     steps = iters * n * n_steps
     updates = iters * 10 * ((n * n_steps) // mb)
+    applied, skipped = model.stats["updates"] - applied0, model.stats["skipped_nonfinite"] - skipped0
     env.close()
+    # "every update taken" is CHECKED, not assumed: the device counts optimiser steps really applied (a non-finite gradient norm
+    # skips one; round 3 found a graph-replay bug that silently skipped whole epochs this way)
+    assert applied == updates and skipped == 0 and not model.stats["early_stop"], (applied, skipped, updates)
     return {"what": "config 5, whole loop (fused collect + GAE + all %d updates per rollout of %d rows each, constant lr, no early stop), "
                     "%d iterations" % (updates // iters, mb, iters),
             "envs": n, "n_steps": n_steps, "minibatch": mb, "epochs": 10, "value": steps / dt, "unit": "env-steps/s",
             "collect_ms_per_rollout": tc / iters * 1e3, "update_ms_per_rollout": (dt - tc) / iters * 1e3,
-            "us_per_update": (dt - tc) / updates * 1e6}
+            "us_per_update": (dt - tc) / updates * 1e6, "updates_applied": applied, "updates_skipped": skipped}
 
 
 def cpu_baseline(variant, n, ga, seconds):

@@ -13,7 +13,9 @@
 //               (ds_read_b64_tr_b16) -- activations h_l and deltas d_l stay in registers in the "lane = sample" form.  Per layer
 //               both are turned into the operand form (lane = unit, k = sample) by multiplying with an identity operand on
 //               the matrix core, exchanged through 64 KB of LDS, and dW_l = d_l^T x h_(l-1) is formed at once: 2 x 2 weight
-//               tiles per wave, k = the workgroup's 128 samples, plain f32 stores to partial[workgroup][param].  Biases ride
+//               tiles per wave, k = the workgroup's 128 samples, plain stores to partial[workgroup][param] -- bf16 by default
+//               (round 3: the partials' trip through the fabric is what bounds a 16 384-row update; QR_PPO_PARTIAL=f32 keeps
+//               f32), widened again and summed in f32 in a fixed order by `apply`.  Biases ride
 //               along as the constant-1 unit of every layer.  No atomics anywhere: log-std gradients and loss statistics
 //               leave as per-wave sums.
 //   apply       ONE kernel: sums the partials and the per-wave sums into the gradient, accumulates its squared norm, crosses a
@@ -71,7 +73,31 @@ struct PpoDims {
     static constexpr int kSlots = kIT + 25;
     static constexpr int kIT2 = (kIT + 1) / 2;
     static constexpr int kBlocksPerNet = 2 * kIT2 + 10;  // 2x2 blocks of 32x32 weight tiles: layer1 2*kIT2, layers 2,3 4 each, layer4 2
+    // Partials of the role-split gradient kernel in ACCUMULATOR ORDER: one 32 x 32 weight tile = 1024 slots
+    // [quad a = r >> 2][lane][k = r & 3] -- what a dW wave holds, written as four 1 KB runs per tile (store_dw_tile_raw);
+    // tiles per net: layer 1 [out tile][in tile], layers 2 and 3 [out tile][in tile] (4 x 4), layer 4 [in tile]
+    static constexpr int kRawT2 = 4 * kIT, kRawT3 = kRawT2 + 16, kRawT4 = kRawT3 + 16, kRawTiles = kRawT4 + 4;
+    static constexpr int kRawSlots = kRawTiles * 1024;   // per net and workgroup (L = 24: 40 tiles = 160 KB of f32)
 };
+
+// slot of one net's accumulator-order partial -> index inside the net's block of the flat parameter vector, or -1 (padding:
+// rows past the layer's outputs, columns past its inputs + bias).  Inverse of the tile order above and of the MFMA accumulator
+// layout (register r of lane (c, h) = dW[32 to + rho(r, h)][32 ti + c]).
+template <int L>
+__device__ __forceinline__ int raw_slot_param(int s, int O) {
+    using D = PpoDims<L>;
+    const NetOff o = net_off(L, O);
+    const int T = s >> 10, a4 = (s >> 8) & 3, ln = (s >> 2) & 63, k = s & 3;
+    const int c = ln & 31, h = ln >> 5;
+    int to, ti, in_dim, out_dim, woff, boff;
+    if (T < D::kRawT2) { to = T / D::kIT; ti = T % D::kIT; in_dim = L; out_dim = kH; woff = o.w1; boff = o.b1; }
+    else if (T < D::kRawT3) { to = (T - D::kRawT2) >> 2; ti = (T - D::kRawT2) & 3; in_dim = kH; out_dim = kH; woff = o.w2; boff = o.b2; }
+    else if (T < D::kRawT4) { to = (T - D::kRawT3) >> 2; ti = (T - D::kRawT3) & 3; in_dim = kH; out_dim = kH; woff = o.w3; boff = o.b3; }
+    else { to = 0; ti = T - D::kRawT4; in_dim = kH; out_dim = O; woff = o.w4; boff = o.b4; }
+    const int row = 32 * to + k + 8 * a4 + 4 * h, col = 32 * ti + c;
+    if (row >= out_dim || col > in_dim) return -1;
+    return col == in_dim ? boff + row : woff + row * in_dim + col;
+}
 
 // ---- pack: f32 parameters -> f16 operand images -----------------------------------------------------------------------
 template <int L>
@@ -261,8 +287,11 @@ struct PpoBatch {
         if ((a).ticks && (threadIdx.x & 63) == 0)                                                               \
             (a).ticks[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6)) * 16 + (slot)] = clock64(); \
     } while (0)
+// constant-rate (100 MHz) device-wide clock: workgroup start / end skew across the grid, and the apply kernel's stages
+#define PPO_WALL(ptr, index) do { if ((ptr) && (threadIdx.x & 63) == 0) (ptr)[index] = wall_clock64(); } while (0)
 #else
 #define PPO_TICK(a, slot) do { } while (0)
+#define PPO_WALL(ptr, index) do { } while (0)
 #endif
 
 // The transposed operands are written once and read once, by phase B: streaming ("nt") stores keep ~54 MB of dirty lines out
@@ -892,8 +921,10 @@ __device__ __forceinline__ void dw_tiles_tr_old_half(unsigned base_d0, unsigned 
 // one 32 x 32 tile of dW (register r of lane (c, h) = dW[row 32 to + rho(r, h)][col 32 ti + c]) into this workgroup's partial;
 // column kInDim is the constant-1 unit = the bias.  `add`: a later pass of the same workgroup (all 16 old values are loaded
 // before the first add).  The row pitch is a compile-time constant, so the 16 rows are one base address + immediates.
-template <int kInDim>
-__device__ __forceinline__ void store_dw_tile(const f32x16p& acc, float* __restrict__ gw, float* __restrict__ gb, int out_dim, int to, int ti,
+// PT = float, or __bf16: the role-split kernel's 16-bit partials (qr_ppo::partial_bf16) -- v_cvt_pk_bf16_f32, round to nearest even,
+// and a 2-byte store per element; the apply kernel widens them again before its fixed-order f32 sum.
+template <int kInDim, typename PT = float>
+__device__ __forceinline__ void store_dw_tile(const f32x16p& acc, PT* __restrict__ gw, PT* __restrict__ gb, int out_dim, int to, int ti,
                                               int lane, float scale, bool add) {
     const int c = lane & 31, h = lane >> 5;
     // Formed HERE: inside the pass loop of ppo_grad_kernel the row addresses are loop invariants, and hoisted out of the loop
@@ -904,7 +935,7 @@ __device__ __forceinline__ void store_dw_tile(const f32x16p& acc, float* __restr
     if (col > kInDim) return;
     const int row0 = 32 * to + 4 * h;
     const bool bias = col == kInDim;
-    float* base = bias ? gb + row0 : gw + row0 * kInDim + col;
+    PT* base = bias ? gb + row0 : gw + row0 * kInDim + col;
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = acc[r] * scale;
@@ -912,22 +943,50 @@ __device__ __forceinline__ void store_dw_tile(const f32x16p& acc, float* __restr
         if (add) {
             float old[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) old[r] = row0 + rho_(r, 0) < out_dim ? base[rho_(r, 0) * kInDim] : 0.0f;
+            for (int r = 0; r < 16; ++r) old[r] = row0 + rho_(r, 0) < out_dim ? (float)base[rho_(r, 0) * kInDim] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] += old[r];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            if (row0 + rho_(r, 0) < out_dim) base[rho_(r, 0) * kInDim] = v[r];
+            if (row0 + rho_(r, 0) < out_dim) base[rho_(r, 0) * kInDim] = (PT)v[r];
     } else {
         if (add) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] += row0 + rho_(r, 0) < out_dim ? base[rho_(r, 0)] : 0.0f;
+            for (int r = 0; r < 16; ++r) v[r] += row0 + rho_(r, 0) < out_dim ? (float)base[rho_(r, 0)] : 0.0f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            if (row0 + rho_(r, 0) < out_dim) base[rho_(r, 0)] = v[r];
+            if (row0 + rho_(r, 0) < out_dim) base[rho_(r, 0)] = (PT)v[r];
     }
+}
+
+// The same tile in ACCUMULATOR ORDER (PpoDims::kRawSlots): quad a of lane l -> tile[(64 a + l) * 4 .. + 3], i.e. each of the four
+// store instructions of a tile writes ONE contiguous, aligned run (512 B as bf16, 1 KB as f32) instead of 64 row segments of 128 B
+// at odd offsets (row pitch 120 / 121 floats).  `rows` = real output rows left in this tile (quads are 4-row aligned: whole or none).
+// The stores are agent-scope (sc1): written THROUGH the XCD's L2 as they are issued, so the partial of a finished layer drains to the
+// fabric while the workgroup still computes the next one -- as plain stores the lines sat dirty in L2 until the end-of-kernel
+// write-back (measured with tools/ppo_launch_timing.py: 6.6 us between the last workgroup's exit and the apply kernel's first
+// instruction; 1.4 us with write-through stores issued per layer).
+template <typename PT>
+__device__ __forceinline__ void store_dw_tile_raw(const f32x16p& acc, PT* __restrict__ tile, int rows, int lane, float scale) {
+    typedef PT pt4 __attribute__((ext_vector_type(4)));
+    int ln = lane;
+    asm volatile("" : "+v"(ln));   // (see store_dw_tile: keeps the address arithmetic next to the stores)
+    const int h4 = 4 * (ln >> 5);
+    pt4* out = reinterpret_cast<pt4*>(tile) + ln;
+#pragma unroll
+    for (int a4 = 0; a4 < 4; ++a4)
+        if (8 * a4 + h4 < rows) {
+            pt4 v;
+            v.x = (PT)(acc[4 * a4] * scale); v.y = (PT)(acc[4 * a4 + 1] * scale);
+            v.z = (PT)(acc[4 * a4 + 2] * scale); v.w = (PT)(acc[4 * a4 + 3] * scale);
+            if constexpr (sizeof(pt4) == 8)
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + 64 * a4), __builtin_bit_cast(unsigned long long, v),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store_dwordx2 ... sc1
+            else
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(out + 64 * a4), "v"(v) : "memory");
+        }
 }
 
 template <int L>
@@ -1213,8 +1272,8 @@ __global__ void __launch_bounds__(256, 1) ppo_grad4_kernel(PpoBatch a, float* __
 // next delta -> barrier -> chain writes ...  Same barrier count per pass as before (8), same arithmetic, same partial layout, same
 // results bit for bit (tests/test_gpu_ppo_kernel.py compares the two kernels); 512 threads, 256 VGPRs per wave.  In a later pass of
 // a large minibatch the chain waves' gather flies while the dW waves finish the previous pass.
-template <int L>
-__global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, float* __restrict__ partial, int num_params) {
+template <int L, typename PT>
+__global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __restrict__ partial, int num_params) {
     using D = PpoDims<L>;
     using P = PolicyDims<L>;
     constexpr int KS1 = P::kSteps1;
@@ -1225,13 +1284,15 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, float* __r
     const int net = blockIdx.y;
     const int stop_flag = *a.stop;
     PPO_TICK(a, 0);
+#ifdef QR_PHASE_TIMING
+    PPO_WALL(a.ticks, (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 16 + 14);
+#endif
     const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int role = wave8 >> 2;          // 0: chain wave, 1: dW wave (wave-uniform: every branch on it is whole-wave)
     const int wave = wave8 & 3;           // chain: the wave's 32-sample tile; dW: its 2 x 2 block of weight tiles
     const int et = wave & 1;
     const int O = net == 0 ? 4 : 1;
-    const NetOff o = net_off(L, O);
-    float* gn = partial + (size_t)blockIdx.x * num_params + (net == 0 ? 0 : net_off(L, 4).total);
+    PT* gn = partial + ((size_t)blockIdx.x * 2 + net) * D::kRawSlots;   // accumulator-order partial of (workgroup, net)
     const float scale = 1.0f / (float)a.B;
     const int pairs = (a.G + 1) / 2;   // passes of 2 sample groups = 128 samples
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -1500,10 +1561,10 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, float* __r
             if (stop_flag) return;
             // The weight-gradient accumulators of ALL four layers live in this wave's registers across the passes of a large
             // minibatch (16 + 64 + 64 + 16 kIT VGPRs): a later pass accumulates on the matrix core instead of reading its partial
-            // back and adding (round 2: a read-modify-write of 126 KB per workgroup and pass), and the partial leaves ONCE.  In the
-            // last pass every layer is stored one stage late, behind the MFMAs of the next layer: the 64 stores per lane of a hidden
-            // layer queue behind the fabric's write bandwidth (all 256 workgroups burst together: ~9 k cycles per layer, measured),
-            // and a wave stuck in store issue must not be the one the chain waves wait for at the next barrier.
+            // back and adding (round 2: a read-modify-write of 126 KB per workgroup and pass), and the partial leaves ONCE, in the
+            // last pass: each layer as soon as it is complete, in accumulator order (16 stores of one contiguous run per lane and
+            // hidden layer -- as 64 row-segment stores per lane they queued for ~9 k cycles per layer and had to be deferred to the
+            // end), written through L2 (store_dw_tile_raw) so that they drain under the remaining layers.
             const bool last = pair + (int)gridDim.x >= pairs;
             const int to0 = 2 * (wave >> 1), ti0 = 2 * (wave & 1);
             __syncthreads();   // [S1]
@@ -1518,7 +1579,13 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, float* __r
             dw_block_tr(ex_lane0 + 2048u * (unsigned)to0, ex_lane1 + 2048u * (unsigned)to0, ex_lane0 + 2048u * (unsigned)ti0, ex_lane1 + 2048u * (unsigned)ti0, dw3);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();   // [S4]
-            if (last) store_dw_tile<kH>(dw4, gn + o.w4, gn + o.b4, O, 0, wave, lane, scale, false);   // 1 tile: cheap
+            if (last) store_dw_tile_raw<PT>(dw4, gn + (D::kRawT4 + wave) * 1024, O, lane, scale);   // 1 tile: cheap
+            if (last) {   // dW3 is complete: its partial drains while dW2 / dW1 are formed
+#pragma unroll
+                for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                    for (int bi = 0; bi < 2; ++bi) store_dw_tile_raw<PT>(dw3[bt][bi], gn + (D::kRawT3 + 4 * (to0 + bt) + ti0 + bi) * 1024, kH - 32 * (to0 + bt), lane, scale);
+            }
             PPO_TICK(a, 9);
             __syncthreads();   // [S5]
             PPO_TICK(a, 10);
@@ -1526,24 +1593,26 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, float* __r
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();   // [S6]
             PPO_TICK(a, 11);
-            __syncthreads();   // [S7] (arrive BEFORE the layer-3 stores: the chain waves are released to their next gather at once)
+            __syncthreads();   // [S7] (arrive BEFORE the layer-2 stores: the chain waves are released to their next gather at once)
             PPO_TICK(a, 12);
+            if (last) {   // likewise dW2 (the chain waves are past their last barrier of this pass)
+#pragma unroll
+                for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                    for (int bi = 0; bi < 2; ++bi) store_dw_tile_raw<PT>(dw2[bt][bi], gn + (D::kRawT2 + 4 * (to0 + bt) + ti0 + bi) * 1024, kH - 32 * (to0 + bt), lane, scale);
+            }
             dw_tiles_tr_old_half<D::kIT, 0>(ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw1);   // tiles (wave, 0..kIT-1)
             dw_tiles_tr_old_half<D::kIT, 4>(ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw1);
             __builtin_amdgcn_sched_barrier(0);
             if (last) {
 #pragma unroll
-                for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-                    for (int bi = 0; bi < 2; ++bi) store_dw_tile<kH>(dw3[bt][bi], gn + o.w3, gn + o.b3, kH, to0 + bt, ti0 + bi, lane, scale, false);
-#pragma unroll
-                for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-                    for (int bi = 0; bi < 2; ++bi) store_dw_tile<kH>(dw2[bt][bi], gn + o.w2, gn + o.b2, kH, to0 + bt, ti0 + bi, lane, scale, false);
-#pragma unroll
-                for (int bi = 0; bi < D::kIT; ++bi) store_dw_tile<L>(dw1[0][bi], gn + o.w1, gn + o.b1, kH, wave, bi, lane, scale, false);
+                for (int bi = 0; bi < D::kIT; ++bi) store_dw_tile_raw<PT>(dw1[0][bi], gn + (D::kIT * wave + bi) * 1024, kH - 32 * wave, lane, scale);
             }
             PPO_TICK(a, 13);
+#ifdef QR_PHASE_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PPO_WALL(a.ticks, (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 16 + 15);
+#endif
             // ([S0] of the next pass separates these reads from the chain waves' next writes)
         }
     }
@@ -1660,7 +1729,10 @@ struct ApplyArgs {
     float *theta, *m, *v;     // parameters and Adam moments (flat, n floats)
     const float* ext_grad;    // data-parallel path: [n + 4] externally averaged gradient + minibatch statistics; else nullptr
     float* grad_out;          // optional [n + 4]: the reduced gradient + minibatch statistics (qr_ppo_grad); else nullptr
-    const float* partial;     // [chunks][n] sample-chunk partials of phase B
+    const float* partial;     // [chunks][n] sample-chunk partials of phase B / of the fused gradient kernel
+    int partial_bf16;         // 1: the partials are __bf16 (same indexing, half the bytes)
+    int partial_raw;          // > 0: accumulator-order partials of ppo_grad_kernel, [chunks][partial_raw] with partial_raw = 2 x
+                              // PpoDims::kRawSlots; thread j of the launch owns slot j (raw_slot_param names its parameter)
     int chunks, n;
     const float* wave_out;    // per-wave sums of phase A, Gw = waves per net
     int Gw;
@@ -1673,6 +1745,9 @@ struct ApplyArgs {
     int take_step;            // 0: reduce only (qr_ppo_grad)
     int device_step;          // 1: bias corrections from PpoCtrl::adam_t + 1 (computed here) instead of bc1 / bc2_sqrt
     int device_lr;            // 1: learning rate = PpoCtrl::lr
+#ifdef QR_PHASE_TIMING
+    unsigned long long* aticks;   // [workgroups][8] wall-clock stamps (profiling build only)
+#endif
 };
 
 // gradient element i and, in the block(s) that own the log_std entries, the per-wave sums of phase A:
@@ -1680,7 +1755,8 @@ struct ApplyArgs {
 constexpr int kApplyThreads = 256;   // 247 workgroups: the 8 MB of chunk partials are pulled by (almost) every CU
                                      // (62 x 1024 threads took 13.5 us for this kernel, bound by 62 CUs' load issue)
 
-__device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, float* red /* shared [8] */) {
+// i = the thread's parameter (n: none), pj = its column in the partial table (natural order: i; accumulator order: the slot)
+__device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, int pj, float* red /* shared [8] */) {
     const int n = a.n;
     if (a.ext_grad) {
         if (blockIdx.x == gridDim.x - 1 && threadIdx.x < 4) red[4 + threadIdx.x] = a.ext_grad[n + threadIdx.x];
@@ -1691,7 +1767,7 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
     // issued up front, together with the chunk partials below: one memory round trip for the whole prologue (a wave that walked
     // its 512 rows in a loop paid eight of them, and the grid barrier waits for exactly these blocks).
     //   policy waves (net 0): slots 0..3 d log_std / B, 4 surrogate, 5 approx kl, 6 clipped;  value waves (net 1): slot 4 squared error
-    const bool owner = ((int)blockIdx.x + 1) * kApplyThreads > n - 4;
+    const bool owner = a.partial_raw > 0 && !a.ext_grad ? blockIdx.x == gridDim.x - 1 : ((int)blockIdx.x + 1) * kApplyThreads > n - 4;
     constexpr int kRowsPerThread = 4;   // up to 1024 waves per net (a 32 768-row minibatch); larger ones take the loop below
     float4 lo[kRowsPerThread], hi[kRowsPerThread];
     float vs[kRowsPerThread];
@@ -1712,8 +1788,15 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
     constexpr int kMaxChunks = 128;
     float gs[kMaxChunks];
     if (i < n - 4) {  // weights and biases: the partials of the gradient kernel (one per workgroup / sample chunk)
+        const size_t pitch = a.partial_raw > 0 ? (size_t)a.partial_raw : (size_t)n;
+        if (a.partial_bf16) {
+            const __bf16* pb = reinterpret_cast<const __bf16*>(a.partial);
 #pragma unroll
-        for (int q = 0; q < kMaxChunks; ++q) gs[q] = a.partial[(size_t)(q < a.chunks ? q : 0) * n + i];  // unconditional loads
+            for (int q = 0; q < kMaxChunks; ++q) gs[q] = (float)pb[(size_t)(q < a.chunks ? q : 0) * pitch + pj];
+        } else {
+#pragma unroll
+            for (int q = 0; q < kMaxChunks; ++q) gs[q] = a.partial[(size_t)(q < a.chunks ? q : 0) * pitch + pj];  // unconditional loads
+        }
     }
     if (owner) {
         float t[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -1804,21 +1887,37 @@ __device__ __forceinline__ void pack_scatter(_Float16* __restrict__ img, int O, 
 }
 
 template <int L>
-__global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
+__global__ void __launch_bounds__(kApplyThreads, 2) ppo_apply_kernel(ApplyArgs a) {   // <= 256 VGPRs: two workgroups per CU are resident
     PpoCtrl* c = a.ctrl;
     const int stop_flag = c->stop;       // set by an EARLIER launch: uniform over the grid; tested after the reduction below
     const unsigned int gen = c->gen;
     const int adam_t = c->adam_t;        // like `gen`: read by everybody before anybody arrives at the barrier, bumped by the master after it
     const float lr_dev = c->lr;
     const int n = a.n;
-    const int i = blockIdx.x * kApplyThreads + threadIdx.x;
+#ifdef QR_PHASE_TIMING
+    PPO_WALL(a.aticks, (size_t)blockIdx.x * 8 + 0);
+#endif
+    const int j = blockIdx.x * kApplyThreads + threadIdx.x;
+    // the thread's parameter: natural order -> j itself; accumulator-order partials -> whatever slot j holds (padding slots and the
+    // tail of the last workgroup own nothing: i = n), the four log_std entries ride behind the two nets' slots
+    int i = j;
+    if (a.partial_raw > 0 && !a.ext_grad) {
+        constexpr int S = PpoDims<L>::kRawSlots;
+        const int n4 = net_off(L, 4).total;
+        if (j < S) { const int p = raw_slot_param<L>(j, 4); i = p < 0 ? n : p; }
+        else if (j < 2 * S) { const int p = raw_slot_param<L>(j - S, 1); i = p < 0 ? n : n4 + p; }
+        else i = j - 2 * S < 4 ? n - 4 + (j - 2 * S) : n;
+    }
     const bool last_block = blockIdx.x == gridDim.x - 1;
     __shared__ float red[8];
     // Adam state and parameter of this element: loaded NOW, together with the chunk partials, so that their round trip is over
     // before the grid barrier releases (they do not depend on the norm): measured -0.15 us
     const bool owns = a.take_step && i < n;
     const float m_in = owns ? a.m[i] : 0.0f, v_in = owns ? a.v[i] : 0.0f, th_in = owns ? a.theta[i] : 0.0f;
-    const float g = reduce_grad_element(a, i, red);
+    const float g = reduce_grad_element(a, i, j, red);
+#ifdef QR_PHASE_TIMING
+    PPO_WALL(a.aticks, (size_t)blockIdx.x * 8 + 1);
+#endif
     if (a.grad_out) {
         if (i < n) a.grad_out[i] = g;
         if (last_block && threadIdx.x < 4) a.grad_out[n + threadIdx.x] = red[4 + threadIdx.x];
@@ -1836,6 +1935,9 @@ __global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
     // the workgroups still summing partials); nothing but the polled word itself is consumed, so no fence is needed.  Bounded.
     double sq = (double)g * g, unused = 0.0;
     block_sum2_f64<kApplyThreads>(sq, unused);
+#ifdef QR_PHASE_TIMING
+    PPO_WALL(a.aticks, (size_t)blockIdx.x * 8 + 2);
+#endif
     const unsigned int want = (gen + 1u) & kGoGenMask;
     if (threadIdx.x == 0) {
         const unsigned long long word = ((unsigned long long)want << 32) | (unsigned long long)__float_as_uint((float)sq);
@@ -1884,6 +1986,9 @@ __global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
         go_s = w;
     }
     __syncthreads();
+#ifdef QR_PHASE_TIMING
+    PPO_WALL(a.aticks, (size_t)blockIdx.x * 8 + 3);
+#endif
     const unsigned long long gw = go_s;
     const float norm_sq = __uint_as_float((unsigned int)gw);
     const bool stop_now = ((unsigned int)(gw >> 32) & kGoStop) != 0u;
@@ -1915,6 +2020,10 @@ __global__ void __launch_bounds__(kApplyThreads) ppo_apply_kernel(ApplyArgs a) {
         else if (finite) { c->applied += 1; c->adam_t = adam_t + 1; }
         else c->skipped_nonfinite += 1;
     }
+#ifdef QR_PHASE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PPO_WALL(a.aticks, (size_t)blockIdx.x * 8 + 4);
+#endif
 }
 
 // ---- GAE(lambda) and episode statistics over a rollout buffer [T][N] (what SB3's RolloutBuffer.compute_returns_and_advantage
@@ -1969,10 +2078,11 @@ __global__ void __launch_bounds__(256) ppo_gae_kernel(int T, int N, const float*
 // ------------------------------------------------------------------------------------------------------------------------
 struct qr_ppo {
     int L = 0, device = 0, max_B = 0, num_params = 0;
-    int image_half8 = 0, slots = 0, max_chunks = 32;  // chunks = split of the minibatch's sample groups in phase B
+    int image_half8 = 0, slots = 0, raw_slots = 0, max_chunks = 32;  // chunks = split of the minibatch's sample groups in phase B
     static constexpr int kFusedChunks = 128;          // workgroups (= partials) per network of the fused gradient kernel
     bool fused = true;                                // QR_PPO_SPLIT=1: the two-kernel form (phase A + phase B through scratch)
     bool grad4 = false;                               // QR_PPO_GRAD4=1: fused gradient kernel in its 4-wave form (round 2)
+    bool partial_bf16 = true;                         // QR_PPO_PARTIAL=f32: the role-split kernel's partials as f32 (twice the bytes)
     bool epoch_graph = true;                          // QR_PPO_EPOCH_GRAPH=0: qr_ppo_epoch enqueues its launches on the stream
     qr::half8* d_images = nullptr;
     qr::half8* d_tbuf = nullptr;
@@ -1980,6 +2090,7 @@ struct qr_ppo {
     float* d_wave = nullptr;     // [2][2 x max groups][8] per-wave sums of phase A
 #ifdef QR_PHASE_TIMING
     unsigned long long* ticks = nullptr;
+    unsigned long long* apply_ticks = nullptr;
 #endif
     qr::PpoCtrl* d_ctrl = nullptr;
     // advantage sums per minibatch: entries 0..kMaxEpochMinibatches-1 are filled for a whole epoch by qr_ppo_epoch_begin,
@@ -2053,14 +2164,16 @@ struct PpoOps {
     // dynamic-LDS limits of the gradient kernels on the CURRENT device (idempotent; not a stream operation, so it also runs
     // before a graph capture instead of inside it)
     static int configure(qr_ppo* p) {
-        static unsigned long long configured_a = 0, configured_a8 = 0, configured_f = 0, configured_f4 = 0;   // per device ordinal
+        static unsigned long long configured_a = 0, configured_a8 = 0, configured_f = 0, configured_fb = 0, configured_f4 = 0;   // per device ordinal
         if (!p->fused) {
             PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 256>), kLdsSplit, configured_a));
             PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 512>), kLdsSplit, configured_a8));
         } else if (p->grad4) {
             PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad4_kernel<L>), kLdsFused, configured_f4));
+        } else if (p->partial_bf16) {
+            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad_kernel<L, __bf16>), kLdsFused, configured_fb));
         } else {
-            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad_kernel<L>), kLdsFused, configured_f));
+            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad_kernel<L, float>), kLdsFused, configured_f));
         }
         return QR_OK;
     }
@@ -2074,8 +2187,11 @@ struct PpoOps {
             const int wgs = pairs < qr_ppo::kFusedChunks ? pairs : qr_ppo::kFusedChunks;
             if (p->grad4)   // QR_PPO_GRAD4=1: the 4-wave form (one dependent chain per wave), kept for comparison
                 hipLaunchKernelGGL((qr::ppo_grad4_kernel<L>), dim3(wgs, 2), dim3(256), lds_f, st, b, p->d_partial, p->num_params);
+            else if (p->partial_bf16)
+                hipLaunchKernelGGL((qr::ppo_grad_kernel<L, __bf16>), dim3(wgs, 2), dim3(512), lds_f, st, b,
+                                   reinterpret_cast<__bf16*>(p->d_partial), p->num_params);
             else
-                hipLaunchKernelGGL((qr::ppo_grad_kernel<L>), dim3(wgs, 2), dim3(512), lds_f, st, b, p->d_partial, p->num_params);
+                hipLaunchKernelGGL((qr::ppo_grad_kernel<L, float>), dim3(wgs, 2), dim3(512), lds_f, st, b, p->d_partial, p->num_params);
             PPO_HIP(hipGetLastError());
             *chunks_out = wgs;
             return QR_OK;
@@ -2102,8 +2218,18 @@ struct PpoOps {
         a.images = p->d_images;
         a.n = p->num_params;
         a.partial = p->d_partial;
+        // the role-split gradient kernel leaves its partials in accumulator order: one thread per slot (+ one workgroup for log_std)
+        const bool raw = p->fused && !p->grad4 && !a.ext_grad;
+        a.partial_bf16 = (raw && p->partial_bf16) ? 1 : 0;
+        a.partial_raw = raw ? 2 * D::kRawSlots : 0;
         a.wave_out = p->d_wave;
-        hipLaunchKernelGGL(qr::ppo_apply_kernel<L>, dim3((p->num_params + qr::kApplyThreads - 1) / qr::kApplyThreads),
+#ifdef QR_PHASE_TIMING
+        a.aticks = p->apply_ticks;
+#endif
+        const int threads = raw ? 2 * D::kRawSlots + qr::kApplyThreads : p->num_params;
+        static_assert((2 * D::kRawSlots) % qr::kApplyThreads == 0 && 2 * D::kRawSlots / qr::kApplyThreads + 1 <= 512,
+                      "grid barrier: arrive[512], two resident workgroups per CU");
+        hipLaunchKernelGGL(qr::ppo_apply_kernel<L>, dim3((threads + qr::kApplyThreads - 1) / qr::kApplyThreads),
                            dim3(qr::kApplyThreads), 0, st, a);
         PPO_HIP(hipGetLastError());
         return QR_OK;
@@ -2179,6 +2305,7 @@ int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo
         using D = qr::PpoDims<decltype(Lc)::value>;
         p->image_half8 = D::kImage;
         p->slots = D::kSlots;
+        p->raw_slots = 2 * D::kRawSlots;
         return (int)QR_OK;
     });
     if (rc != QR_OK) { delete p; return rc; }
@@ -2188,6 +2315,8 @@ int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo
         p->fused = !(split && split[0] == '1');
         const char* g4 = getenv("QR_PPO_GRAD4");
         p->grad4 = g4 && g4[0] == '1';
+        const char* pf = getenv("QR_PPO_PARTIAL");
+        p->partial_bf16 = !(pf && pf[0] == 'f');
         const char* eg = getenv("QR_PPO_EPOCH_GRAPH");
         p->epoch_graph = !(eg && eg[0] == '0');
     }
@@ -2196,7 +2325,7 @@ int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo
     const size_t mbbytes = (size_t)(qr_ppo::kMaxEpochMinibatches + 1) * 2 * sizeof(double);
     hipError_t e = hipMalloc((void**)&p->d_images, (size_t)2 * p->image_half8 * 16);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_tbuf, tbytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_partial, (size_t)qr_ppo::kFusedChunks * p->num_params * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_partial, (size_t)qr_ppo::kFusedChunks * (p->raw_slots > p->num_params ? p->raw_slots : p->num_params) * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_wave, (size_t)2 * 2 * (max_minibatch / 64) * 8 * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_ctrl, sizeof(qr::PpoCtrl));
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_mbstats, mbbytes);
@@ -2228,6 +2357,7 @@ int qr_ppo_destroy(qr_ppo* p) {
 
 #ifdef QR_PHASE_TIMING
 __attribute__((visibility("default"))) int qr_ppo_debug_set_ticks(qr_ppo* p, unsigned long long* ticks_dev) { p->ticks = ticks_dev; return QR_OK; }
+__attribute__((visibility("default"))) int qr_ppo_debug_set_apply_ticks(qr_ppo* p, unsigned long long* ticks_dev) { p->apply_ticks = ticks_dev; return QR_OK; }
 #endif
 
 int qr_ppo_num_params(const qr_ppo* p) { return p ? p->num_params : ppofail(QR_E_INVALID, "qr_ppo_num_params: null handle"); }

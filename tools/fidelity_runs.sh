@@ -7,7 +7,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out/fid
 summ() { python -c "
 import json,sys
-j=json.loads(sys.stdin.read()); print('$1 seed', j['seed'], j['evaluated'][:5], 'train_s %.1f' % j['train_seconds'], 'flying lap %.3f' % j['eval_flying_lap_seconds'], 'first %.2f' % j['eval_lap_seconds']['lap1'], 'gates12 %.2f crashes %.3f' % (j['eval_gates_per_12s'], j['eval_crashes_per_12s']))"; }
+j=json.loads(sys.stdin.read()); print('$1 seed', j['seed'], j['evaluated'][:5], 'train_s %.1f' % j['train_seconds'], 'flying lap %.3f' % j['eval_flying_lap_seconds'], 'first %.2f' % j['eval_lap_seconds']['lap1'], 'gates12 %.2f crashes %.3f' % (j['eval_gates_per_12s'], j['eval_crashes_per_12s']), 'updates', j['updates'], 'skipped', j['skipped_nonfinite'])"; }
 # run_geo ENVS NSTEPS SEED [train_ppo.py flags...]  -> gpurun_out/fid/r03_ppo_e2e_<tag>_seed<SEED>.json (TAG env var names the series)
 run_geo() {
   envs=$1; ns=$2; seed=$3; shift 3

@@ -114,6 +114,9 @@ res = dict(evaluated="final policy" if a.eval_final else "best checkpoint by tra
            eval_seconds_per_lap_4gates=float(4 * 1200 * dt / gates12.mean().clamp(min=1e-9)),
            eval_lap_seconds={f"lap{i}": laps[i] for i in range(1, 7)}, eval_laps_counted=lap_cnt[1:].tolist(),
            eval_flying_lap_seconds=float(lap_sum[2:].sum() / lap_cnt[2:].sum().clamp(min=1)), **model.stats)
+sk, up_n = res.get("skipped_nonfinite", 0), res.get("updates", 0)
+if sk > 0.002 * max(1, sk + up_n):   # a handful of skips = diverged sims in a minibatch; more means something is wrong
+    print(f"WARNING: {sk} of {sk + up_n} minibatch updates were skipped for a non-finite gradient norm", file=sys.stderr, flush=True)
 print(json.dumps(res))
 if a.out:
     json.dump(res, open(a.out, "w"), indent=1)
