@@ -227,9 +227,12 @@ int qr_ppo_grad(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const
  * early stop or a non-finite gradient norm do not count, like torch.optim.Adam under SB3) -- see qr_ppo_adam_step.  lr >= 0.
  * Two launches:
  * ONE gradient kernel (forward, loss, backward and the weight gradients of 128 samples per workgroup and pass; per-workgroup
- * f32 partials) and ONE kernel that reduces the partials, takes the global norm across a grid-wide barrier, clips, applies
- * Adam and re-packs the f16 operand images.  (Environment QR_PPO_SPLIT=1 at qr_ppo_create: the earlier three-launch form,
- * forward/backward and weight gradients as two kernels with the operands passed through an HBM scratch buffer.)  A non-finite gradient norm makes
+ * partial sums, rounded to bf16 when they leave the workgroup) and ONE kernel that sums the partials in f32 in a fixed order, takes
+ * the global norm across a grid-wide barrier, clips, applies Adam and re-packs the f16 operand images.  Environment, read at
+ * qr_ppo_create: QR_PPO_PARTIAL=f32 keeps the partials in f32 (twice the bytes through the fabric; the form the kernels are
+ * verified in to f32 summation noise); QR_PPO_SPLIT=1 / QR_PPO_GRAD4=1 select the earlier forms of the gradient kernel (three
+ * launches with the operands passed through an HBM scratch buffer / the 4-wave fused kernel); QR_PPO_EPOCH_GRAPH=0 makes
+ * qr_ppo_epoch enqueue plain launches instead of replaying a captured graph.  A non-finite gradient norm makes
  * the whole update a no-op (counted, see qr_ppo_status).  stats_dev (may be NULL) float[4] is accumulated into. */
 int qr_ppo_minibatch(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* adam_v_dev, const float* obs_dev,
                      const float* act_dev, const float* old_logp_dev, const float* adv_dev, const float* ret_dev,

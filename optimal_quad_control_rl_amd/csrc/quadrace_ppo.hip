@@ -80,24 +80,54 @@ struct PpoDims {
     static constexpr int kRawSlots = kRawTiles * 1024;   // per net and workgroup (L = 24: 40 tiles = 160 KB of f32)
 };
 
-// slot of one net's accumulator-order partial -> index inside the net's block of the flat parameter vector, or -1 (padding:
-// rows past the layer's outputs, columns past its inputs + bias).  Inverse of the tile order above and of the MFMA accumulator
-// layout (register r of lane (c, h) = dW[32 to + rho(r, h)][32 ti + c]).
+// The apply kernel's threads enumerate the REAL slots of one net's accumulator-order partial densely, in storage order: layer by
+// layer, tile by tile, and inside a tile [row quad (a, h)][column c][k] over the tile's real rows and columns only (a layer's 120
+// output rows end in the fourth tile row after 6 of its 8 quads, its in_dim + 1 columns somewhere in the last tile column) -- so a
+// wave's 64 threads read (nearly) one contiguous run per chunk, and no thread is spent on padding: kDenseThreads = the net's
+// parameter count (value net: + 363, the three unused rows of the output layer's stored quad).
+// t -> slot in the partial and index inside the net's block of the flat parameter vector (-1: the unused rows just mentioned).
 template <int L>
-__device__ __forceinline__ int raw_slot_param(int s, int O) {
+struct DenseMap {
     using D = PpoDims<L>;
-    const NetOff o = net_off(L, O);
-    const int T = s >> 10, a4 = (s >> 8) & 3, ln = (s >> 2) & 63, k = s & 3;
-    const int c = ln & 31, h = ln >> 5;
-    int to, ti, in_dim, out_dim, woff, boff;
-    if (T < D::kRawT2) { to = T / D::kIT; ti = T % D::kIT; in_dim = L; out_dim = kH; woff = o.w1; boff = o.b1; }
-    else if (T < D::kRawT3) { to = (T - D::kRawT2) >> 2; ti = (T - D::kRawT2) & 3; in_dim = kH; out_dim = kH; woff = o.w2; boff = o.b2; }
-    else if (T < D::kRawT4) { to = (T - D::kRawT3) >> 2; ti = (T - D::kRawT3) & 3; in_dim = kH; out_dim = kH; woff = o.w3; boff = o.b3; }
-    else { to = 0; ti = T - D::kRawT4; in_dim = kH; out_dim = O; woff = o.w4; boff = o.b4; }
-    const int row = 32 * to + k + 8 * a4 + 4 * h, col = 32 * ti + c;
-    if (row >= out_dim || col > in_dim) return -1;
-    return col == in_dim ? boff + row : woff + row * in_dim + col;
-}
+    static constexpr int W1 = L + 1, WH = kH + 1;
+    static constexpr int kN1 = kH * W1, kNH = kH * WH, kN4 = 4 * WH;
+    static constexpr int kDenseThreads = kN1 + 2 * kNH + kN4;
+    // one layer: W = in_dim + 1 columns in NTI tile columns, row blocks of 8 quads (the last: QL)
+    template <int W, int NTI, bool kOutputLayer>
+    static __device__ __forceinline__ void decode(int u, int& to, int& ti, int& a4, int& h, int& c, int& k) {
+        constexpr int VL = W - 32 * (NTI - 1);   // real columns of the last tile column
+        int quads = 1;
+        to = 0;
+        if constexpr (!kOutputLayer) {
+            constexpr int full = 8 * W * 4;      // dense threads of a full row block (32 rows)
+            to = u / full;
+            to = to > 3 ? 3 : to;
+            u -= to * full;
+            quads = to < 3 ? 8 : 6;              // 120 = 3 x 32 + 24
+        }
+        const int tsz = quads * 128;             // a full-width tile of this row block
+        ti = u / tsz;
+        ti = ti > NTI - 1 ? NTI - 1 : ti;
+        u -= ti * tsz;
+        k = u & 3;
+        const int cc = u >> 2;
+        const int ah = ti == NTI - 1 ? cc / VL : cc >> 5;
+        c = cc - ah * (ti == NTI - 1 ? VL : 32);
+        a4 = ah >> 1;
+        h = ah & 1;
+    }
+    static __device__ __forceinline__ void map(int t, int O, int& slot, int& param) {
+        const NetOff o = net_off(L, O);
+        int to, ti, a4, h, c, k, T, in_dim, out_dim, woff, boff;
+        if (t < kN1) { decode<W1, D::kIT, false>(t, to, ti, a4, h, c, k); T = to * D::kIT + ti; in_dim = L; out_dim = kH; woff = o.w1; boff = o.b1; }
+        else if (t < kN1 + kNH) { decode<WH, 4, false>(t - kN1, to, ti, a4, h, c, k); T = D::kRawT2 + 4 * to + ti; in_dim = kH; out_dim = kH; woff = o.w2; boff = o.b2; }
+        else if (t < kN1 + 2 * kNH) { decode<WH, 4, false>(t - kN1 - kNH, to, ti, a4, h, c, k); T = D::kRawT3 + 4 * to + ti; in_dim = kH; out_dim = kH; woff = o.w3; boff = o.b3; }
+        else { decode<WH, 4, true>(t - kN1 - 2 * kNH, to, ti, a4, h, c, k); T = D::kRawT4 + ti; in_dim = kH; out_dim = O; woff = o.w4; boff = o.b4; }
+        slot = ((T * 4 + a4) * 64 + 32 * h + c) * 4 + k;
+        const int row = 32 * to + k + 8 * a4 + 4 * h, col = 32 * ti + c;
+        param = row < out_dim ? (col == in_dim ? boff + row : woff + row * in_dim + col) : -1;
+    }
+};
 
 // ---- pack: f32 parameters -> f16 operand images -----------------------------------------------------------------------
 template <int L>
@@ -1732,7 +1762,8 @@ struct ApplyArgs {
     const float* partial;     // [chunks][n] sample-chunk partials of phase B / of the fused gradient kernel
     int partial_bf16;         // 1: the partials are __bf16 (same indexing, half the bytes)
     int partial_raw;          // > 0: accumulator-order partials of ppo_grad_kernel, [chunks][partial_raw] with partial_raw = 2 x
-                              // PpoDims::kRawSlots; thread j of the launch owns slot j (raw_slot_param names its parameter)
+                              // PpoDims::kRawSlots; thread -> (slot, parameter) by DenseMap
+    int owner_from;           // first thread index of the log_std entries (the workgroups from there on also sum the per-wave sums)
     int chunks, n;
     const float* wave_out;    // per-wave sums of phase A, Gw = waves per net
     int Gw;
@@ -1755,8 +1786,9 @@ struct ApplyArgs {
 constexpr int kApplyThreads = 256;   // 247 workgroups: the 8 MB of chunk partials are pulled by (almost) every CU
                                      // (62 x 1024 threads took 13.5 us for this kernel, bound by 62 CUs' load issue)
 
-// i = the thread's parameter (n: none), pj = its column in the partial table (natural order: i; accumulator order: the slot)
-__device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, int pj, float* red /* shared [8] */) {
+// i = the thread's parameter (n: none), pj = its column in the partial table (natural order: i; accumulator order: the slot),
+// pair = accumulator-order launch and this thread is one of the slot threads (see the pair scheme below)
+__device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, int pj, bool pair, float* red /* shared [8] */) {
     const int n = a.n;
     if (a.ext_grad) {
         if (blockIdx.x == gridDim.x - 1 && threadIdx.x < 4) red[4 + threadIdx.x] = a.ext_grad[n + threadIdx.x];
@@ -1767,7 +1799,8 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
     // issued up front, together with the chunk partials below: one memory round trip for the whole prologue (a wave that walked
     // its 512 rows in a loop paid eight of them, and the grid barrier waits for exactly these blocks).
     //   policy waves (net 0): slots 0..3 d log_std / B, 4 surrogate, 5 approx kl, 6 clipped;  value waves (net 1): slot 4 squared error
-    const bool owner = a.partial_raw > 0 && !a.ext_grad ? blockIdx.x == gridDim.x - 1 : ((int)blockIdx.x + 1) * kApplyThreads > n - 4;
+    // (accumulator-order launch: a.owner_from = 2 x DenseMap::kDenseThreads, the first log_std thread; else n - 4)
+    const bool owner = ((int)blockIdx.x + 1) * kApplyThreads > a.owner_from;
     constexpr int kRowsPerThread = 4;   // up to 1024 waves per net (a 32 768-row minibatch); larger ones take the loop below
     float4 lo[kRowsPerThread], hi[kRowsPerThread];
     float vs[kRowsPerThread];
@@ -1787,16 +1820,36 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
     // previous kernel had just written (32 MB per minibatch: this read is most of the kernel's time).
     constexpr int kMaxChunks = 128;
     float gs[kMaxChunks];
-    if (i < n - 4) {  // weights and biases: the partials of the gradient kernel (one per workgroup / sample chunk)
-        const size_t pitch = a.partial_raw > 0 ? (size_t)a.partial_raw : (size_t)n;
+    // Accumulator-order partials: the threads of slots (k, k + 1) of one lane's quad -- neighbours t, t ^ 1 -- share the work the other
+    // way round: BOTH read the pair of slots (one dword of two bf16, or a dwordx2), thread t & 1 = 0 for chunks 0..63 and thread
+    // t & 1 = 1 for chunks 64..127.  64 loads per thread is what a wave can have in flight (vmcnt), so the whole table (16 MB) is
+    // requested in ONE round trip; 128 two-byte loads per thread went out in two rounds (measured: 5.4 -> 3 us for this phase).
+    // Each thread sums its 64 chunks of both slots (fixed tree), then the two exchange the half they do not own.
+    if (pair) {
+        const size_t pitch = (size_t)a.partial_raw;
+        const int qh = pj & 1, pb2 = pj & ~1;
         if (a.partial_bf16) {
-            const __bf16* pb = reinterpret_cast<const __bf16*>(a.partial);
+            const unsigned int* pw = reinterpret_cast<const unsigned int*>(a.partial);   // two bf16 per dword
 #pragma unroll
-            for (int q = 0; q < kMaxChunks; ++q) gs[q] = (float)pb[(size_t)(q < a.chunks ? q : 0) * pitch + pj];
+            for (int q = 0; q < kMaxChunks / 2; ++q) {
+                const int qq = 64 * qh + q;
+                const unsigned int w = pw[((size_t)(qq < a.chunks ? qq : 0) * pitch + pb2) >> 1];
+                gs[q] = __uint_as_float(w << 16);
+                gs[q + 64] = __uint_as_float(w & 0xFFFF0000u);
+            }
         } else {
 #pragma unroll
-            for (int q = 0; q < kMaxChunks; ++q) gs[q] = a.partial[(size_t)(q < a.chunks ? q : 0) * pitch + pj];  // unconditional loads
+            for (int q = 0; q < kMaxChunks / 2; ++q) {
+                const int qq = 64 * qh + q;
+                const float2 w = *reinterpret_cast<const float2*>(a.partial + (size_t)(qq < a.chunks ? qq : 0) * pitch + pb2);
+                gs[q] = w.x;
+                gs[q + 64] = w.y;
+            }
         }
+    } else if (i < n - 4) {  // natural order (split / 4-wave forms): the partials of one parameter, one per sample chunk
+        const size_t pitch = (size_t)n;
+#pragma unroll
+        for (int q = 0; q < kMaxChunks; ++q) gs[q] = a.partial[(size_t)(q < a.chunks ? q : 0) * pitch + pj];  // unconditional loads
     }
     if (owner) {
         float t[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -1829,7 +1882,25 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
         }
         __syncthreads();
     }
-    if (i < n - 4) {
+    if (pair) {
+        // gs[0..63] = slot k even, gs[64..127] = slot k + 1, this thread's 64 chunks each: two fixed-shape trees (chunks past the
+        // count hold zeros), then lower half + upper half -- the order depends on nothing but the chunk index: bitwise reproducible
+        const int qh = pj & 1;
+#pragma unroll
+        for (int q = 0; q < kMaxChunks / 2; ++q) {
+            const bool on = 64 * qh + q < a.chunks;
+            gs[q] = on ? gs[q] : 0.0f;
+            gs[q + 64] = on ? gs[q + 64] : 0.0f;
+        }
+#pragma unroll
+        for (int w = kMaxChunks / 4; w >= 1; w >>= 1)
+#pragma unroll
+            for (int q = 0; q < w; ++q) { gs[q] += gs[q + w]; gs[64 + q] += gs[64 + q + w]; }
+        const float send = qh == 0 ? gs[64] : gs[0];          // the half sum of the slot the neighbour owns
+        const float recv = __shfl_xor(send, 1);
+        g = qh == 0 ? gs[0] + recv : recv + gs[64];           // chunks 0..63 + chunks 64..127
+        if (i >= n - 4) g = 0.0f;                             // (the unused rows of the value net's output quad)
+    } else if (i < n - 4) {
         // fixed-shape tree over the 128 slots (slots past the chunk count hold zeros): the summation order depends on nothing but
         // the chunk index -> bitwise reproducible
 #pragma unroll
@@ -1898,15 +1969,21 @@ __global__ void __launch_bounds__(kApplyThreads, 2) ppo_apply_kernel(ApplyArgs a
     PPO_WALL(a.aticks, (size_t)blockIdx.x * 8 + 0);
 #endif
     const int j = blockIdx.x * kApplyThreads + threadIdx.x;
-    // the thread's parameter: natural order -> j itself; accumulator-order partials -> whatever slot j holds (padding slots and the
-    // tail of the last workgroup own nothing: i = n), the four log_std entries ride behind the two nets' slots
+    // the thread's parameter: natural order -> j itself; accumulator-order partials -> DenseMap (the unused rows of the value net's
+    // output quad and the tail of the last workgroup own nothing: i = n), the four log_std entries ride behind the two nets
     int i = j;
+    int pj = j;
+    bool slot_thread = false;
     if (a.partial_raw > 0 && !a.ext_grad) {
-        constexpr int S = PpoDims<L>::kRawSlots;
+        using M = DenseMap<L>;
+        constexpr int S = PpoDims<L>::kRawSlots, T = M::kDenseThreads;
         const int n4 = net_off(L, 4).total;
-        if (j < S) { const int p = raw_slot_param<L>(j, 4); i = p < 0 ? n : p; }
-        else if (j < 2 * S) { const int p = raw_slot_param<L>(j - S, 1); i = p < 0 ? n : n4 + p; }
-        else i = j - 2 * S < 4 ? n - 4 + (j - 2 * S) : n;
+        int p = -1;
+        pj = 0;
+        if (j < T) { M::map(j, 4, pj, p); i = p < 0 ? n : p; }
+        else if (j < 2 * T) { M::map(j - T, 1, pj, p); pj += S; i = p < 0 ? n : n4 + p; }
+        else i = j - 2 * T < 4 ? n - 4 + (j - 2 * T) : n;
+        slot_thread = j < 2 * T;
     }
     const bool last_block = blockIdx.x == gridDim.x - 1;
     __shared__ float red[8];
@@ -1914,7 +1991,7 @@ __global__ void __launch_bounds__(kApplyThreads, 2) ppo_apply_kernel(ApplyArgs a
     // before the grid barrier releases (they do not depend on the norm): measured -0.15 us
     const bool owns = a.take_step && i < n;
     const float m_in = owns ? a.m[i] : 0.0f, v_in = owns ? a.v[i] : 0.0f, th_in = owns ? a.theta[i] : 0.0f;
-    const float g = reduce_grad_element(a, i, j, red);
+    const float g = reduce_grad_element(a, i, pj, slot_thread, red);
 #ifdef QR_PHASE_TIMING
     PPO_WALL(a.aticks, (size_t)blockIdx.x * 8 + 1);
 #endif
@@ -2226,8 +2303,9 @@ struct PpoOps {
 #ifdef QR_PHASE_TIMING
         a.aticks = p->apply_ticks;
 #endif
-        const int threads = raw ? 2 * D::kRawSlots + qr::kApplyThreads : p->num_params;
-        static_assert((2 * D::kRawSlots) % qr::kApplyThreads == 0 && 2 * D::kRawSlots / qr::kApplyThreads + 1 <= 512,
+        const int threads = raw ? 2 * qr::DenseMap<L>::kDenseThreads + 4 : p->num_params;
+        a.owner_from = threads - 4;
+        static_assert((2 * qr::DenseMap<L>::kDenseThreads + 4 + qr::kApplyThreads - 1) / qr::kApplyThreads <= 512,
                       "grid barrier: arrive[512], two resident workgroups per CU");
         hipLaunchKernelGGL(qr::ppo_apply_kernel<L>, dim3((threads + qr::kApplyThreads - 1) / qr::kApplyThreads),
                            dim3(qr::kApplyThreads), 0, st, a);

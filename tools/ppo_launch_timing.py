@@ -54,11 +54,13 @@ for rep in range(K):
     a = a[a[:, 0] > 0]
     g0 = g[:, 14].min()
     us = lambda x: (x - g0) / 100.0   # noqa: E731  (100 MHz -> us)
-    rows.append(dict(grad_last_start=us(g[:, 14].max()), grad_first_exit=us(g[:, 15].min()), grad_last_exit=us(g[:, 15].max()),
+    rows.append(dict(grad_last_start=us(g[:, 14].max()), grad_first_exit=us(g[:, 15][g[:, 15] > 0].min()), grad_last_exit=us(g[:, 15].max()),   # (only the dW waves stamp their exit)
                      apply_first_start=us(a[:, 0].min()), apply_last_start=us(a[:, 0].max()),
                      apply_reduced_med=us(np.median(a[:, 1])), apply_reduced_last=us(a[:, 1].max()),
                      apply_arrived_last=us(a[:, 2].max()), apply_released_first=us(a[:, 3].min()), apply_released_last=us(a[:, 3].max()),
-                     apply_last_exit=us(a[:, 4].max()), apply_wgs=len(a)))
+                     apply_last_exit=us(a[:, 4].max()), apply_wgs=len(a),
+                     apply_reduced_p90=us(np.percentile(a[:, 1], 90)), apply_reduced_owner=us(a[-1, 1]), apply_start_owner=us(a[-1, 0]),
+                     apply_slowest_reduced_wg=int(a[:, 1].argmax())))
 print(f"one minibatch update, obs_len {L_}, {Bn} rows; wall-clock us since the FIRST workgroup of the gradient kernel started (median of {K - 4} updates)")
 for k in rows[0]:
     print(f"  {k:24s} {np.median([r[k] for r in rows[4:]]):8.2f}")

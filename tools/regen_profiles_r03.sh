@@ -11,6 +11,8 @@ for v in e2e indi; do
 done
 (for a in "--obs-len 17" "--obs-len 24" "--obs-len 24 --minibatch 32768" "--obs-len 24 --minibatch 65536"; do python tools/bench_ppo_update.py $a 2>/dev/null | tail -1; done) > $O/${T}_ppo_update_bench.json
 (for a in "--obs-len 24" "--obs-len 24 --minibatch 65536"; do QR_PPO_GRAD4=1 python tools/bench_ppo_update.py $a 2>/dev/null | tail -1; done) > $O/${T}_ppo_update_bench_grad4.json
+(for a in "--obs-len 24" "--obs-len 24 --minibatch 65536"; do QR_PPO_PARTIAL=f32 python tools/bench_ppo_update.py $a 2>/dev/null | tail -1; done) > $O/${T}_ppo_update_bench_f32partials.json
+(python tools/ppo_launch_timing.py 24 16384; QR_PPO_PARTIAL=f32 python tools/ppo_launch_timing.py 24 16384) 2>/dev/null | grep -v amdgpu > $O/${T}_ppo_launch_timing.txt
 (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_ppo -o ppo -- python $R/tools/bench_ppo_update.py --obs-len 24 --iters 100 > /dev/null 2>&1)
 python tools/rocprof_summary.py /tmp/prof_ppo/ppo_results.db > $O/${T}_ppo_update_kernel_stats.txt 2>&1
 (cd /tmp && QR_PPO_GRAD4=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_ppo4 -o ppo -- python $R/tools/bench_ppo_update.py --obs-len 24 --iters 100 > /dev/null 2>&1)
