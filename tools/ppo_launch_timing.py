@@ -60,7 +60,12 @@ for rep in range(K):
                      apply_arrived_last=us(a[:, 2].max()), apply_released_first=us(a[:, 3].min()), apply_released_last=us(a[:, 3].max()),
                      apply_last_exit=us(a[:, 4].max()), apply_wgs=len(a),
                      apply_reduced_p90=us(np.percentile(a[:, 1], 90)), apply_reduced_owner=us(a[-1, 1]), apply_start_owner=us(a[-1, 0]),
-                     apply_slowest_reduced_wg=int(a[:, 1].argmax())))
+                     apply_slowest_reduced_wg=int(a[:, 1].argmax()),
+                     # gradient kernel by network (grid.y: 0 = policy, 1 = value): exit of the last dW wave of each workgroup
+                     grad_exit_policy_med=us(np.median(g[:len(g) // 2].reshape(-1, 8, 16)[:, 4:, 15].max(1))),
+                     grad_exit_policy_last=us(g[:len(g) // 2, 15].max()),
+                     grad_exit_value_med=us(np.median(g[len(g) // 2:].reshape(-1, 8, 16)[:, 4:, 15].max(1))),
+                     grad_exit_value_last=us(g[len(g) // 2:, 15].max())))
 print(f"one minibatch update, obs_len {L_}, {Bn} rows; wall-clock us since the FIRST workgroup of the gradient kernel started (median of {K - 4} updates)")
 for k in rows[0]:
     print(f"  {k:24s} {np.median([r[k] for r in rows[4:]]):8.2f}")
