@@ -207,7 +207,8 @@ int qr_rollout_policy(qr_env* env, qr_policy* policy, int32_t num_steps, const f
  * (global L2) and applied with Adam (torch.optim.Adam semantics).  Forward / backward GEMMs use f16 operands with f32
  * accumulation; parameters, gradient accumulation and Adam are f32.
  * Rollout rows (obs [rows][obs_len], act [rows][4], old_logp / adv / ret [rows]) are device arrays; idx_dev[B] selects
- * the rows of this minibatch (B a multiple of 64, <= max_minibatch). */
+ * the rows of this minibatch (64 <= B <= max_minibatch; a last, partial group of 64 rows is masked inside the gradient kernel --
+ * the reference's batch_size is 5000, R:792; the QR_PPO_SPLIT / QR_PPO_GRAD4 forms need B % 64 == 0). */
 typedef struct qr_ppo qr_ppo;
 int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo** out);
 int qr_ppo_destroy(qr_ppo* ppo);

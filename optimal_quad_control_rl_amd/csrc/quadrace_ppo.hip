@@ -1346,10 +1346,14 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
             // the kernel could form it instead of loading it -- one dependent round trip less, 3.4 k of the prologue's 7.7 k cycles
             // in a probe that skipped the index.  The 8-round Feistel + key derivation in front of the gather cost as much as the
             // trip saved: epoch graph 38.4 -> 39.4 us per update at 16 384 rows, 70 -> 75 us at 65 536.  -DQR_EXP_NOIDX keeps the probe.)
+            // a minibatch need not be a multiple of 64 rows (the reference's batch_size is 5000, R:792): positions past B in the last
+            // group read the minibatch's last row and carry zero loss gradients, like the rows of a wave without samples
+            const int pos = (live ? g : a.G - 1) * 64 + 32 * et + c;
+            const bool row_ok = pos < a.B;
 #ifdef QR_EXP_NOIDX
-            const int b = (live ? g : a.G - 1) * 64 + 32 * et + c;
+            const int b = row_ok ? pos : a.B - 1;
 #else
-            const int b = a.idx[(live ? g : a.G - 1) * 64 + 32 * et + c];
+            const int b = a.idx[row_ok ? pos : a.B - 1];
 #endif
             float xin[KS1][8];
             {
@@ -1397,7 +1401,7 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
                 }
                 in[s] = sat_pack(v);
             }
-            const bool valid = h == 0 && live;
+            const bool valid = h == 0 && live && row_ok;
             // ---- forward: the activations stay in registers until they have been published for their layer's weight gradient
             uint32_t m1[2], m2[2], m3[2];
             half8 h1[8], h2[8], h3[8];
@@ -2335,9 +2339,12 @@ int fill_batch(qr_ppo* p, qr::PpoBatch& b, const float* theta, const float* obs,
                const float* adv, const float* ret, const int32_t* idx, int32_t B, float clip, float vf_coef, float ent_coef,
                float* stats) {
     if (!p || !theta || !obs || !act || !old_logp || !adv || !ret || !idx) return ppofail(QR_E_INVALID, "qr_ppo: null argument");
-    if (B < 64 || B % 64 != 0 || B > p->max_B) return ppofail(QR_E_INVALID, "qr_ppo: minibatch size must be a multiple of 64 within max_minibatch");
+    // the role-split gradient kernel masks the tail of a last, partial group of 64 rows; the earlier forms need whole groups
+    const bool ragged_ok = p->fused && !p->grad4;
+    if (B < 64 || (B % 64 != 0 && !ragged_ok) || B > p->max_B)
+        return ppofail(QR_E_INVALID, "qr_ppo: minibatch size must be >= 64 (a multiple of 64 under QR_PPO_SPLIT / QR_PPO_GRAD4) and <= max_minibatch");
     b.obs = obs; b.act = act; b.old_logp = old_logp; b.adv = adv; b.ret = ret; b.idx = idx;
-    b.B = B; b.G = B / 64;
+    b.B = B; b.G = (B + 63) / 64;
     b.clip = clip; b.vf_coef = vf_coef; b.ent_coef = ent_coef;
     b.acc = nullptr;
     b.theta = theta;
@@ -2473,7 +2480,7 @@ int qr_ppo_epoch_begin(qr_ppo* p, const float* adv_dev, const int32_t* idx_dev, 
 static int epoch_begin_impl(qr_ppo* p, const float* adv_dev, const int32_t* idx_dev, int32_t B, int32_t num_minibatches, void* stream,
                             unsigned long long* bump) {
     if (!p || !adv_dev || !idx_dev) return ppofail(QR_E_INVALID, "qr_ppo_epoch_begin: null argument");
-    if (B < 64 || B % 64 != 0 || B > p->max_B || num_minibatches < 1 || num_minibatches > qr_ppo::kMaxEpochMinibatches)
+    if (B < 64 || (B % 64 != 0 && !(p->fused && !p->grad4)) || B > p->max_B || num_minibatches < 1 || num_minibatches > qr_ppo::kMaxEpochMinibatches)
         return ppofail(QR_E_INVALID, "qr_ppo_epoch_begin: bad minibatch size / count");
     PPO_HIP(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
@@ -2610,7 +2617,7 @@ int qr_ppo_epoch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_d
                  float max_grad_norm, float lr, float beta1, float beta2, float eps, float* stats_dev, void* stream) {
     if (!p || !theta_dev || !adam_m_dev || !adam_v_dev || !obs_dev || !act_dev || !old_logp_dev || !adv_dev || !ret_dev || !perm_dev)
         return ppofail(QR_E_INVALID, "qr_ppo_epoch: null argument");
-    if (B < 64 || B % 64 != 0 || B > p->max_B || num_minibatches < 1 || num_minibatches > qr_ppo::kMaxEpochMinibatches || lr < 0.0f)
+    if (B < 64 || (B % 64 != 0 && !(p->fused && !p->grad4)) || B > p->max_B || num_minibatches < 1 || num_minibatches > qr_ppo::kMaxEpochMinibatches || lr < 0.0f)
         return ppofail(QR_E_INVALID, "qr_ppo_epoch: bad minibatch size / count / learning rate");
     if (num_epochs < 1 || num_epochs > 64 || (num_epochs > 1 && !device_shuffle))
         return ppofail(QR_E_INVALID, "qr_ppo_epoch: num_epochs > 1 needs device_shuffle (the caller cannot rewrite the permutation in between)");

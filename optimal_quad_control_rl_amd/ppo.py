@@ -94,7 +94,8 @@ class MfmaPpoUpdater:
         self._h = None
         self.device = device
         h = C.c_void_p()
-        _lib.check(self._L.qr_ppo_create(int(obs_len), int(device.index or 0), int(max_minibatch), C.byref(h)))
+        # (capacity in whole groups of 64 rows; a minibatch itself may be any size >= 64: the kernel masks a partial last group)
+        _lib.check(self._L.qr_ppo_create(int(obs_len), int(device.index or 0), (int(max_minibatch) + 63) // 64 * 64, C.byref(h)))
         self._h = h
         n = self._L.qr_ppo_num_params(self._h)
         self.theta = torch.zeros(n, dtype=torch.float32, device=device)
@@ -314,7 +315,7 @@ class PPO:
         self._updater = None
         if native_update:
             assert tuple(net_arch) == (120, 120, 120), "the matrix-core update is built for the reference's 3 x 120 networks"
-            assert self.batch_size % 64 == 0 and (T * N) % self.batch_size == 0
+            assert self.batch_size >= 64 and (T * N) % self.batch_size == 0
             self._updater = MfmaPpoUpdater(self.policy, obs_dim, self.dev, self.batch_size)
             self._updater.set_shuffle(0x5EED0000 + int(seed))   # on-device epoch permutations (single-process native update)
         self.fused_collect = fused_collect

@@ -207,7 +207,7 @@ class PPO:
             from .ppo import PPO as Trainer
 
             rows = core.num_envs * self.n_steps
-            shapes_ok = tuple(self.net_arch) == (120, 120, 120) and self.batch_size % 64 == 0 and rows % self.batch_size == 0
+            shapes_ok = tuple(self.net_arch) == (120, 120, 120) and self.batch_size >= 64 and rows % self.batch_size == 0
             native = shapes_ok if native_update == "auto" else bool(native_update)
             fused = (tuple(self.net_arch) == (120, 120, 120)) if fused_collect == "auto" else bool(fused_collect)
             self._trainer = Trainer(core, n_steps=self.n_steps, batch_size=self.batch_size, n_epochs=self.n_epochs,

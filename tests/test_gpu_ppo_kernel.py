@@ -73,7 +73,8 @@ def _flat_ref_grads(ref):
 
 
 @pytest.mark.parametrize("L,B,clip", [(17, 1024, 0.2), (17, 1024, 50.0), (24, 512, 0.2), (36, 256, 50.0), (13, 64, 0.2),
-                                      (17, 16384, 0.2), (24, 32768, 50.0), (17, 6400, 0.2)])   # 6400: 100 groups -> 25 chunks (no XCD mapping)
+                                      (17, 16384, 0.2), (24, 32768, 50.0), (17, 6400, 0.2),    # 6400: 100 groups -> 25 chunks (no XCD mapping)
+                                      (24, 5000, 0.2), (24, 5000, 50.0), (13, 100, 50.0)])      # 5000 = the reference's batch_size (R:792): 78 groups + 8 rows
 @pytest.mark.parametrize("partial", ["bf16", "f32"])
 def test_gradient_matches_autograd(L, B, clip, partial, monkeypatch):
     """Two references: (1) autograd through the same networks with f16-rounded GEMM operands -- what the kernels compute,
@@ -197,13 +198,21 @@ def test_grad_then_apply_equals_minibatch():
     assert torch.allclose(up_a.m, up_b.m, rtol=1e-5, atol=1e-9)
 
 
-def test_argument_validation():
+def test_argument_validation(monkeypatch):
     from optimal_quad_control_rl_amd import _lib
+    from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
 
     pol, ref, up, obs, act, old_lp, adv, ret = _setup(17, 256, seed=2)
+    idx = torch.arange(40, device=obs.device, dtype=torch.int32)
+    with pytest.raises(_lib.QuadraceError):
+        up.grad(obs, act, old_lp, adv, ret, idx)                # fewer than 64 rows
+    monkeypatch.setenv("QR_PPO_GRAD4", "1")
+    up4 = MfmaPpoUpdater(pol, 17, obs.device, max_minibatch=4096)
+    monkeypatch.delenv("QR_PPO_GRAD4")
     idx = torch.arange(100, device=obs.device, dtype=torch.int32)
     with pytest.raises(_lib.QuadraceError):
-        up.grad(obs, act, old_lp, adv, ret, idx)                # not a multiple of 64
+        up4.grad(obs, act, old_lp, adv, ret, idx)               # the earlier kernel forms need whole groups of 64 rows
+    up4.close()
     idx = torch.arange(8192, device=obs.device, dtype=torch.int32) % 256
     with pytest.raises(_lib.QuadraceError):
         up.grad(obs, act, old_lp, adv, ret, idx.contiguous())   # larger than max_minibatch

@@ -233,18 +233,31 @@ def test_sb3_model_trains_saves_loads_and_continues_bit_for_bit(tmp_path):
     assert any(not torch.equal(sd_a[k], model2.policy.state_dict()[k].to(sd_a[k].device)) for k in sd_a)   # and it did train
 
 
-def test_sb3_model_with_the_reference_batch_size_uses_the_torch_update():
-    """batch_size = 5000 (R:792) is not a multiple of 64: the facade falls back from the matrix-core update to torch autograd on
-    the same device tensors (still no host round trip per step), and says so."""
+def test_sb3_model_with_the_reference_hyper_parameters_runs_on_the_matrix_cores():
+    """The training cell's own settings (R:783-795: n_steps = 1000, batch_size = 5000, n_epochs = 10, 100 envs): 5000 is not a multiple
+    of 64 -- the gradient kernel masks the 8-row tail of the last group -- so the facade keeps the matrix-core update; every one of the
+    20 x 10 updates per rollout is applied (the gradient of a 5000-row minibatch is checked against autograd in
+    test_gpu_ppo_kernel.py).  Only a batch size that does not divide the rollout falls back to torch autograd."""
     from optimal_quad_control_rl_amd import PPO, Quadcopter3DGates, TRAIN_DISTURBANCE_RANGES, square_track
 
-    env = Quadcopter3DGates(1000, *square_track(), gates_ahead=1, infos_mode="none", seed=3)
+    kw = dict(policy_kwargs=dict(activation_fn=torch.nn.ReLU, net_arch=[dict(pi=[120, 120, 120], vf=[120, 120, 120])]),
+              n_steps=1000, batch_size=5000, n_epochs=10, gamma=0.999, seed=5)
+    env = Quadcopter3DGates(100, *square_track(), gates_ahead=1, infos_mode="none", seed=3)
     env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
-    m = PPO("MlpPolicy", env, policy_kwargs=dict(activation_fn=torch.nn.ReLU, net_arch=[dict(pi=[120, 120, 120], vf=[120, 120, 120])]),
-            n_steps=10, batch_size=5000, n_epochs=2, gamma=0.999)
+    m = PPO("MlpPolicy", env, **kw)
+    assert m._trainer.native_update
+    theta0 = m._trainer._updater.theta.clone()
+    m.learn(total_timesteps=2 * 100 * 1000)
+    st = m._trainer.stats
+    assert m.num_timesteps == 200000 and st["updates"] == 2 * 10 * 20 and st["skipped_nonfinite"] == 0 and np.isfinite(st["loss"])
+    assert torch.isfinite(m._trainer._updater.theta).all() and not torch.equal(m._trainer._updater.theta, theta0)
+    env.close()
+    env = Quadcopter3DGates(1000, *square_track(), gates_ahead=1, infos_mode="none", seed=3)
+    m = PPO("MlpPolicy", env, **dict(kw, n_steps=10, batch_size=3000))      # 10 000 rows % 3000 != 0
     assert not m._trainer.native_update
     m.learn(total_timesteps=10 * 1000)
     assert m.num_timesteps == 10000 and np.isfinite(m.ep_info.get("loss", 0.0))
+    env.close()
 
 
 def test_gather_rollout_over_rccl_at_config4_size_stays_within_its_buffers():
