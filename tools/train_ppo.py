@@ -32,6 +32,8 @@ ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--no-trunc-bootstrap", action="store_true", help="round-1 behaviour: a time-limit truncation is a termination")
 ap.add_argument("--eval-final", action="store_true", help="evaluate the FINAL policy (no best-by-training-statistic checkpoint)")
 ap.add_argument("--save", default="", help="save an SB3-shaped checkpoint (optimal_quad_control_rl_amd.sb3 format) of the final model here")
+ap.add_argument("--curve", type=int, default=0, help="evaluate the current policy every this many rollouts (training clock stopped)")
+ap.add_argument("--lap-target", type=float, default=2.6, help="flying lap (s) that counts as the reference's level for --curve")
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 
@@ -58,65 +60,96 @@ model = PPO(env, seed=a.seed, ent_coef=a.ent_coef, gamma=a.gamma, n_steps=a.n_st
 if "RANK" in os.environ:
     model._updater.broadcast_parameters(0)   # identical start on every rank (the seed already makes it so; this guarantees it)
     model.noise_seed = a.seed                 # same key, different global env ids -> independent action noise per rank
+# deterministic evaluation on a separate env: 2000 steps = 20 s of flight (six laps), crashes auto-reset and restart the lap count
+n_eval = 4096
+ev = cls(n_eval, *trk, gates_ahead=1, infos_mode="none", seed=99)
+if a.variant == "e2e":
+    ev.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+ev.max_steps = 10 ** 6
+G = 4 if a.track == "square" else len(trk[0])   # square_track() lists its four gates twice: a lap is four passes
+dt = 0.01
+
+
+@torch.no_grad()
+def evaluate(m):
+    ev.seed(99)
+    obs = ev.reset_device()
+    dev = obs.device
+    gates12 = torch.zeros(n_eval, device=dev); crashes12 = torch.zeros(n_eval, device=dev)
+    passed = torch.zeros(n_eval, device=dev)            # gates passed since this env's last (re)start
+    lap_start = torch.zeros(n_eval, device=dev)         # time of the last lap boundary (or restart)
+    lap_sum = torch.zeros(7, device=dev); lap_cnt = torch.zeros(7, device=dev)   # laps 1..6 (index 0 unused)
+    for k in range(2000):
+        obs, rew, done, trunc = ev.step_device(m.act_device(obs).contiguous())
+        t = (k + 1) * dt
+        g = (rew > 5).float()
+        if k < 1200:
+            gates12 += g; crashes12 += (done.float() - trunc.float()).clamp(min=0)
+        passed += g
+        lap_done = (g > 0) & (passed % G == 0) & (passed > 0)
+        lap_no = (passed / G).long().clamp(max=6)
+        if lap_done.any():
+            sel = lap_done & (passed / G <= 6)
+            lap_sum.index_add_(0, lap_no[sel], (t - lap_start)[sel])
+            lap_cnt.index_add_(0, lap_no[sel], torch.ones_like(lap_start)[sel])
+            lap_start = torch.where(lap_done, torch.full_like(lap_start, t), lap_start)
+        d = done.bool()
+        passed = torch.where(d, torch.zeros_like(passed), passed)
+        lap_start = torch.where(d, torch.full_like(lap_start, t), lap_start)
+    laps = (lap_sum / lap_cnt.clamp(min=1)).tolist()
+    return dict(eval_gates_per_12s=float(gates12.mean()), eval_crashes_per_12s=float(crashes12.mean()),
+                eval_seconds_per_gate=float(1200 * dt / gates12.mean().clamp(min=1e-9)),
+                eval_seconds_per_lap_4gates=float(4 * 1200 * dt / gates12.mean().clamp(min=1e-9)),
+                eval_lap_seconds={f"lap{i}": laps[i] for i in range(1, 7)}, eval_laps_counted=lap_cnt[1:].tolist(),
+                eval_flying_lap_seconds=float(lap_sum[2:].sum() / lap_cnt[2:].sum().clamp(min=1)))
+
+
 best = {"gates": -1.0, "state": None}
 def keep_best(m):
     g = m.stats.get("gates_per_episode", 0.0)
     if g > best["gates"] and m.stats.get("ep_len_mean", 0) > 600:
         best["gates"] = g
         best["state"] = {k: v.clone() for k, v in m.policy.state_dict().items()}
+# --curve K: every K rollouts the CURRENT policy is evaluated (clock stopped) -> wall-clock-to-quality curve (BASELINE config 5's metric)
+curve, paused, it_no = [], [0.0], [0]
+def on_rollout(m):
+    if not a.eval_final:
+        keep_best(m)
+    it_no[0] += 1
+    if a.curve and it_no[0] % a.curve == 0 and rank == 0:
+        torch.cuda.synchronize()
+        e0 = time.perf_counter()
+        tsec = e0 - t0 - paused[0]
+        r = evaluate(m)
+        torch.cuda.synchronize()
+        paused[0] += time.perf_counter() - e0
+        curve.append(dict(train_seconds=tsec, env_steps=m.num_timesteps * world,
+                          flying_lap=r["eval_flying_lap_seconds"], crashes_per_12s=r["eval_crashes_per_12s"], gates_per_12s=r["eval_gates_per_12s"]))
 t0 = time.perf_counter()
-model.learn(int(a.steps) // world, log_every=20, callback=None if a.eval_final else keep_best)   # --steps counts env-steps of the whole job
+model.learn(int(a.steps) // world, log_every=20, callback=on_rollout)   # --steps counts env-steps of the whole job
 if best["state"] is not None and not a.eval_final:
     model.policy.load_state_dict(best["state"])  # evaluate the best checkpoint (the reference saves one every 10 rollouts, R:823)
 torch.cuda.synchronize()
-train_s = time.perf_counter() - t0
+train_s = time.perf_counter() - t0 - paused[0]
 
-# deterministic evaluation on a fresh env: 2000 steps = 20 s of flight (six laps), crashes auto-reset and restart the lap count
-n_eval = 4096
-ev = cls(n_eval, *trk, gates_ahead=1, infos_mode="none", seed=99)
-if a.variant == "e2e":
-    ev.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
-ev.max_steps = 10 ** 6
-obs = ev.reset_device()
-dev = obs.device
-G = 4 if a.track == "square" else len(trk[0])   # square_track() lists its four gates twice: a lap is four passes
-gates12 = torch.zeros(n_eval, device=dev); crashes12 = torch.zeros(n_eval, device=dev)
-passed = torch.zeros(n_eval, device=dev)            # gates passed since this env's last (re)start
-lap_start = torch.zeros(n_eval, device=dev)         # time of the last lap boundary (or restart)
-lap_sum = torch.zeros(7, device=dev); lap_cnt = torch.zeros(7, device=dev)   # laps 1..6 (index 0 unused)
-dt = 0.01
-for k in range(2000):
-    obs, rew, done, trunc = ev.step_device(model.act_device(obs).contiguous())
-    t = (k + 1) * dt
-    g = (rew > 5).float()
-    if k < 1200:
-        gates12 += g; crashes12 += (done.float() - trunc.float()).clamp(min=0)
-    passed += g
-    lap_done = (g > 0) & (passed % G == 0) & (passed > 0)
-    lap_no = (passed / G).long().clamp(max=6)
-    if lap_done.any():
-        sel = lap_done & (passed / G <= 6)
-        lap_sum.index_add_(0, lap_no[sel], (t - lap_start)[sel])
-        lap_cnt.index_add_(0, lap_no[sel], torch.ones_like(lap_start)[sel])
-        lap_start = torch.where(lap_done, torch.full_like(lap_start, t), lap_start)
-    d = done.bool()
-    passed = torch.where(d, torch.zeros_like(passed), passed)
-    lap_start = torch.where(d, torch.full_like(lap_start, t), lap_start)
-laps = (lap_sum / lap_cnt.clamp(min=1)).tolist()
+final = evaluate(model)
 res = dict(evaluated="final policy" if a.eval_final else "best checkpoint by training statistic", lr_final_frac=a.lr_final,
            world_size=world, fused_collect=a.fused, native_update=a.native_update, variant=a.variant, track=a.track, envs=a.envs,
            gamma=a.gamma, seed=a.seed, n_steps=a.n_steps, epochs=a.epochs, minibatches=a.minibatches, lr=a.lr, target_kl=a.target_kl,
            truncation_bootstrap=not a.no_trunc_bootstrap,
            train_steps=model.num_timesteps * world, train_seconds=train_s,
            train_Msteps_per_s=model.num_timesteps * world / train_s / 1e6,
-           eval_gates_per_12s=float(gates12.mean()), eval_crashes_per_12s=float(crashes12.mean()),
-           eval_seconds_per_gate=float(1200 * dt / gates12.mean().clamp(min=1e-9)),
-           eval_seconds_per_lap_4gates=float(4 * 1200 * dt / gates12.mean().clamp(min=1e-9)),
-           eval_lap_seconds={f"lap{i}": laps[i] for i in range(1, 7)}, eval_laps_counted=lap_cnt[1:].tolist(),
-           eval_flying_lap_seconds=float(lap_sum[2:].sum() / lap_cnt[2:].sum().clamp(min=1)), **model.stats)
+           **final, **model.stats)
 sk, up_n = res.get("skipped_nonfinite", 0), res.get("updates", 0)
 if sk > 0.002 * max(1, sk + up_n):   # a handful of skips = diverged sims in a minibatch; more means something is wrong
     print(f"WARNING: {sk} of {sk + up_n} minibatch updates were skipped for a non-finite gradient norm", file=sys.stderr, flush=True)
+if curve:
+    # first time the policy flies laps like the reference's (simulated flying laps 2.51-2.59 s, FP:3474-3488) without crashing
+    hit = [c for c in curve if 0 < c["flying_lap"] <= a.lap_target and c["crashes_per_12s"] <= 0.1]
+    res["curve"] = curve
+    res["seconds_to_reference_lap"] = hit[0]["train_seconds"] if hit else None
+    res["env_steps_to_reference_lap"] = hit[0]["env_steps"] if hit else None
+    res["lap_target"] = a.lap_target
 print(json.dumps(res))
 if a.out:
     json.dump(res, open(a.out, "w"), indent=1)
