@@ -1336,8 +1336,6 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
         int lane = (int)(threadIdx.x & 63), tid = (int)threadIdx.x;
         asm volatile("" : "+v"(lane), "+v"(tid));
         const int c = lane & 31, h = lane >> 5;
-        const unsigned ex_lane0 = lds_base + 16u * (unsigned)D::kImage + ex_lane_const(lane, 0);   // exchange area + lane
-        const unsigned ex_lane1 = lds_base + 16u * (unsigned)D::kImage + ex_lane_const(lane, 1);   // constants (two reads)
         float* stash = reinterpret_cast<float*>(E + kExHalf8) + wave * 32 + c;
             // =========================================== chain waves ===========================================================
             const int g = 2 * pair + (wave >> 1);
@@ -1586,10 +1584,8 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
         // (89 spilled registers and a scratch segment, i.e. the runtime's scratch set-up on every launch).
         int lane = (int)(threadIdx.x & 63), tid = (int)threadIdx.x;
         asm volatile("" : "+v"(lane), "+v"(tid));
-        const int c = lane & 31, h = lane >> 5;
         const unsigned ex_lane0 = lds_base + 16u * (unsigned)D::kImage + ex_lane_const(lane, 0);   // exchange area + lane
         const unsigned ex_lane1 = lds_base + 16u * (unsigned)D::kImage + ex_lane_const(lane, 1);   // constants (two reads)
-        float* stash = reinterpret_cast<float*>(E + kExHalf8) + wave * 32 + c;
             // ============================================= dW waves ============================================================
             __syncthreads();   // [S0]
             if (stop_flag) return;
@@ -1925,7 +1921,6 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
 template <int L>
 __device__ __forceinline__ void pack_scatter(_Float16* __restrict__ img, int O, int local, float val) {
     using P = PolicyDims<L>;
-    using D = PpoDims<L>;
     const NetOff o = net_off(L, O);
     const _Float16 hv = (_Float16)val;
     // (row, hidden k-slot) of a 128-wide layer image starting at half8 offset `off`: see ppo_pack_kernel
