@@ -184,18 +184,26 @@ __device__ __forceinline__ void assign_reset(Env<V>& e, const float* v) {
 // reset_ for one env, every lane for itself (reset kernel: whole batches reset at once).
 // Distributions of R:455-489 / I:270-296; `rtab` = reset table in LDS.
 template <int V>
-__device__ __forceinline__ void reset_env(const Params& P, const float* __restrict__ rtab, Env<V>& e, uint32_t gid_lo,
-                                          uint32_t gid_hi) {
-    constexpr int NB = (V == kE2E) ? 6 : 4;
+constexpr int reset_value_count() { return 4 * ((V == kE2E) ? 6 : 4); }
+// the reset draws of env (gid) for episode `episode`: 4 values per Philox block, each with its own table row
+template <int V>
+__device__ __forceinline__ void reset_values(const Params& P, const float* __restrict__ rtab, uint32_t episode, uint32_t gid_lo,
+                                             uint32_t gid_hi, float* __restrict__ v) {
+    constexpr int NB = reset_value_count<V>() / 4;
     const float4* rows = reinterpret_cast<const float4*>(rtab);
-    float v[4 * NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         uint32_t o[4];
-        philox4x32_10(gid_lo, gid_hi, e.episode, (uint32_t)b, P.seed_lo, P.seed_hi, o);
+        philox4x32_10(gid_lo, gid_hi, episode, (uint32_t)b, P.seed_lo, P.seed_hi, o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[4 * b + k] = reset_value(rows[4 * b + k], o[k]);
     }
+}
+template <int V>
+__device__ __forceinline__ void reset_env(const Params& P, const float* __restrict__ rtab, Env<V>& e, uint32_t gid_lo,
+                                          uint32_t gid_hi) {
+    float v[reset_value_count<V>()];
+    reset_values<V>(P, rtab, e.episode, gid_lo, gid_hi, v);
     assign_reset<V>(e, v);
 }
 
@@ -595,12 +603,13 @@ __device__ __forceinline__ void observe(const Params& P, const float* __restrict
 // -------------------------------------------------------------------------------------------------
 // `before_reset(done)` is invoked (all lanes) after the state update and before the auto-reset -- the caller's hook
 // for the terminal observation SB3 bootstraps time-limit truncations from (R:589-594).
-template <int V, class BeforeReset>
+// `do_reset(need)` performs the auto-reset of the lanes with `need` (all lanes call it); the default is reset_done_lanes().
+template <int V, class BeforeReset, class DoReset>
 __device__ __forceinline__ float step_env(const Params& P, const float* __restrict__ gates,
                                           const float* __restrict__ rtab, float* __restrict__ tile, const MlpRegs& mlp,
                                           int lane, bool active, Env<V>& e, const float u[4], uint32_t gid_lo,
                                           uint32_t gid_hi, bool& done, bool& trunc, bool& did_reset,
-                                          BeforeReset&& before_reset) {
+                                          BeforeReset&& before_reset, DoReset&& do_reset) {
     constexpr int S = Env<V>::S;
     const Rot R = make_rot(e.s[6], e.s[7], e.s[8]);
     QR_TICK(P, 3);
@@ -667,9 +676,19 @@ __device__ __forceinline__ float step_env(const Params& P, const float* __restri
         for (int k = 0; k < S; ++k) e.s[k] = nw[k];
         did_reset = done;
         before_reset(done);
-        reset_done_lanes<V>(P, rtab, tile, lane, done && active, e, gid_lo, gid_hi);  // shadow lanes are not reset
+        do_reset(done && active);  // shadow lanes are not reset
     }
     return reward;
+}
+template <int V, class BeforeReset>
+__device__ __forceinline__ float step_env(const Params& P, const float* __restrict__ gates,
+                                          const float* __restrict__ rtab, float* __restrict__ tile, const MlpRegs& mlp,
+                                          int lane, bool active, Env<V>& e, const float u[4], uint32_t gid_lo,
+                                          uint32_t gid_hi, bool& done, bool& trunc, bool& did_reset,
+                                          BeforeReset&& before_reset) {
+    return step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc, did_reset,
+                       static_cast<BeforeReset&&>(before_reset),
+                       [&](bool need) { reset_done_lanes<V>(P, rtab, tile, lane, need, e, gid_lo, gid_hi); });
 }
 
 }  // namespace qr

@@ -229,10 +229,16 @@ constexpr int act_chunk() {  // steps of actions staged per burst, sized so the 
     return (65536 - 4 * (kResetTableFloats + kMaxGates * kGateStride) - 4 * kBlock * obs_len<V, GA>()) / (16 * kBlock) >= 8 ? 8 : 4;
 }
 
-template <int V, int GA>
-__global__ void __launch_bounds__(kBlock)
-rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
-               float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+// kStash (round 3; launches with at most one workgroup per CU, where the register budget is free): every lane keeps the draws of
+// ITS OWN next reset -- 24 (16) floats: Philox blocks 0..5 (0..3) of (seed, global env id, current episode) -- and an auto-reset
+// is a masked register copy.  The stash is refilled for all 64 lanes at once, and only when a lane that has used its stash up
+// terminates again (about every 14 steps at a 1.2 % termination rate), instead of the wave walking its done lanes one by one
+// through reset_done_lanes() in 56 % of the steps: measured 0.31 us of a 2.80 us step (tools probe: 2.49 us with resets off,
+// +0.21 us per per cent of terminating lanes).  Same stream, same arithmetic as reset_env(): bit-identical.
+template <int V, int GA, bool kStash>
+__device__ __forceinline__ void rollout_body(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
+                                             float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
+                                             uint8_t* __restrict__ trunc_out) {
     constexpr int kActChunk = act_chunk<V, GA>();
     constexpr int L = obs_len<V, GA>();
     __shared__ __attribute__((aligned(16))) float lds[kResetTableFloats + kMaxGates * kGateStride + kBlock * L +
@@ -260,6 +266,8 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
     // 16 B, conflict-free); each lane only reads back what it wrote itself
     float4* act_slot = reinterpret_cast<float4*>(gates + kMaxGates * kGateStride + kBlock * L) + threadIdx.x;
     bool any_reset = false;
+    float stash[kStash ? reset_value_count<V>() : 1];
+    bool stash_ok = false;
     for (int k0 = 0; k0 < K; k0 += kActChunk) {
         const int c = (K - k0 < kActChunk) ? K - k0 : kActChunk;
         float4 burst[kActChunk];  // all loads first (clamped step index keeps them unconditional), then the LDS writes
@@ -282,6 +290,21 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
             const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc,
                                              did_reset, [&](bool fin) {
                                                  store_terminal_obs<V, GA>(P, gates, e, (size_t)k * n, i, fin && active);
+                                             }, [&](bool need) {
+                                                 if constexpr (kStash) {
+                                                     if (__ballot(need) != 0ull) {                       // wave-uniform
+                                                         if (__ballot(need && !stash_ok) != 0ull) {      // refill ALL lanes (a lane whose stash
+                                                             reset_values<V>(P, rtab, e.episode, gid_lo, gid_hi, stash);   // is intact recomputes it)
+                                                             stash_ok = true;
+                                                         }
+                                                         if (need) {
+                                                             assign_reset<V>(e, stash);
+                                                             stash_ok = false;
+                                                         }
+                                                     }
+                                                 } else {
+                                                     reset_done_lanes<V>(P, rtab, tile, lane, need, e, gid_lo, gid_hi);
+                                                 }
                                              });
             any_reset |= did_reset;
             if (active) {
@@ -304,6 +327,19 @@ rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __res
     if (P.flags & kFlagPause) return;
     store_world<V>(P, i, e);
     if (any_reset) store_dist<V>(P, i, e);
+}
+
+template <int V, int GA>
+__global__ void __launch_bounds__(kBlock)
+rollout_kernel(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
+               float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+    rollout_body<V, GA, false>(P, K, actions, obs_out, rew_out, done_out, trunc_out);
+}
+template <int V, int GA>
+__global__ void __launch_bounds__(kBlock)
+rollout_stash_kernel(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
+                     float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+    rollout_body<V, GA, true>(P, K, actions, obs_out, rew_out, done_out, trunc_out);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -604,9 +640,31 @@ hipError_t launch_step(int variant, const Params& P, const float* actions, float
     return hipGetLastError();
 }
 
+// the reset stash costs 24 registers for the whole loop: worth it while every workgroup has a CU to itself (then the wave's budget is
+// 512 registers anyway); beyond that the plain form keeps two workgroups per CU.  QR_ROLLOUT_STASH=0 / 1 forces the choice.
+static bool use_rollout_stash(int n) {
+    static int forced = -2, cus = 0;
+    if (forced == -2) {
+        const char* v = getenv("QR_ROLLOUT_STASH");
+        forced = v ? (v[0] == '0' ? 0 : 1) : -1;
+    }
+    if (forced >= 0) return forced == 1;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    return (n + kBlock - 1) / kBlock <= cus;
+}
+
 hipError_t launch_rollout(int variant, const Params& P, int K, const float* actions, float* obs, float* rew,
                           uint8_t* done, uint8_t* trunc, hipStream_t st) {
     const float4* a4 = reinterpret_cast<const float4*>(actions);
+    if (use_rollout_stash(P.n)) {
+        if (variant == kE2E) { QR_DISPATCH_GA(kE2E, rollout_stash_kernel, P, K, a4, obs, rew, done, trunc) }
+        else { QR_DISPATCH_GA(kINDI, rollout_stash_kernel, P, K, a4, obs, rew, done, trunc) }
+        return hipGetLastError();
+    }
     if (variant == kE2E) { QR_DISPATCH_GA(kE2E, rollout_kernel, P, K, a4, obs, rew, done, trunc) }
     else { QR_DISPATCH_GA(kINDI, rollout_kernel, P, K, a4, obs, rew, done, trunc) }
     return hipGetLastError();
