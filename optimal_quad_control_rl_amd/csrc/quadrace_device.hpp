@@ -207,6 +207,23 @@ __device__ __forceinline__ void reset_env(const Params& P, const float* __restri
     assign_reset<V>(e, v);
 }
 
+// Auto-reset from a per-lane STASH of the lane's own next reset draws (kernels that keep the env in registers over many steps and
+// have the registers: 24 / 16 floats): a reset is a masked copy; the stash is refilled for the whole wave, and only when a lane that
+// has used its stash up terminates again.  reset_values() for the lane's CURRENT episode = what reset_env() would draw: bit-identical.
+template <int V>
+__device__ __forceinline__ void reset_from_stash(const Params& P, const float* __restrict__ rtab, bool need, Env<V>& e,
+                                                 uint32_t gid_lo, uint32_t gid_hi, float* __restrict__ stash, bool& stash_ok) {
+    if (__ballot(need) == 0ull) return;                 // wave-uniform
+    if (__ballot(need && !stash_ok) != 0ull) {          // refill ALL lanes (a lane whose stash is intact recomputes the same values)
+        reset_values<V>(P, rtab, e.episode, gid_lo, gid_hi, stash);
+        stash_ok = true;
+    }
+    if (need) {
+        assign_reset<V>(e, stash);
+        stash_ok = false;
+    }
+}
+
 // Auto-reset inside the step: typically 0-2 of a wave's 64 envs terminate in a step, so instead of every done
 // lane grinding through 4-6 Philox blocks under a divergent branch (the whole wave waits), the WAVE resets one
 // done env at a time: lanes 0..5 each compute one Philox block of that env's (seed, global id, episode) stream and

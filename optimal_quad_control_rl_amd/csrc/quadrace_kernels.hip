@@ -292,16 +292,7 @@ __device__ __forceinline__ void rollout_body(Params P, int K, const float4* __re
                                                  store_terminal_obs<V, GA>(P, gates, e, (size_t)k * n, i, fin && active);
                                              }, [&](bool need) {
                                                  if constexpr (kStash) {
-                                                     if (__ballot(need) != 0ull) {                       // wave-uniform
-                                                         if (__ballot(need && !stash_ok) != 0ull) {      // refill ALL lanes (a lane whose stash
-                                                             reset_values<V>(P, rtab, e.episode, gid_lo, gid_hi, stash);   // is intact recomputes it)
-                                                             stash_ok = true;
-                                                         }
-                                                         if (need) {
-                                                             assign_reset<V>(e, stash);
-                                                             stash_ok = false;
-                                                         }
-                                                     }
+                                                     reset_from_stash<V>(P, rtab, need, e, gid_lo, gid_hi, stash, stash_ok);
                                                  } else {
                                                      reset_done_lanes<V>(P, rtab, tile, lane, need, e, gid_lo, gid_hi);
                                                  }
@@ -383,6 +374,8 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
     const bool full_wave = wave_first + 64 <= P.n;
     float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
     bool any_reset = false;
+    float stash[reset_value_count<V>()];   // the lane's own next reset draws (reset_from_stash; this kernel always has the registers)
+    bool stash_ok = false;
     float o[L];
     observe<V, GA>(P, gates, e, o);
     for (int k = 0; k < K; ++k) {
@@ -460,7 +453,7 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
         const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc,
                                          did_reset, [&](bool fin) {
                                              store_terminal_obs<V, GA>(P, gates, e, (size_t)k * n, i, fin && active);
-                                         });
+                                         }, [&](bool need) { reset_from_stash<V>(P, rtab, need, e, gid_lo, gid_hi, stash, stash_ok); });
         any_reset |= did_reset;
         if (active) {
             stream_store(rew_out + (size_t)k * n + i, reward);
