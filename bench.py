@@ -104,23 +104,34 @@ class Runtime:
         self.collectives = (world > 1) if collectives is None else bool(collectives)
 
     @classmethod
-    def from_env(cls, expected_world):
+    def from_env(cls, expected_world, standin=False):
+        """One rank of the job, as the launcher (torch.distributed.run: the driver's, or spawn_ranks() below) described it in the
+        environment.  The world size the launcher gave, the one the process group reports and --gpus must all agree: a run that
+        would print another n_gpus than it was asked for exits non-zero instead.  `standin`: CPU ranks over gloo (tests only)."""
         import torch
         import torch.distributed as dist
 
         rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         world = int(os.environ.get("WORLD_SIZE", "1"))
-        if expected_world != world and world > 1:
-            raise SystemExit(f"--gpus {expected_world} but WORLD_SIZE={world}")
-        assert torch.cuda.is_available(), "bench.py needs an MI355X"
-        torch.cuda.set_device(local_rank)
+        if expected_world != world:
+            raise SystemExit(f"bench.py: --gpus {expected_world} but WORLD_SIZE={world}: refusing to print a line for another job size")
         collectives = world > 1 or os.environ.get("QR_BENCH_FORCE_DIST", "0") == "1"
+        if standin:
+            device, backend, kw = torch.device("cpu"), "gloo", {}
+        else:
+            assert torch.cuda.is_available(), "bench.py needs an MI355X"
+            if local_rank >= torch.cuda.device_count():
+                raise SystemExit(f"bench.py: rank {rank} (local rank {local_rank}) has no GPU: {torch.cuda.device_count()} visible")
+            torch.cuda.set_device(local_rank)
+            device, backend, kw = torch.device("cuda", local_rank), "nccl", {"device_id": torch.device("cuda", local_rank)}
         if collectives:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
-        return cls(rank, local_rank, world, torch.device("cuda", local_rank), True, collectives)
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            if dist.get_world_size() != expected_world:
+                raise SystemExit(f"bench.py: --gpus {expected_world} but the process group has {dist.get_world_size()} ranks")
+        return cls(rank, local_rank, world, device, not standin, collectives)
 
     def env_id_base(self, envs_per_rank):
         """global index of this rank's env 0: rank r owns global envs [r n, (r + 1) n) (keys the reset RNG stream)"""
@@ -717,10 +728,55 @@ def run(args, rt, env_factory=make_env, closed_loop=True):
     return result
 
 
-def main():
-    args = parse()
-    rt = Runtime.from_env(args.gpus)
-    result = run(args, rt)
+def _standin_factory():
+    """TEST HOOK (tests/test_bench_gloo.py): QR_BENCH_TEST_FACTORY="module:callable" names an env factory with make_env()'s
+    signature that runs on CPU ranks over gloo, so that the launcher logic of this file (rank spawning, world-size checks, the
+    multi-rank bracket) can be exercised where there is no GPU.  A stand-in run labels its line `data: "cpu-standin (test only)"`;
+    nothing in a measurement run reads this variable's target."""
+    spec = os.environ.get("QR_BENCH_TEST_FACTORY")
+    if not spec:
+        return None
+    import importlib
+
+    mod, _, name = spec.partition(":")
+    return getattr(importlib.import_module(mod), name)
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks HERE (re-exec under
+    torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1) and return their exit code.  Fewer than N visible GPUs is
+    an error, never a smaller job."""
+    import socket
+    import subprocess
+
+    if not os.environ.get("QR_BENCH_TEST_FACTORY"):
+        import torch
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this box has {have}: not running a smaller job")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print("bench.py: --gpus %d without a launcher: spawning the ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, argv))
+    factory = _standin_factory()
+    rt = Runtime.from_env(args.gpus, standin=factory is not None)
+    if factory is not None:
+        result = run(args, rt, env_factory=factory, closed_loop=False)
+        result["data"] = "cpu-standin (test only)"
+    else:
+        result = run(args, rt)
     if rt.rank == 0:
         # the full object: a file next to the profiles scratch (pulled back by gpurun) and stderr; stdout gets ONE compact line, last
         full_path = None

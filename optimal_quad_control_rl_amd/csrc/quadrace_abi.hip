@@ -613,8 +613,8 @@ int qr_profile_steps(qr_env* e, int32_t K, const float* actions_dev, float* obs_
     return QR_OK;
 }
 
-#ifdef QR_PHASE_TIMING
-// profiling build only (tools/phase_timing.py): device buffer [n_waves][16] of shader-clock stamps, or NULL
+#if defined(QR_PHASE_TIMING) || defined(QR_CLOCK_PROBE)
+// profiling builds only (tools/phase_timing.py, tools/clock_probe.py): device buffer [n_waves][16] of shader-clock stamps, or NULL
 __attribute__((visibility("default"))) int qr_debug_set_ticks(qr_env* e, unsigned long long* ticks_dev) {
     if (!e) return QR_E_INVALID;
     e->P.ticks = ticks_dev;

@@ -69,11 +69,37 @@ struct Params {
     float obs_lo[4], obs_inv[4];  // observation scaling of (Mx,My,Mz,Fz): lo and 1/(hi-lo) after the R:419-441 fix-up
     float* term_obs;    // optional (qr_set_terminal_obs): rows [N][obs_len] (per-step kernel) / [K][N][obs_len] (K-step kernels)
                         // receiving the PRE-reset observation of every env that finished at that step
-#ifdef QR_PHASE_TIMING
-    unsigned long long* ticks;  // [n_waves][16] shader-clock stamps (profiling build only, tools/phase_timing.py)
+#if defined(QR_PHASE_TIMING) || defined(QR_CLOCK_PROBE)
+    unsigned long long* ticks;  // [n_waves][16] shader-clock stamps (profiling builds only, tools/phase_timing.py / clock_probe.py)
     int tick_on;
 #endif
 };
+
+#ifdef QR_CLOCK_PROBE
+// tools/clock_probe.py: un-drained stamps around a kernel's step loop -- shader cycles (s_memtime) AND the constant 100 MHz
+// counter (s_memrealtime), so that cycles per step and the EFFECTIVE shader clock under that load both come out; slot 6 = HW_ID
+#define QR_CLOCK_STAMP(P, slot)                                                                                   \
+    do {                                                                                                          \
+        if ((P).ticks && (threadIdx.x & 63) == 0) {                                                               \
+            unsigned long long* t_ = (P).ticks + ((size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * 16; \
+            t_[2 * (slot)] = clock64();                                                                           \
+            t_[2 * (slot) + 1] = wall_clock64();                                                                  \
+        }                                                                                                         \
+    } while (0)
+#define QR_CLOCK_HWID(P)                                                                                          \
+    do {                                                                                                          \
+        if ((P).ticks && (threadIdx.x & 63) == 0) {                                                               \
+            unsigned hw_, xcc_;                                                                                   \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                     \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                   \
+            (P).ticks[((size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * 16 + 8] =                   \
+                (unsigned long long)hw_ | ((unsigned long long)xcc_ << 32);                                       \
+        }                                                                                                         \
+    } while (0)
+#else
+#define QR_CLOCK_STAMP(P, slot) do { } while (0)
+#define QR_CLOCK_HWID(P) do { } while (0)
+#endif
 
 #ifdef QR_PHASE_TIMING
 #define QR_TICK(P, slot)                                                                      \

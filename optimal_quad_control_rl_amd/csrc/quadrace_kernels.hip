@@ -247,6 +247,8 @@ __device__ __forceinline__ void rollout_body(Params P, int K, const float4* __re
     const int lane = threadIdx.x & 63;
     const bool active = i < P.n;  // ragged tail lanes stay active (wave-wide MLP ops) and shadow env 0
     const int ii = active ? i : 0;
+    QR_CLOCK_STAMP(P, 0);
+    QR_CLOCK_HWID(P);
     Env<V> e;
     load_env<V>(P, ii, e);
     MlpRegs mlp;  // weights stay in registers for all K steps
@@ -268,6 +270,7 @@ __device__ __forceinline__ void rollout_body(Params P, int K, const float4* __re
     bool any_reset = false;
     float stash[kStash ? reset_value_count<V>() : 1];
     bool stash_ok = false;
+    QR_CLOCK_STAMP(P, 1);
     for (int k0 = 0; k0 < K; k0 += kActChunk) {
         const int c = (K - k0 < kActChunk) ? K - k0 : kActChunk;
         float4 burst[kActChunk];  // all loads first (clamped step index keeps them unconditional), then the LDS writes
@@ -313,11 +316,13 @@ __device__ __forceinline__ void rollout_body(Params P, int K, const float4* __re
             QR_TICK(P, 7);
         }
     }
+    QR_CLOCK_STAMP(P, 2);
     if (!active) return;
     P.ts[i] = pack_ts<V>(e);
     if (P.flags & kFlagPause) return;
     store_world<V>(P, i, e);
     if (any_reset) store_dist<V>(P, i, e);
+    QR_CLOCK_STAMP(P, 3);
 }
 
 template <int V, int GA>

@@ -130,6 +130,42 @@ def test_bench_multirank_path_world2(tmp_path):
     assert (tmp_path / "ok").exists()
 
 
+def bench_standin_factory(variant, n, ga, env_id_base, seed=0, residual=None):
+    """QR_BENCH_TEST_FACTORY target (bench.py's test hook): the CPU stand-in env of this file."""
+    return CpuBenchEnv(variant, n, ga, env_id_base, seed, residual)
+
+
+def _run_bench(argv, extra_env=None, timeout=600):
+    import subprocess
+
+    env = dict(os.environ, QR_BENCH_TEST_FACTORY="test_bench_gloo:bench_standin_factory",
+               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), os.environ.get("PYTHONPATH", "")]))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus2_without_a_launcher_spawns_two_ranks():
+    """`python bench.py --gpus 2` launched PLAINLY (no torchrun around it, WORLD_SIZE unset) must start its two
+    ranks itself -- it used to run one rank and print n_gpus 1.  CPU ranks over gloo stand in for the GPUs."""
+    r = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--envs", "64", "--repeats", "2", "--no-cpu-baseline", "--no-parity",
+                    "--variant", "indi", "--no-extras"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl"]["rccl_world_size"] == 2 and line["rccl"]["backend"] == "gloo"
+    assert len(line["rccl"]["per_rank_ms_per_step"]) == 2
+    assert line["data"].startswith("cpu-standin")          # a stand-in run can never pass for a measurement
+    assert abs(line["value"] - 64 * 2 * 6 / (line["ms_per_step"] * 1e-3 * 6)) < 1e-6 * line["value"]
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    """a launcher that started another number of ranks than --gpus says: every rank exits non-zero, no line is printed"""
+    r = _run_bench(["--gpus", "4", "--steps", "2", "--warmup", "1", "--envs", "64", "--no-cpu-baseline", "--no-parity", "--no-extras"],
+                   extra_env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout) and not r.stdout.strip()
+
+
 def test_timed_region_fills_the_bracket():
     import time
 

@@ -32,9 +32,11 @@ GROUP_B = "SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_V
 GROUP_C = "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU"
 GROUP_D = "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVES SQ_INSTS_VALU"
 K_FUSED = 32       # steps per fused launch in the probe
-N = 65536
-KERNELS = ("q3_step_kernel<", "q3_rollout_kernel<", "step_kernel<0", "step_kernel<1", "rollout_kernel<0", "rollout_kernel<1",
-           "rollout_policy_kernel<0", "rollout_policy_kernel<1", "ppo_")
+N = int(os.environ.get("QR_PMC_ENVS", "65536"))         # envs of the probe (round 4: also run at 1 Mi envs for the throughput regime)
+ONLY_ENV = os.environ.get("QR_PMC_ONLY_ENV", "0") == "1"  # skip the predecessor-env and PPO legs of the probe
+# (the fused rollout launches as rollout_stash_kernel<V, GA> up to one workgroup per CU and as rollout_kernel<V, GA> beyond)
+KERNELS = ("q3_step_kernel<", "q3_rollout_kernel<", "step_kernel<0", "step_kernel<1", "rollout_stash_kernel<0", "rollout_stash_kernel<1",
+           "rollout_kernel<0", "rollout_kernel<1", "rollout_policy_kernel<0", "rollout_policy_kernel<1", "ppo_")
 
 
 def probe():
@@ -65,6 +67,9 @@ def probe():
                                             out=None if res is None else res[:6])
         torch.cuda.synchronize()
         env.close()
+    if ONLY_ENV:
+        print("pmc compute probe done (env kernels only)")
+        return
     # predecessor envs (include/quad3d.h): hover (f64) and gates (f32)
     from optimal_quad_control_rl_amd.quad3d import Quadcopter3DVec, Quadcopter3DVecGates
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -116,7 +121,8 @@ def summarise(paths, out_path):
                     continue
                 acc.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     res = {"counters": "rocprofv3 --kernel-trace --pmc (two SQ passes, groups A and B of tools/pmc_compute.py), per launch "
-                       "(mean over launches after the first two); N = 65 536 envs, fused kernels: %d steps per launch" % K_FUSED,
+                       "(mean over launches after the first two); N = %d envs, fused kernels: %d steps per launch" % (N, K_FUSED),
+           "n_envs": N,
            "units": "SQ_WAVE_CYCLES/SQ_WAIT_*/SQ_ACTIVE_INST_* = quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES = cycles "
                     "summed over SIMDs; SQ_INSTS_* = wave-instructions; GRBM_GUI_ACTIVE = GPU cycles",
            "kernels": {}}

@@ -34,7 +34,7 @@ def summarise(rows):
     cal = [v for k, v in rows if "copyBuffer" in k]
     cal = [v for v in cal if v > 0.9 * max(cal)]  # only the 256 MiB calibration copies, not small H2D uploads
     step = [v for k, v in rows if "step_kernel" in k]
-    roll = [v for k, v in rows if "rollout_kernel" in k]
+    roll = [v for k, v in rows if "rollout_kernel" in k or "rollout_stash_kernel" in k]
     rpol = [v for k, v in rows if "rollout_policy_kernel" in k]
     return (sum(cal) / len(cal), sum(step[4:]) / max(1, len(step[4:])), sum(roll) / max(1, len(roll)),
             sum(rpol) / max(1, len(rpol)))
