@@ -225,7 +225,8 @@ int qr_ppo_grad(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const
                 float clip, float vf_coef, float ent_coef, float* grad_out_dev, float* stats_dev, void* stream);
 /* one complete minibatch update of theta (and the Adam moments).  adam_step = 1, 2, ...: the caller counts the updates; adam_step = 0:
  * the library's device-resident count of optimiser steps REALLY taken is used and advanced (launches turned into no-ops by the
- * early stop or a non-finite gradient norm do not count, like torch.optim.Adam under SB3) -- see qr_ppo_adam_step.  lr >= 0.
+ * early stop or a non-finite gradient norm do not count, like torch.optim.Adam under SB3) -- see qr_ppo_adam_step.  lr >= 0 (a
+ * negative or NaN learning rate is QR_E_INVALID, here and in qr_ppo_apply / qr_ppo_epoch).
  * Two launches:
  * ONE gradient kernel (forward, loss, backward and the weight gradients of 128 samples per workgroup and pass; per-workgroup
  * partial sums, rounded to bf16 when they leave the workgroup) and ONE kernel that sums the partials in f32 in a fixed order, takes

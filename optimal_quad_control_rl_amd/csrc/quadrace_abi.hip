@@ -317,19 +317,27 @@ int qr_set_residual(qr_env* e, const float* blob, size_t n_floats) {
     // device image: MFMA A operands, layer-2 weights per wave half, output biases (see quadrace_device.hpp)
     float* T = e->mlp_table;
     std::memset(T, 0, sizeof(e->mlp_table));
-    for (int t = 0; t < 10; ++t)
-        for (int l = 0; l < 64; ++l) {
-            const int j = l & 31;
-            float v;
-            if (t < 4) {
-                const int k = 2 * t + (l >> 5);
-                v = k < 7 ? tW1[j * 7 + k] : (k == 7 ? tb1[j] : 0.0f);
-            } else {
-                const int k = 2 * (t - 4) + (l >> 5);
-                v = k < 10 ? mW1[j * 10 + k] : (k == 10 ? mb1[j] : 0.0f);
-            }
-            T[qr::kOffTabA + 64 * t + l] = v;
+    // layer 1: every weight and bias as two f16 pieces w = W0 + W1 (round to nearest even; w - W0 is exact in float32), laid out as
+    // the A operands of the five v_mfma_f32_32x32x16_f16 instructions per env tile (quadrace_device.hpp, "Residual-MLP table")
+    auto piece0 = [](float w) { return (_Float16)w; };
+    auto piece1 = [](float w) { return (_Float16)(w - (float)(_Float16)w); };
+    _Float16* A = reinterpret_cast<_Float16*>(T + qr::kOffTabA);
+    auto slot = [&](int q, int lane, int j) -> _Float16& { return A[((size_t)q * 64 + lane) * 8 + j]; };
+    for (int row = 0; row < 32; ++row) {
+        const int lo = row, hi = row + 32;   // lanes holding k-slots 0..7 / 8..15 of this hidden row
+        for (int k = 0; k < 7; ++k) {
+            slot(0, lo, k) = piece0(tW1[row * 7 + k]);   slot(0, hi, k) = piece0(tW1[row * 7 + k]);    // X0 W0 | X1 W0
+            slot(1, lo, k) = piece1(tW1[row * 7 + k]);                                                  // X0 W1 | 0
+            slot(2, lo, k) = piece0(mW1[row * 10 + k]);  slot(2, hi, k) = piece0(mW1[row * 10 + k]);
+            slot(3, lo, k) = piece1(mW1[row * 10 + k]);
         }
+        slot(0, lo, 7) = piece0(tb1[row]);  slot(1, lo, 7) = piece1(tb1[row]);   // k-slot 7 of the low half multiplies the constant 1
+        slot(2, lo, 7) = piece0(mb1[row]);  slot(3, lo, 7) = piece1(mb1[row]);
+        for (int k = 0; k < 3; ++k) {        // rates p, q, r: [X0 (3), 0, X1 (3), 0] in both halves
+            slot(4, lo, k) = piece0(mW1[row * 10 + 7 + k]);  slot(4, lo, 4 + k) = piece0(mW1[row * 10 + 7 + k]);   // X0 W0, X1 W0
+            slot(4, hi, k) = piece1(mW1[row * 10 + 7 + k]);                                                          // X0 W1
+        }
+    }
     for (int h = 0; h < 2; ++h)
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;

@@ -34,15 +34,22 @@ constexpr int kFlagPauseIfCollision = 4;
 
 // Gate table row (LDS, 48 B): [x y z yaw | cos(yaw) sin(yaw) 0 0 | rel_x rel_y rel_z rel_yaw]
 //
-// Residual-MLP table (device image, see residual_mlp() below for why layer 1 runs on the f32 matrix core):
-//   tabA [10][64]  layer-1 A operands of v_mfma_f32_32x32x2_f32, one float per lane per K-step:
-//                  t = 0..3  thrust tile,  k = 2t + (lane>>5):      k < 7 ? W1t[lane&31][k] : (k == 7  ? b1t[lane&31] : 0)
-//                  t = 4..9  moment tile,  k = 2(t-4) + (lane>>5):  k < 10 ? W1m[lane&31][k] : (k == 10 ? b1m[lane&31] : 0)
+// Residual-MLP table (device image; residual_mlp() below says why layer 1 runs on the f16 matrix core with split operands):
+//   tabA [5][64][4 dwords]  layer-1 A operands of v_mfma_f32_32x32x16_f16: lane l holds 8 f16 = hidden row l&31, k-slots 8(l>>5)..+7
+//                  of MFMA q.  W = W0 + W1 (f16 pieces, round to nearest even; b likewise), inputs 0..6 = (w1..w4, vbx, vby, vbz),
+//                  7..9 = (p, q, r):
+//                  q = 0 thrust A : lo [W0t[row][0..6], b0t[row]]                  hi [same with W0t -> the X1 slots: W0t[row][0..6], 0]
+//                  q = 1 thrust B : lo [W1t[row][0..6], b1t[row]]                  hi zeros
+//                  q = 2 moment A : lo [W0m[row][0..6], b0m[row]]                  hi [W0m[row][0..6], 0]
+//                  q = 3 moment B : lo [W1m[row][0..6], b1m[row]]                  hi zeros
+//                  q = 4 moment C : lo [W0m[row][7..9], 0, W0m[row][7..9], 0]      hi [W1m[row][7..9], 0, 0, 0, 0, 0]
 //   tabW2 [2][64]  layer-2 weights x 2^40 (see relu2_scaled) seen by the lanes of wave half h = lane>>5; accumulator register
 //                  r holds hidden row(r,h) = (r&3) + 8*(r>>2) + 4h:   [r] = W2t[0][row]   [16 + 16m + r] = W2m[m][row], m = 0..2
 //   b2 [4]         output biases (thrust, moment x/y/z)
-constexpr int kOffTabA = 0, kOffTabW2 = 640, kOffB2 = 768;
-constexpr int kMlpTableFloats = 784;  // 772 used, padded to a multiple of 16
+constexpr int kMlpQuads = 5;
+constexpr int kOffTabA = 0, kOffTabW2 = kMlpQuads * 64 * 4, kOffB2 = kOffTabW2 + 128;
+constexpr int kMlpTableFloats = 1424;  // 1412 used, padded to a multiple of 16
+static_assert(kOffB2 + 4 <= kMlpTableFloats && kMlpTableFloats % 16 == 0, "MLP table layout");
 //
 // Reset table [24][4] (host-built, staged to LDS with the gate rows): row t = (lo, hi - lo, add, mul) of the t-th
 // reset draw, value = ((lo + (hi - lo) * u) + add) * mul with separately rounded operations:
@@ -102,10 +109,15 @@ struct Params {
 #endif
 
 #ifdef QR_PHASE_TIMING
+#ifdef QR_PHASE_TIMING_NODRAIN   /* where the wave IS at each stamp (only the LDS / scalar queue drains: s_memtime returns through it) */
+#define QR_TICK_DRAIN() do { } while (0)
+#else                            /* what each phase costs in isolation: memory queues drained at every stamp */
+#define QR_TICK_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#endif
 #define QR_TICK(P, slot)                                                                      \
     do {                                                                                      \
         if (!(P).tick_on) break;                                                              \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                           \
+        QR_TICK_DRAIN();                                                                      \
         if ((P).ticks && (threadIdx.x & 63) == 0)                                             \
             (P).ticks[((size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * 16 + (slot)] = clock64(); \
     } while (0)
@@ -250,39 +262,53 @@ __device__ __forceinline__ void reset_from_stash(const Params& P, const float* _
     }
 }
 
-// Auto-reset inside the step: typically 0-2 of a wave's 64 envs terminate in a step, so instead of every done
-// lane grinding through 4-6 Philox blocks under a divergent branch (the whole wave waits), the WAVE resets one
-// done env at a time: lanes 0..5 each compute one Philox block of that env's (seed, global id, episode) stream and
-// turn it into four reset values with their own table rows; the 24 values reach the env's lane through the wave's
-// LDS tile.  Same stream, same arithmetic as reset_env() -> bit-identical values.
+// Auto-reset inside the step (kernels without the per-lane stash: the per-step kernel, the fused kernel at two workgroups per CU).
+// Typically 0-2 of a wave's 64 envs terminate in a step -- but a launch ends with its SLOWEST wave, and among the 1 024 waves of a
+// 65 536-env step a few have five or six.  Rounds 1-3 reset one done env at a time (readlane, ten dependent Philox rounds on eight
+// lanes, an LDS exchange: ~780 cycles per done env, so the unluckiest wave of a step spent ~4 k cycles here).  Now the wave resets
+// up to EIGHT envs per pass: lane j computes Philox block (j & 7) of the (j >> 3)-th done env of the pass -- the done lanes publish
+// (lane id, episode) ranked by v_mbcnt through the wave's LDS tile -- and the 24 (16) values reach each env's lane through the
+// same tile: one pass costs what one env used to, whatever the number of done envs up to eight.
+// Same stream -- (seed, global env id, episode, block) -- and same arithmetic as reset_env(): bit-identical values.
+// `tile`: >= 1 280 bytes of wave-private LDS that hold nothing live at the call.
 template <int V>
 __device__ __forceinline__ void reset_done_lanes(const Params& P, const float* __restrict__ rtab,
                                                  float* __restrict__ tile, int lane, bool done, Env<V>& e,
                                                  uint32_t gid_lo, uint32_t gid_hi) {
     constexpr int NB = (V == kE2E) ? 6 : 4;
-    unsigned long long pending = __ballot(done);
-    const int b = lane & 7;
+    const unsigned long long pending = __ballot(done);
+    if (pending == 0ull) return;                        // wave-uniform
+    uint32_t* who = reinterpret_cast<uint32_t*>(tile);  // [8] (lane id | episode << 8) of the pass's envs
+    float4* t4 = reinterpret_cast<float4*>(tile) + 16;  // [8 envs][8 blocks] reset values
+    const int b = lane & 7, s = lane >> 3;
     const float4* rows = reinterpret_cast<const float4*>(rtab) + 4 * (b < NB ? b : 0);
-    float4* t4 = reinterpret_cast<float4*>(tile);
-    while (pending) {  // wave-uniform
-        const int d = __builtin_ctzll(pending);
-        pending &= pending - 1;
-        const uint32_t g_lo = __builtin_amdgcn_readlane(gid_lo, d);
-        const uint32_t g_hi = __builtin_amdgcn_readlane(gid_hi, d);
-        const uint32_t ep = __builtin_amdgcn_readlane(e.episode, d);
-        uint32_t o[4];
-        philox4x32_10(g_lo, g_hi, ep, (uint32_t)b, P.seed_lo, P.seed_hi, o);
-        if (lane < 8)
-            t4[lane] = make_float4(reset_value(rows[0], o[0]), reset_value(rows[1], o[1]), reset_value(rows[2], o[2]),
-                                   reset_value(rows[3], o[3]));
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pending >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pending, 0u));
+    const int total = __builtin_popcountll(pending);
+    // done lanes are active lanes, and an active lane's global id is (global id of the wave's lane 0) + lane
+    const uint32_t w_lo = __builtin_amdgcn_readfirstlane(gid_lo) - (uint32_t)__builtin_amdgcn_readfirstlane(lane);
+    const uint32_t w_hi = __builtin_amdgcn_readfirstlane(gid_hi);
+    for (int base = 0; base < total; base += 8) {       // wave-uniform; one pass unless more than eight envs finished
+        const bool mine = done && rank >= base && rank < base + 8;
+        if (mine) who[rank - base] = (uint32_t)lane | (e.episode << 8);   // the episode counter has 24 bits
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane == d) {
+        const uint32_t info = who[s];                   // a slot past the pass's last env holds stale bits: computed on, never read
+        const uint32_t g_lo = w_lo + (info & 0xFFu);
+        const uint32_t g_hi = w_hi + (g_lo < w_lo ? 1u : 0u);
+        uint32_t o[4];
+        philox4x32_10(g_lo, g_hi, info >> 8, (uint32_t)b, P.seed_lo, P.seed_hi, o);
+        if (b < NB)
+            t4[8 * s + b] = make_float4(reset_value(rows[0], o[0]), reset_value(rows[1], o[1]), reset_value(rows[2], o[2]),
+                                        reset_value(rows[3], o[3]));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (mine) {
             float v[4 * NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const float4 q = t4[j];
+                const float4 q = t4[8 * (rank - base) + j];
                 v[4 * j + 0] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
             }
             assign_reset<V>(e, v);
@@ -349,33 +375,57 @@ __device__ __forceinline__ Rot make_rot(float phi, float theta, float psi) {
 // -------------------------------------------------------------------------------------------------
 // Residual thrust / moment MLPs: 7->32->1 and 10->32->3, ReLU (R:227-262).
 //
-// One lane = one env means every lane needs all 740 weights.  Feeding them as wave-uniform operands was
-// measured on MI355X (N = 65 536, one wave per SIMD): broadcast ds_read_b128 from LDS is bandwidth-bound at 16
-// unique bytes per ~4.8 cycles per CU (5.9-8.5 k of the step kernel's 18 k wave cycles, pipelined or not), and
-// scalar loads expose ~24 scalar-cache round trips (8.3 k cycles).  The first layer is a genuine small GEMM per
-// wave -- H^T[64 hidden x 64 envs] = W1[64 x 10(+bias)] * X^T[10(+1) x 64] -- so it runs on the f32 matrix core:
-// v_mfma_f32_32x32x2_f32 is bit-exactly a k-ordered fmaf chain at the f32 vector rate, and the MFMA itself
-// distributes each weight (held ONCE per wave, one float per lane per K-step) to all envs.  20 MFMAs replace
-// 544 broadcast-fed FMAs; the bias is folded in as an extra K element multiplying a constant 1.
-//   A (weights): lane l holds W1[tile row l&31][k = 2s + (l>>5)]            (tabA, loop invariant)
-//   B (inputs):  lane l holds x[k = 2s + (l>>5)] of env (tile*32 + (l&31)) -- built from the lane-per-env inputs
-//                with ONE v_permlane32_swap per input pair (gfx950), which yields both env tiles at once
-//   D: lane l, register r = hidden row (r&3) + 8*(r>>2) + 4*(l>>5) of env tile*32 + (l&31)
-// The 128 output-layer MACs stay on the VALU in that layout (each lane owns 16 hidden rows per tile) and the
-// two wave halves are combined with v_permlane32_swap, which also returns every env's result to its own lane.
+// One lane = one env means every lane needs all 740 weights.  Feeding them as wave-uniform operands was measured on MI355X
+// (N = 65 536, one wave per SIMD): broadcast ds_read_b128 from LDS is bandwidth-bound at 16 unique bytes per ~4.8 cycles per CU
+// (5.9-8.5 k of the step kernel's 18 k wave cycles, pipelined or not), scalar loads expose ~24 scalar-cache round trips (8.3 k
+// cycles).  The first layer is a genuine small GEMM per wave -- H^T[64 hidden x 64 envs] = W1[64 x 10(+bias)] * X^T -- so it runs
+// on the matrix core, which also distributes each weight (held ONCE per wave) to all envs.
+//
+// Rounds 1-3 used v_mfma_f32_32x32x2_f32 (bit-exactly a k-ordered fmaf chain): 20 instructions of 64 cycles each that run at the
+// f32 VECTOR rate and block the wave's VALU while they do (tools/ubench/valu_rate.hip: one f32 MFMA + 15 independent v_fma take
+// 153 cycles, i.e. nothing overlaps) -- 1 500 of the fused step's 5 200 cycles.  Round 4: the same layer on
+// v_mfma_f32_32x32x16_f16 (32 cycles per instruction on the separate matrix pipe) with BOTH operands split into two f16 pieces,
+//     x = X0 + X1,  X0 = f16(x), X1 = f16(x - X0)         (x - X0 is exact in f32; |x - X0 - X1| <= 2^-22 |x|)
+//     w = W0 + W1   (host side, once)
+//     w x  ~  X0 W0 + X0 W1 + X1 W0                        (the dropped X1 W1 is <= 2^-22 |w x|)
+// Every f16 x f16 product is exact in f32 and the matrix core adds the 16 products of an instruction and the accumulator with
+// <= 3.3e-8 relative error of the sum of magnitudes (tools/ubench/mfma_f16_denorm.hip; f16 subnormals are honoured on both
+// operands, so small inputs and weights lose nothing).  Against the float64 value of the layer the result is AS ACCURATE AS the f32
+// fmaf chain it replaces: on the reference's 257 fixture rows (F1) max relative output error 1.4e-6 vs 1.3e-6 for the chain
+// (tools/check_mlp_split.py; tests/test_gpu_round4.py pins both against float64).  33 products per hidden unit (thrust 7 x 3 + 2
+// bias slots, moment 10 x 3 + 2) -> 5 instructions of 16 k-slots per 32-env tile, 10 per wave-step, 320 matrix-pipe cycles.
+//   A (weights): lane l holds hidden row l&31, k-slots 8(l>>5)..+7 of instruction q (tabA, loop invariant, 5 x 4 registers)
+//   B (inputs):  lane l holds k-slots 8(l>>5)..+7 of env tile*32 + (l&31): the lane-per-env quads (4 registers = 8 f16) of the
+//                low and the high k-half meet in one v_permlane32_swap per register, which yields BOTH env tiles' operands
+//   D: lane l, register r = hidden row (r&3) + 8*(r>>2) + 4*(l>>5) of env tile*32 + (l&31)   (as before)
+// The 128 output-layer MACs stay on the VALU in that layout (each lane owns 16 hidden rows per tile) and the two wave halves are
+// combined with v_permlane32_swap, which also returns every env's result to its own lane.
 // -------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 struct MlpRegs {   // loop-invariant per-lane registers
-    float a[10];   // tabA[t][lane]
-    float w2[64];  // tabW2[lane>>5][..]
+    u32x4 a[kMlpQuads];  // tabA[q][lane] -- or, where registers decide the occupancy (the fused kernel at two workgroups per CU), read
+    const u32x4* a_lds = nullptr;   // from an LDS copy of tabA every step: five conflict-free ds_read_b128 instead of 20 registers
+    float w2[64];        // tabW2[lane>>5][..]
     float b2[4];
 };
+// stage tabA into LDS (kMlpQuads * 64 x 16 B) for MlpRegs::a_lds; the caller's barrier publishes it
+__device__ __forceinline__ void mlp_stage_a(const float* __restrict__ tab, u32x4* __restrict__ lds_a) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(tab + kOffTabA);
+    for (int i = threadIdx.x; i < kMlpQuads * 64; i += blockDim.x) lds_a[i] = src[i];
+}
 
-__device__ __forceinline__ void mlp_load_regs(const float* __restrict__ tab, int lane, MlpRegs& m) {
+__device__ __forceinline__ void mlp_load_regs(const float* __restrict__ tab, int lane, MlpRegs& m, bool a_in_regs = true) {
+    if (a_in_regs) {
+        const u32x4* a4 = reinterpret_cast<const u32x4*>(tab + kOffTabA) + lane;
 #pragma unroll
-    for (int t = 0; t < 10; ++t) m.a[t] = tab[kOffTabA + 64 * t + lane];
+        for (int q = 0; q < kMlpQuads; ++q) m.a[q] = a4[64 * q];
+    }
     const float4* w4 = reinterpret_cast<const float4*>(tab + kOffTabW2 + 64 * (lane >> 5));
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -386,11 +436,27 @@ __device__ __forceinline__ void mlp_load_regs(const float* __restrict__ tab, int
     m.b2[0] = b.x; m.b2[1] = b.y; m.b2[2] = b.z; m.b2[3] = b.w;
 }
 
-// (a, b) lane-per-env  ->  lo = {a[0..31], b[0..31]} (B operand of env tile 0), hi = {a[32..63], b[32..63]} (tile 1)
+// (a, b) lane-per-env  ->  lo = {a[0..31], b[0..31]} (operand of env tile 0), hi = {a[32..63], b[32..63]} (tile 1)
 __device__ __forceinline__ void pair_to_tiles(float a, float b, float& lo, float& hi) {
     const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     lo = __uint_as_float(r.x);
     hi = __uint_as_float(r.y);
+}
+__device__ __forceinline__ void pair_to_tiles(uint32_t a, uint32_t b, uint32_t& lo, uint32_t& hi) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    lo = r.x;
+    hi = r.y;
+}
+
+// two f32 -> one register of two f16, round to nearest even (v_cvt_pk_f16_f32), and back
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+    const f32x2v v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ void unpack_f16(uint32_t p, float& a, float& b) {
+    const f16x2 h = __builtin_bit_cast(f16x2, p);
+    a = (float)h[0];
+    b = (float)h[1];
 }
 
 // ReLU of TWO accumulator rows in ONE instruction: v_pk_mul_f32 with the CLAMP modifier, clamp(x * 2^-40) in [0, 1].  For
@@ -403,7 +469,6 @@ __device__ __forceinline__ void pair_to_tiles(float a, float b, float& lo, float
 // MFMA -> VALU read hazards: the wait states after a matrix instruction are inserted by the compiler's hazard recogniser,
 // which does not look inside inline asm.  `ready` is the result of acc_ready(): a compiler-visible VALU read of the same
 // accumulator (so the wait states are inserted before IT), and passing it in orders every relu2 of that accumulator behind it.
-typedef float f32x2v __attribute__((ext_vector_type(2)));
 constexpr float kReluDown = 0x1p-40f, kReluUp = 0x1p40f;   // tabW2 holds W2 * kReluUp
 __device__ __forceinline__ f32x2v relu2_scaled(f32x2v x, f32x2v down, uint32_t ready) {
     f32x2v r;
@@ -415,8 +480,7 @@ __device__ __forceinline__ uint32_t acc_ready(const Acc& acc) {
     return (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(acc[0]));
 }
 
-// dot(w[0..15], relu(acc[0..15])) over this lane's 16 hidden rows as four independent chains (two packed pairs), cut into 4-row
-// chunks so that the chunks can be placed between MFMAs
+// dot(w[0..15], relu(acc[0..15])) over this lane's 16 hidden rows as four independent chains (two packed pairs), in 4-row chunks
 struct DotAcc {
     f32x2v s01 = {0.0f, 0.0f}, s23 = {0.0f, 0.0f};
     __device__ __forceinline__ float sum() const { return (s01.x + s01.y) + (s23.x + s23.y); }
@@ -429,63 +493,67 @@ __device__ __forceinline__ void dot_chunk(const float* w, const f32x16& acc, int
     d.s23 = __builtin_elementwise_fma(w23, relu2_scaled(a23, down, ready), d.s23);
 }
 
+template <bool kALds = false>   // kALds: layer-1 weight operands from MlpRegs::a_lds (re-read every call) instead of MlpRegs::a
 __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const float x[10], float& thrust,
                                              float moment[3]) {
-    float b01[2], b23[2], b45[2], b67[2], b89[2], b6one[2];
-    pair_to_tiles(x[0], x[1], b01[0], b01[1]);
-    pair_to_tiles(x[2], x[3], b23[0], b23[1]);
-    pair_to_tiles(x[4], x[5], b45[0], b45[1]);
-    pair_to_tiles(x[6], x[7], b67[0], b67[1]);
-    pair_to_tiles(x[8], x[9], b89[0], b89[1]);
-    pair_to_tiles(x[6], 1.0f, b6one[0], b6one[1]);          // thrust net: k = 6 is vbz, k = 7 carries the bias
-    const float bias_sel = (lane < 32) ? 1.0f : 0.0f;        // moment net: k = 10 carries the bias, k = 11 unused
-    // Software pipeline over the two 32-env tiles.  A wave issues in order and an MFMA issued while the matrix core is
-    // still busy stalls the whole wave, so output-layer VALU work only overlaps the matrix pipe when it sits BETWEEN
-    // two MFMAs in program order.  The 20 MFMAs (20 x 64 cycles = the floor of this phase) are therefore issued as one
-    // stream and the ReLU + dot product of each finished accumulator is cut into 4-row chunks (8 VALU instructions)
-    // that are written, pinned by sched_barrier, behind the MFMAs of the NEXT accumulator.  (What the compiler makes of it:
-    // the ReLUs -- inline asm -- stay there; the fmaf()s are pure nodes and instruction selection linearises all of them
-    // behind the last MFMA, paired into v_pk_fma_f32.  Forcing them between the MFMAs as asm v_fmac_f32 was measured
-    // SLOWER, fused step 2.54 -> 2.80 us: a VALU instruction between two dependent f32 MFMAs costs more than its slot.)
-    //   thrust tile 0 (4 MFMA) | moment tile 0 (6 MFMA) + thrust-0 dot | thrust tile 1 (4) + 3 moment-0 dots
-    //   | moment tile 1 (6) + thrust-1 dot | 3 moment-1 dots (exposed)
-    // Same operations on the same operands in the same per-chain order as a plain 16-row loop -> bit-identical results.
+    // ---- split the inputs: P0 = f16 pairs of x, P1 = f16 pairs of x - X0 (exact difference) ----
+    const uint32_t p0_01 = pack_f16(x[0], x[1]), p0_23 = pack_f16(x[2], x[3]), p0_45 = pack_f16(x[4], x[5]);
+    const uint32_t p0_6o = pack_f16(x[6], 1.0f);   // k-slot 7 multiplies the bias
+    const uint32_t p0_78 = pack_f16(x[7], x[8]), p0_9z = pack_f16(x[9], 0.0f);
+    float h[12];
+    unpack_f16(p0_01, h[0], h[1]); unpack_f16(p0_23, h[2], h[3]); unpack_f16(p0_45, h[4], h[5]);
+    unpack_f16(p0_6o, h[6], h[10]); unpack_f16(p0_78, h[7], h[8]); unpack_f16(p0_9z, h[9], h[11]);
+    float r[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) r[k] = x[k] - h[k];
+    const uint32_t p1_01 = pack_f16(r[0], r[1]), p1_23 = pack_f16(r[2], r[3]), p1_45 = pack_f16(r[4], r[5]);
+    const uint32_t p1_6z = pack_f16(r[6], 0.0f), p1_78 = pack_f16(r[7], r[8]), p1_9z = pack_f16(r[9], 0.0f);
+    // ---- B operands of both env tiles: O1 = (X0 of inputs 0..6 + bias | X1 of inputs 0..6), O2 = (p, q, r terms, both halves) ----
+    uint32_t a1[4], b1[4], a2[4], b2[4];   // [k-slot pair] of tile 0 (a) / tile 1 (b)
+    pair_to_tiles(p0_01, p1_01, a1[0], b1[0]);
+    pair_to_tiles(p0_23, p1_23, a1[1], b1[1]);
+    pair_to_tiles(p0_45, p1_45, a1[2], b1[2]);
+    pair_to_tiles(p0_6o, p1_6z, a1[3], b1[3]);
+    pair_to_tiles(p0_78, p0_78, a2[0], b2[0]);
+    pair_to_tiles(p0_9z, p0_9z, a2[1], b2[1]);
+    pair_to_tiles(p1_78, p1_78, a2[2], b2[2]);
+    pair_to_tiles(p1_9z, p1_9z, a2[3], b2[3]);
+    const u32x4 o1[2] = {{a1[0], a1[1], a1[2], a1[3]}, {b1[0], b1[1], b1[2], b1[3]}};
+    const u32x4 o2[2] = {{a2[0], a2[1], a2[2], a2[3]}, {b2[0], b2[1], b2[2], b2[3]}};
     const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    f32x16 hT0 = zero, hM0 = zero, hT1 = zero, hM1 = zero;
-    DotAcc dT0, dT1, dM0[3], dM1[3];
-#define QR_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, ACC, 0, 0, 0)
-#define QR_PIN() __builtin_amdgcn_sched_barrier(0)
-    QR_MFMA(hT0, m.a[0], b01[0]); QR_MFMA(hT0, m.a[1], b23[0]); QR_MFMA(hT0, m.a[2], b45[0]); QR_MFMA(hT0, m.a[3], b6one[0]);
-    QR_PIN();
-    QR_MFMA(hM0, m.a[4], b01[0]); const uint32_t rT0 = acc_ready(hT0); QR_PIN();
-    QR_MFMA(hM0, m.a[5], b23[0]); dot_chunk(m.w2 + 0, hT0, 0, dT0, rT0); QR_PIN();
-    QR_MFMA(hM0, m.a[6], b45[0]); dot_chunk(m.w2 + 0, hT0, 4, dT0, rT0); QR_PIN();
-    QR_MFMA(hM0, m.a[7], b67[0]); dot_chunk(m.w2 + 0, hT0, 8, dT0, rT0); QR_PIN();
-    QR_MFMA(hM0, m.a[8], b89[0]); dot_chunk(m.w2 + 0, hT0, 12, dT0, rT0); QR_PIN();
-    QR_MFMA(hM0, m.a[9], bias_sel); QR_PIN();
-    QR_MFMA(hT1, m.a[0], b01[1]); const uint32_t rM0 = acc_ready(hM0); QR_PIN();
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {  // MFMA g + 1 of thrust tile 1 hosts moment-0 output g (4 chunks = 32 VALU)
-        if (g == 0) QR_MFMA(hT1, m.a[1], b23[1]);
-        if (g == 1) QR_MFMA(hT1, m.a[2], b45[1]);
-        if (g == 2) QR_MFMA(hT1, m.a[3], b6one[1]);
-#pragma unroll
-        for (int r = 0; r < 16; r += 4) dot_chunk(m.w2 + 16 + 16 * g, hM0, r, dM0[g], rM0);
-        QR_PIN();
+    f32x16 hT0, hM0, hT1, hM1;
+    u32x4 aq0, aq1, aq2, aq3, aq4;
+    if constexpr (kALds) {
+        int li = lane;
+        asm volatile("" : "+v"(li));   // opaque per call: keeps the five reads INSIDE the step loop (hoisted, they are 20 registers again)
+        aq0 = m.a_lds[li]; aq1 = m.a_lds[64 + li]; aq2 = m.a_lds[128 + li]; aq3 = m.a_lds[192 + li]; aq4 = m.a_lds[256 + li];
+    } else {
+        aq0 = m.a[0]; aq1 = m.a[1]; aq2 = m.a[2]; aq3 = m.a[3]; aq4 = m.a[4];
     }
-    QR_MFMA(hM1, m.a[4], b01[1]); const uint32_t rT1 = acc_ready(hT1); QR_PIN();
-    QR_MFMA(hM1, m.a[5], b23[1]); dot_chunk(m.w2 + 0, hT1, 0, dT1, rT1); QR_PIN();
-    QR_MFMA(hM1, m.a[6], b45[1]); dot_chunk(m.w2 + 0, hT1, 4, dT1, rT1); QR_PIN();
-    QR_MFMA(hM1, m.a[7], b67[1]); dot_chunk(m.w2 + 0, hT1, 8, dT1, rT1); QR_PIN();
-    QR_MFMA(hM1, m.a[8], b89[1]); dot_chunk(m.w2 + 0, hT1, 12, dT1, rT1); QR_PIN();
-    QR_MFMA(hM1, m.a[9], bias_sel); QR_PIN();
+#define QR_MFMA(ACC, Q, B, C) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq##Q), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
+    // ten instructions on four accumulators, round robin: an accumulator's next instruction is three others (>= 96 cycles) away
+    QR_MFMA(hT0, 0, o1[0], zero); QR_MFMA(hM0, 2, o1[0], zero); QR_MFMA(hT1, 0, o1[1], zero); QR_MFMA(hM1, 2, o1[1], zero);
+    // instructions 1 / 3 (the W1 pieces) read the same operand: their high k-half weights are zero
+    QR_MFMA(hT0, 1, o1[0], hT0); QR_MFMA(hM0, 3, o1[0], hM0); QR_MFMA(hT1, 1, o1[1], hT1); QR_MFMA(hM1, 3, o1[1], hM1);
+    QR_MFMA(hM0, 4, o2[0], hM0); QR_MFMA(hM1, 4, o2[1], hM1);
+#undef QR_MFMA
+    DotAcc dT0, dT1, dM0[3], dM1[3];
+    const uint32_t rT0 = acc_ready(hT0);
+#pragma unroll
+    for (int q = 0; q < 16; q += 4) dot_chunk(m.w2 + 0, hT0, q, dT0, rT0);
+    const uint32_t rT1 = acc_ready(hT1);
+#pragma unroll
+    for (int q = 0; q < 16; q += 4) dot_chunk(m.w2 + 0, hT1, q, dT1, rT1);
+    const uint32_t rM0 = acc_ready(hM0);
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) dot_chunk(m.w2 + 16 + 16 * g, hM0, q, dM0[g], rM0);
     const uint32_t rM1 = acc_ready(hM1);
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; r += 4) dot_chunk(m.w2 + 16 + 16 * g, hM1, r, dM1[g], rM1);
-#undef QR_MFMA
-#undef QR_PIN
+        for (int q = 0; q < 16; q += 4) dot_chunk(m.w2 + 16 + 16 * g, hM1, q, dM1[g], rM1);
     float part[2][4];
     part[0][0] = dT0.sum();
     part[1][0] = dT1.sum();
@@ -594,12 +662,38 @@ __device__ __forceinline__ void eom_indi(const float* s, const Rot& R, const flo
 // -------------------------------------------------------------------------------------------------
 // Gate-frame observation of one env (update_states_gate, R:365-450 / I:218-265) into o[obs_len]
 // -------------------------------------------------------------------------------------------------
+// the target gate's table row as a step / an observation uses it, and the rows of the gates ahead
+struct GateRow {
+    float4 g0;   // x y z yaw
+    float2 cs;   // cos(yaw) sin(yaw)
+};
+__device__ __forceinline__ GateRow read_gate_row(const float* __restrict__ gates, int target) {
+    GateRow g;
+    const float* row = gates + __mul24(kGateStride, target);
+    g.g0 = *reinterpret_cast<const float4*>(row);
+    g.cs = *reinterpret_cast<const float2*>(row + 4);
+    return g;
+}
+// relative position / yaw of the GA gates after `target` (R:406-412), indices modulo the gate count
+template <int GA>
+__device__ __forceinline__ void read_gates_ahead(const Params& P, const float* __restrict__ gates, int target, float4* rel) {
+#pragma unroll
+    for (int a = 0; a < GA; ++a) {
+        int idx = target + a + 1;
+        // target < num_gates, so one conditional subtraction suffices unless the track has fewer gates than a + 1 (wave-uniform)
+        if (idx >= P.num_gates) idx -= P.num_gates;
+        if (P.num_gates <= a) {
+            while (idx >= P.num_gates) idx -= P.num_gates;
+        }
+        rel[a] = *reinterpret_cast<const float4*>(gates + __mul24(kGateStride, idx) + 8);
+    }
+}
+
 template <int V, int GA>
-__device__ __forceinline__ void observe(const Params& P, const float* __restrict__ gates, const Env<V>& e,
-                                        float* o) {
+__device__ __forceinline__ void observe_with(const Params& P, const GateRow& g, const float4* rel, const Env<V>& e, float* o) {
     constexpr int S = Env<V>::S;
-    const float4 g0 = *reinterpret_cast<const float4*>(gates + kGateStride * e.target);      // x y z yaw
-    const float2 cs = *reinterpret_cast<const float2*>(gates + kGateStride * e.target + 4);  // cos sin
+    const float4 g0 = g.g0;
+    const float2 cs = g.cs;
     const float dx = e.s[0] - g0.x, dy = e.s[1] - g0.y;
     o[0] = fmaf(dx, cs.x, dy * cs.y);            // R:380-382
     o[1] = fmaf(dy, cs.x, -(dx * cs.y));
@@ -623,13 +717,10 @@ __device__ __forceinline__ void observe(const Params& P, const float* __restrict
     for (int i = 9; i < S; ++i) o[i] = e.s[i];
 #pragma unroll
     for (int a = 0; a < GA; ++a) {  // R:406-412
-        int idx = e.target + a + 1;
-        while (idx >= P.num_gates) idx -= P.num_gates;
-        const float4 rel = *reinterpret_cast<const float4*>(gates + kGateStride * idx + 8);
-        o[S + 4 * a + 0] = rel.x;
-        o[S + 4 * a + 1] = rel.y;
-        o[S + 4 * a + 2] = rel.z;
-        o[S + 4 * a + 3] = rel.w;
+        o[S + 4 * a + 0] = rel[a].x;
+        o[S + 4 * a + 1] = rel[a].y;
+        o[S + 4 * a + 2] = rel[a].z;
+        o[S + 4 * a + 3] = rel[a].w;
     }
     if constexpr (V == kE2E) {  // R:414-448: (Mx, My, Mz, Fz) mapped to [-1,1] by their ranges
         constexpr int base = S + 4 * GA;
@@ -639,6 +730,14 @@ __device__ __forceinline__ void observe(const Params& P, const float* __restrict
             o[base + c] = fmaf(2.0f * (e.d[col[c]] - P.obs_lo[c]), P.obs_inv[c], -1.0f);
     }
 }
+template <int V, int GA>
+__device__ __forceinline__ void observe(const Params& P, const float* __restrict__ gates, const Env<V>& e,
+                                        float* o) {
+    const GateRow g = read_gate_row(gates, e.target);
+    float4 rel[GA > 0 ? GA : 1];
+    read_gates_ahead<GA>(P, gates, e.target, rel);
+    observe_with<V, GA>(P, g, rel, e, o);
+}
 
 // -------------------------------------------------------------------------------------------------
 // One env step (step_wait, R:501-595 / I:303-385).  Returns reward; sets done / trunc flags.
@@ -647,12 +746,11 @@ __device__ __forceinline__ void observe(const Params& P, const float* __restrict
 // `before_reset(done)` is invoked (all lanes) after the state update and before the auto-reset -- the caller's hook
 // for the terminal observation SB3 bootstraps time-limit truncations from (R:589-594).
 // `do_reset(need)` performs the auto-reset of the lanes with `need` (all lanes call it); the default is reset_done_lanes().
-template <int V, class BeforeReset, class DoReset>
-__device__ __forceinline__ float step_env(const Params& P, const float* __restrict__ gates,
-                                          const float* __restrict__ rtab, float* __restrict__ tile, const MlpRegs& mlp,
-                                          int lane, bool active, Env<V>& e, const float u[4], uint32_t gid_lo,
-                                          uint32_t gid_hi, bool& done, bool& trunc, bool& did_reset,
-                                          BeforeReset&& before_reset, DoReset&& do_reset) {
+// the arithmetic of one step from the pre-step state: new state `nw`, reward, flags, the target after the step
+template <int V, bool kALds = false>
+__device__ __forceinline__ float step_dynamics(const Params& P, const GateRow& gate, const MlpRegs& mlp, bool use_mlp, int lane,
+                                               const Env<V>& e, const float u[4], float* nw, int& new_target, bool& done,
+                                               bool& trunc) {
     constexpr int S = Env<V>::S;
     const Rot R = make_rot(e.s[6], e.s[7], e.s[8]);
     QR_TICK(P, 3);
@@ -664,10 +762,10 @@ __device__ __forceinline__ float step_env(const Params& P, const float* __restri
     if constexpr (V == kE2E) {
         float M[3] = {e.d[0], e.d[1], e.d[2]};
         float F[3] = {e.d[3], e.d[4], e.d[5]};
-        if (P.flags & kFlagResidual) {  // R:502-509: residual evaluated on the PRE-step state
+        if (use_mlp) {  // R:502-509: residual evaluated on the PRE-step state
             const float x[10] = {e.s[12], e.s[13], e.s[14], e.s[15], vb[0], vb[1], vb[2], e.s[9], e.s[10], e.s[11]};
             float thrust, moment[3];
-            residual_mlp(mlp, lane, x, thrust, moment);
+            residual_mlp<kALds>(mlp, lane, x, thrust, moment);
             M[0] += moment[0]; M[1] += moment[1]; M[2] += moment[2];
             F[2] += thrust;
         }
@@ -676,13 +774,12 @@ __device__ __forceinline__ float step_env(const Params& P, const float* __restri
     } else {
         eom_indi(e.s, R, vb, u, ds);
     }
-    float nw[S];
 #pragma unroll
     for (int k = 0; k < S; ++k) nw[k] = fmaf(P.dt, ds[k], e.s[k]);  // forward Euler, R:512
     const int steps = e.steps + 1;                                   // R:514
 
-    const float4 g0 = *reinterpret_cast<const float4*>(gates + kGateStride * e.target);      // R:518-519
-    const float2 cs = *reinterpret_cast<const float2*>(gates + kGateStride * e.target + 4);
+    const float4 g0 = gate.g0;                                       // R:518-519
+    const float2 cs = gate.cs;
     const float ox = e.s[0] - g0.x, oy = e.s[1] - g0.y, oz = e.s[2] - g0.z;
     const float nx = nw[0] - g0.x, ny = nw[1] - g0.y, nz = nw[2] - g0.z;
     const float d2g_old = fast_sqrt(fmaf(ox, ox, fmaf(oy, oy, oz * oz)));  // R:522-525
@@ -702,9 +799,25 @@ __device__ __forceinline__ float step_env(const Params& P, const float* __restri
                      (fabsf(nw[10]) > 1000.0f) || (fabsf(nw[11]) > 1000.0f);           // R:549-550
     if (oob) reward = -10.0f;
     trunc = steps >= P.max_steps;                                   // R:553
-    if (gate_passed) e.target = (e.target + 1 == P.num_gates) ? 0 : e.target + 1;      // R:556-557
+    new_target = e.target;
+    if (gate_passed) new_target = (e.target + 1 == P.num_gates) ? 0 : e.target + 1;    // R:556-557
     done = trunc || ground || gate_collision || oob;                // R:566
-    e.steps = steps;
+    return reward;
+}
+
+template <int V, bool kALds = false, class BeforeReset, class DoReset>
+__device__ __forceinline__ float step_env(const Params& P, const float* __restrict__ gates,
+                                          const float* __restrict__ rtab, float* __restrict__ tile, const MlpRegs& mlp,
+                                          int lane, bool active, Env<V>& e, const float u[4], uint32_t gid_lo,
+                                          uint32_t gid_hi, bool& done, bool& trunc, bool& did_reset,
+                                          BeforeReset&& before_reset, DoReset&& do_reset) {
+    constexpr int S = Env<V>::S;
+    float nw[S];
+    int new_target;
+    const GateRow gate = read_gate_row(gates, e.target);
+    const float reward = step_dynamics<V, kALds>(P, gate, mlp, (V == kE2E) && (P.flags & kFlagResidual), lane, e, u, nw, new_target, done, trunc);
+    e.target = new_target;
+    e.steps = e.steps + 1;
     did_reset = false;
     QR_TICK(P, 5);
     if (P.flags & kFlagPause) {                                     // R:570-572: state not advanced
@@ -729,7 +842,7 @@ __device__ __forceinline__ float step_env(const Params& P, const float* __restri
                                           int lane, bool active, Env<V>& e, const float u[4], uint32_t gid_lo,
                                           uint32_t gid_hi, bool& done, bool& trunc, bool& did_reset,
                                           BeforeReset&& before_reset) {
-    return step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc, did_reset,
+    return step_env<V, false>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc, did_reset,
                        static_cast<BeforeReset&&>(before_reset),
                        [&](bool need) { reset_done_lanes<V>(P, rtab, tile, lane, need, e, gid_lo, gid_hi); });
 }

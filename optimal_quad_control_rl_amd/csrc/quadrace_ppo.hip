@@ -240,6 +240,10 @@ __global__ void __launch_bounds__(256) ppo_shuffle_kernel(int* __restrict__ perm
 // Clears the advantage-sum table ahead of ppo_adv_stats_kernel.  A KERNEL, not hipMemsetAsync: inside qr_ppo_epoch's captured graph
 // a memset node was seen to lose its ordering against the kernel nodes around it on REPLAY (ROCm 7.2: whole epochs whose sums
 // were cleared mid-accumulation -> non-finite gradients, every update of the epoch skipped; tests/test_gpu_round2.py config-5 loop).
+// PpoCtrl::lr <- lr (qr_ppo_epoch): a kernel node, not a host-to-device copy -- the value travels in the kernel arguments, so nothing on
+// the host has to outlive the launch, and captured into a caller's graph the node replays the value it was captured with
+__global__ void ppo_set_lr_kernel(float* __restrict__ dst, float lr) { *dst = lr; }
+
 __global__ void __launch_bounds__(256) ppo_zero_table_kernel(double* __restrict__ table, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) table[i] = 0.0;
@@ -277,7 +281,7 @@ struct PpoCtrl {
     // (qr_ppo_epoch) -- and so that the Adam step count advances only when a step was really TAKEN (a launch turned into a no-op by
     // the early stop or a non-finite norm does not count: torch.optim.Adam / SB3 count real steps).
     int adam_t;                   // optimiser steps taken over the life of the parameters (bias correction uses adam_t + 1)
-    float lr;                     // learning rate of launches that pass lr < 0 ("read it from the device")
+    float lr;                     // learning rate of the launches qr_ppo_epoch enqueues (ApplyArgs::device_lr)
     unsigned long long shuffle_count;   // epochs shuffled on the device so far (ppo_shuffle_kernel's stream position)
 };
 constexpr unsigned int kGoStop = 0x40000000u, kGoNonFinite = 0x80000000u, kGoGenMask = 0x3FFFFFFFu;
@@ -2189,7 +2193,6 @@ struct qr_ppo {
         float clip = 0, vf_coef = 0, ent_coef = 0, max_grad_norm = 0, beta1 = 0, beta2 = 0, eps = 0, target_kl = 0;
     } eg;
     hipStream_t capture_stream = nullptr;
-    float lr_host = 0.0f;          // source of the asynchronous copy into PpoCtrl::lr (must outlive the call)
     unsigned long long shuffle_seed = 0;   // key of the on-device epoch permutations (qr_ppo_shuffle_state)
 };
 
@@ -2355,11 +2358,12 @@ int fill_batch(qr_ppo* p, qr::PpoBatch& b, const float* theta, const float* obs,
 }
 
 // adam_step >= 1: the caller counts the steps (bias corrections computed here); adam_step == 0: the device's own count of steps
-// really taken (PpoCtrl::adam_t).  lr >= 0: this value; lr < 0: PpoCtrl::lr (set by qr_ppo_epoch / qr_ppo_set_lr).
-void adam_constants(qr::ApplyArgs& a, float max_grad_norm, float lr, float beta1, float beta2, float eps, int adam_step) {
+// really taken (PpoCtrl::adam_t).  device_lr: the learning rate is PpoCtrl::lr (qr_ppo_epoch writes it; library-internal mode --
+// the extern "C" entry points take lr >= 0 and reject anything else).
+void adam_constants(qr::ApplyArgs& a, float max_grad_norm, float lr, bool device_lr, float beta1, float beta2, float eps, int adam_step) {
     a.max_norm = max_grad_norm; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.device_step = adam_step == 0;
-    a.device_lr = lr < 0.0f;
+    a.device_lr = device_lr ? 1 : 0;
     const int t = adam_step > 0 ? adam_step : 1;
     a.bc1 = 1.0f - powf(beta1, (float)t);
     a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)t));
@@ -2520,10 +2524,10 @@ int qr_ppo_grad(qr_ppo* p, const float* theta_dev, const float* obs_dev, const f
     });
 }
 
-int qr_ppo_minibatch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_dev, const float* obs_dev, const float* act_dev,
-                     const float* old_logp_dev, const float* adv_dev, const float* ret_dev, const int32_t* idx_dev, int32_t B,
-                     float clip, float vf_coef, float ent_coef, float max_grad_norm, float lr, float beta1, float beta2, float eps,
-                     int32_t adam_step, float* stats_dev, void* stream) {
+static int ppo_minibatch_impl(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_dev, const float* obs_dev, const float* act_dev,
+                              const float* old_logp_dev, const float* adv_dev, const float* ret_dev, const int32_t* idx_dev, int32_t B,
+                              float clip, float vf_coef, float ent_coef, float max_grad_norm, float lr, bool device_lr, float beta1,
+                              float beta2, float eps, int32_t adam_step, float* stats_dev, void* stream) {
     qr::PpoBatch b;
     if (int rc = fill_batch(p, b, theta_dev, obs_dev, act_dev, old_logp_dev, adv_dev, ret_dev, idx_dev, B, clip, vf_coef, ent_coef, stats_dev))
         return rc;
@@ -2543,9 +2547,18 @@ int qr_ppo_minibatch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam
         a.stats = stats_dev;
         a.kl_limit = p->target_kl > 0.0f ? 1.5f * p->target_kl * (float)B : 0.0f;
         a.take_step = 1;
-        adam_constants(a, max_grad_norm, lr, beta1, beta2, eps, adam_step);
+        adam_constants(a, max_grad_norm, lr, device_lr, beta1, beta2, eps, adam_step);
         return PpoOps<L>::apply(p, a, st);
     });
+}
+
+int qr_ppo_minibatch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_dev, const float* obs_dev, const float* act_dev,
+                     const float* old_logp_dev, const float* adv_dev, const float* ret_dev, const int32_t* idx_dev, int32_t B,
+                     float clip, float vf_coef, float ent_coef, float max_grad_norm, float lr, float beta1, float beta2, float eps,
+                     int32_t adam_step, float* stats_dev, void* stream) {
+    if (!(lr >= 0.0f)) return ppofail(QR_E_INVALID, "qr_ppo_minibatch: the learning rate must be >= 0");
+    return ppo_minibatch_impl(p, theta_dev, adam_m_dev, adam_v_dev, obs_dev, act_dev, old_logp_dev, adv_dev, ret_dev, idx_dev, B, clip,
+                              vf_coef, ent_coef, max_grad_norm, lr, false, beta1, beta2, eps, adam_step, stats_dev, stream);
 }
 
 // Data-parallel training: every rank calls qr_ppo_grad on its shard of the minibatch, the caller averages the [n + 4] vector
@@ -2553,8 +2566,8 @@ int qr_ppo_minibatch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam
 // including the same target-KL decision, because the KL sum travels with the gradient.
 int qr_ppo_apply(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_dev, float* grad_dev, int32_t B, float max_grad_norm,
                  float lr, float beta1, float beta2, float eps, int32_t adam_step, float* stats_dev, void* stream) {
-    if (!p || !theta_dev || !adam_m_dev || !adam_v_dev || !grad_dev || adam_step < 0 || B < 1)
-        return ppofail(QR_E_INVALID, "qr_ppo_apply: bad argument");
+    if (!p || !theta_dev || !adam_m_dev || !adam_v_dev || !grad_dev || adam_step < 0 || B < 1 || !(lr >= 0.0f))
+        return ppofail(QR_E_INVALID, "qr_ppo_apply: bad argument (null pointer, adam_step < 0, B < 1 or a learning rate below 0)");
     PPO_HIP(hipSetDevice(p->device));
     p->packed_theta = theta_dev;
     hipStream_t st = (hipStream_t)stream;
@@ -2566,7 +2579,7 @@ int qr_ppo_apply(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_d
         a.stats = stats_dev;
         a.kl_limit = p->target_kl > 0.0f ? 1.5f * p->target_kl * (float)B : 0.0f;
         a.take_step = 1;
-        adam_constants(a, max_grad_norm, lr, beta1, beta2, eps, adam_step);
+        adam_constants(a, max_grad_norm, lr, false, beta1, beta2, eps, adam_step);
         return PpoOps<L>::apply(p, a, st);
     });
 }
@@ -2620,9 +2633,11 @@ int qr_ppo_epoch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_d
     hipStream_t st = (hipStream_t)stream;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool caller_captures = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-    // the learning rate travels through device memory (it may follow a schedule; the captured nodes read PpoCtrl::lr)
-    p->lr_host = lr;
-    PPO_HIP(hipMemcpyAsync(&p->d_ctrl->lr, &p->lr_host, sizeof(float), hipMemcpyHostToDevice, st));
+    // the learning rate travels through device memory (it may follow a schedule; the epoch graph's nodes read PpoCtrl::lr).  Written by
+    // a one-thread kernel: when the CALLER captures `st`, this node carries the value of the capturing call (lr is frozen into that
+    // graph, like every other scalar argument of the call).
+    hipLaunchKernelGGL(qr::ppo_set_lr_kernel, dim3(1), dim3(1), 0, st, &p->d_ctrl->lr, lr);
+    PPO_HIP(hipGetLastError());
     p->packed_theta = theta_dev;
     // per-device kernel attributes are set outside the capture (not a stream operation)
     if (int rc = dispatch_L(p->L, [&](auto Lc) { return PpoOps<decltype(Lc)::value>::configure(p); })) return rc;
@@ -2637,9 +2652,9 @@ int qr_ppo_epoch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_d
             if (int rc = epoch_begin_impl(p, adv_dev, perm_dev, B, num_minibatches, s, device_shuffle ? &p->d_ctrl->shuffle_count : nullptr))
                 return rc;
             for (int k = 0; k < num_minibatches; ++k)
-                if (int rc = qr_ppo_minibatch(p, theta_dev, adam_m_dev, adam_v_dev, obs_dev, act_dev, old_logp_dev, adv_dev, ret_dev,
-                                              perm_dev + (size_t)k * B, B, clip, vf_coef, ent_coef, max_grad_norm, -1.0f, beta1, beta2,
-                                              eps, 0, stats_dev, s))
+                if (int rc = ppo_minibatch_impl(p, theta_dev, adam_m_dev, adam_v_dev, obs_dev, act_dev, old_logp_dev, adv_dev, ret_dev,
+                                                perm_dev + (size_t)k * B, B, clip, vf_coef, ent_coef, max_grad_norm, 0.0f, true, beta1,
+                                                beta2, eps, 0, stats_dev, s))
                     return rc;
         }
         return QR_OK;

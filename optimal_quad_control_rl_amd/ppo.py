@@ -320,6 +320,10 @@ class PPO:
             self._updater.set_shuffle(0x5EED0000 + int(seed))   # on-device epoch permutations (single-process native update)
         self.fused_collect = fused_collect
         self.noise_seed = seed
+        # position in the action-noise stream, in env steps: counts every step ever collected and is NOT reset with num_timesteps
+        # (SB3's learn(reset_num_timesteps=True) resets its counter, not its RNG: a second learn() must not replay the first one's
+        # noise -- ADVICE r03)
+        self.noise_step = 0
         self._mfma = None
         if fused_collect:
             from .policy import MfmaPolicy
@@ -351,7 +355,8 @@ class PPO:
     @torch.no_grad()
     def collect_fused(self):
         self._mfma.load_torch(self.policy.pi)
-        first_step = self.num_timesteps // self.n_envs
+        first_step = self.noise_step
+        self.noise_step += self.n_steps
         obs, act, logp, rew, done, trunc, last_obs = self.env.rollout_policy_device(
             self._mfma, self.n_steps, self.policy.log_std, noise_seed=self.noise_seed, first_step=first_step,
             out=(self.buf_obs, self.buf_act, self.buf_lp, self.buf_rew, self._done_u8, self._trunc_u8))
@@ -627,7 +632,7 @@ class PPO:
         env = dict(world=world.cpu(), dist=None if dist is None else dist.cpu(), target=target.cpu(), steps=steps.cpu(),
                    episode=episode.cpu())
         return dict(optimizer=opt, num_timesteps=int(self.num_timesteps), ep_ret=self.ep_ret.cpu(), ep_len=self.ep_len.cpu(),
-                    ep_gates=self.ep_gates.cpu(), stats=dict(self.stats), noise_seed=int(self.noise_seed),
+                    ep_gates=self.ep_gates.cpu(), stats=dict(self.stats), noise_seed=int(self.noise_seed), noise_step=int(self.noise_step),
                     lr0=float(self.lr0), lr_final_frac=float(self.lr_final_frac), total_hint=self.total_hint,
                     kl_trips=int(getattr(self, "_kl_first_trips", 0)), kl_lr_scale=float(getattr(self, "_kl_lr_scale", 1.0)), env=env, rng=self._gen.get_state())
 
@@ -651,6 +656,7 @@ class PPO:
         self.ep_ret.copy_(sd["ep_ret"]); self.ep_len.copy_(sd["ep_len"]); self.ep_gates.copy_(sd["ep_gates"])
         self.stats = dict(sd["stats"])
         self.noise_seed = int(sd["noise_seed"])
+        self.noise_step = int(sd.get("noise_step", self.num_timesteps // self.n_envs))   # older checkpoints: derived from the step count
         self.lr0, self.lr_final_frac, self.total_hint = float(sd["lr0"]), float(sd["lr_final_frac"]), sd["total_hint"]
         self._kl_first_trips = int(sd.get("kl_trips", 0))
         self._kl_lr_scale = float(sd.get("kl_lr_scale", 1.0))

@@ -207,7 +207,13 @@ class PPO:
             from .ppo import PPO as Trainer
 
             rows = core.num_envs * self.n_steps
-            shapes_ok = tuple(self.net_arch) == (120, 120, 120) and self.batch_size >= 64 and rows % self.batch_size == 0
+            # the matrix-core update: the reference's 3 x 120 networks, whole minibatches of >= 64 rows, and at most 4 096 minibatches
+            # per epoch (qr_ppo_epoch's limit; all epochs of a train() are one graph of ~2 x minibatches x epochs kernel nodes, kept
+            # below 32 768 nodes) -- anything else, e.g. SB3's own defaults batch_size=64 x n_steps=2048 on > 128 envs, takes the
+            # torch update on the same device tensors instead of failing inside learn()
+            minibatches = rows // self.batch_size if self.batch_size > 0 else 0
+            shapes_ok = (tuple(self.net_arch) == (120, 120, 120) and self.batch_size >= 64 and rows % self.batch_size == 0
+                         and minibatches <= 4096 and minibatches * self.n_epochs <= 16384)
             native = shapes_ok if native_update == "auto" else bool(native_update)
             fused = (tuple(self.net_arch) == (120, 120, 120)) if fused_collect == "auto" else bool(fused_collect)
             self._trainer = Trainer(core, n_steps=self.n_steps, batch_size=self.batch_size, n_epochs=self.n_epochs,
@@ -309,20 +315,27 @@ class PPO:
             path += ".zip"
         with zipfile.ZipFile(path) as z:
             data = json.loads(z.read("data"))
+            # everything is validated BEFORE a model (and, with an env, its GPU buffers) is built
+            if data.get("format_version") != FORMAT_VERSION:
+                raise ValueError("checkpoint format version %r, this build reads %d" % (data.get("format_version"), FORMAT_VERSION))
+            if env is not None and _unwrap(env).state_len != data["observation_dim"]:
+                raise ValueError("checkpoint and env disagree on the observation length")
             names = set(z.namelist())
-            rd = lambda n: torch.load(io.BytesIO(z.read(n)), map_location="cpu", weights_only=False)  # noqa: E731
+            # the members hold tensors, dicts, tuples and scalars only: the restricted unpickler is enough, and a downloaded
+            # checkpoint cannot run code
+            rd = lambda n: torch.load(io.BytesIO(z.read(n)), map_location="cpu", weights_only=True)  # noqa: E731
             policy_sd = rd("policy.pth")
             opt = rd("policy.optimizer.pth") if "policy.optimizer.pth" in names else None
             trainer_state = rd("trainer_state.pth") if "trainer_state.pth" in names else None
-        assert data["format_version"] == FORMAT_VERSION, data["format_version"]
         hyper = {k: data[k] for k in ("learning_rate", "n_steps", "batch_size", "n_epochs", "gamma", "gae_lambda", "clip_range",
                                       "ent_coef", "vf_coef", "max_grad_norm", "target_kl")}
+        kwargs = dict(kwargs)
+        seed = kwargs.pop("seed", data["seed"])           # explicit keywords win over the checkpoint's, without colliding with it
+        device = kwargs.pop("device", device)
         hyper.update(kwargs)
         pk = dict(activation_fn=nn.ReLU, net_arch=dict(pi=data["net_arch"], vf=data["net_arch"]), log_std_init=data["log_std_init"])
-        model = cls("MlpPolicy", env, policy_kwargs=pk, seed=data["seed"], device=device,
+        model = cls("MlpPolicy", env, policy_kwargs=pk, seed=seed, device=device,
                     observation_dim=data["observation_dim"], **hyper)
-        if env is not None and _unwrap(env).state_len != data["observation_dim"]:
-            raise ValueError("checkpoint and env disagree on the observation length")
         model.policy.load_state_dict({k: v.to(model.device) for k, v in policy_sd.items()})
         model._num_timesteps = int(data["num_timesteps"])
         if model._trainer is not None:

@@ -363,13 +363,21 @@ class Quadcopter3DGates(_Base):
     @property
     def states(self):
         """Observation array [N, state_len] of the last reset()/step() (R:343, read by animate_policy R:803)."""
-        return self._last_obs.cpu().numpy()
+        return self._current_obs().cpu().numpy()
 
     @property
     def states_tensor(self):
-        """The current observation on the device.  After rollout_device / step_sequence_device this is a VIEW of the last row of
-        the rollout buffer that call wrote (valid until that buffer is overwritten); otherwise the env's own buffer."""
-        return self._last_obs
+        """The current observation on the device: always the env's OWN buffer.  A K-step call (rollout_device /
+        step_sequence_device) leaves its last observation in row K-1 of the caller's rollout buffer and does not copy it (that copy
+        was a 6 MB kernel behind every rollout); the FIRST read here takes the copy, so readers get a stable buffer that later
+        reuse of the rollout buffer cannot change.  Read it before overwriting that buffer yourself."""
+        return self._current_obs()
+
+    def _current_obs(self):
+        if self._last_obs is not self._obs:     # first read after a K-step call: row K-1 of the caller's buffer -> own buffer
+            self._obs.copy_(self._last_obs)
+            self._last_obs = self._obs
+        return self._obs
 
     # ------------------------------------------------------------------ reference methods
     def update_states(self):

@@ -159,14 +159,22 @@ def test_integer_attributes_are_int64_like_the_reference(PA):
 
 
 def test_states_tensor_tracks_the_rollout_buffer_without_a_copy(PA, residual_blob):
+    """A K-step call leaves its last observation in row K-1 of the caller's buffer and launches NO copy; the first read of
+    `states` / `states_tensor` takes a stable copy into the env's own buffer (readers must not see later reuse of the
+    rollout buffer)."""
     g = PA(E2E, 1024, P.tracks()["zigzag"], gates_ahead=1, residual=residual_blob, dist_ranges=P.TRAIN_DIST_RANGES)
     env = g.env
     first = env.reset_device().clone()
     assert torch.equal(env.states_tensor, first)
     acts = torch.rand((5, 1024, 4), device=env.device) * 2 - 1
     obs, rew, done, trunc = env.rollout_device(acts)
-    assert env.states_tensor.data_ptr() == obs[4].data_ptr()               # a view of row K-1, no copy kernel
-    np.testing.assert_array_equal(env.states, obs[4].cpu().numpy())
+    assert env._last_obs.data_ptr() == obs[4].data_ptr()                   # still a view of row K-1: no copy kernel behind the rollout
+    last = obs[4].clone()
+    st = env.states_tensor                                                 # first read: the stable copy
+    assert st.data_ptr() != obs[4].data_ptr() and torch.equal(st, last)
+    obs.zero_()                                                            # the caller reuses its rollout buffer ...
+    assert torch.equal(env.states_tensor, last)                            # ... and the env's current observation is unaffected
+    np.testing.assert_array_equal(env.states, last.cpu().numpy())
     o2, *_ = env.step_device(acts[0].contiguous())
     assert env.states_tensor.data_ptr() == o2.data_ptr()
     env.update_states()

@@ -22,19 +22,20 @@ extra = os.environ.get("QR_PROBE_FLAGS", "").split()
 tag = os.environ.get("QR_PROBE_TAG", "")
 dbg = os.path.join(B.PKG, "_dbg", "libquadrace_clk%s.so" % tag)   # travels with the snapshot when built in the container
 os.makedirs(os.path.dirname(dbg), exist_ok=True)
-deps = [os.path.join(B.CSRC, h) for h in B.HEADERS]
+CSRC = os.environ.get("QR_PROBE_CSRC", B.CSRC)   # A/B against another checkout of the sources (same box, same call)
+deps = [os.path.join(CSRC, h) for h in B.HEADERS]
 flags = ["-DQR_CLOCK_PROBE", *extra]
 os.makedirs(B.OBJ_DIR, exist_ok=True)
 objs, procs = [], []
-for src in B.SOURCES:   # per-source objects, compiled concurrently, only the stale ones (an edit of one .hip costs one compile)
+for src in ([] if (os.environ.get("QR_PROBE_NOBUILD") == "1" and os.path.exists(dbg)) else B.SOURCES):   # per-source objects, compiled concurrently, only the stale ones (an edit of one .hip costs one compile)
     obj = B._obj(src, ["-DQR_CLOCK_PROBE" + tag, *extra])
     objs.append(obj)
-    path = os.path.join(B.CSRC, src)
+    path = os.path.join(CSRC, src)
     if not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in [path] + deps):
         procs.append(subprocess.Popen([B._hipcc(), *[f for f in B.FLAGS if f != "-shared"], *flags, "-c", path, "-o", obj]))
 for pr in procs:
     assert pr.wait() == 0
-if procs or not os.path.exists(dbg):
+if procs or (objs and not os.path.exists(dbg)):
     subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", dbg, *objs])
 if "--build" in sys.argv:
     sys.exit(0)
@@ -50,7 +51,7 @@ L.qr_debug_set_ticks.argtypes = [C.c_void_p, C.c_void_p]
 print(f"# {variant} K={K} stash={os.environ.get('QR_ROLLOUT_STASH', 'auto')} flags={extra}")
 print("#     envs  waves | kernel_us us/step | loop cyc/step (med, p90) | eff MHz | prologue cyc(us) | tail cyc | waves/SIMD max | first->last wave entry us")
 for n in sizes:
-    env = bench.make_env(variant, n, 1, 0)
+    env = bench.make_env(variant, n, 1, 0, residual=None if os.environ.get("QR_PROBE_NORES") == "1" else "default")
     n_waves = (n + 255) // 256 * 4
     ticks = torch.zeros((n_waves, 16), dtype=torch.int64, device="cuda")
     env.reset_device()
