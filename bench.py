@@ -54,9 +54,12 @@ FUSED_BYTES_PER_ENV_STEP = {"e2e": lambda ga: 16 + 4 * (20 + 4 * ga) + 6, "indi"
 MIN_TIMED_MS = 20.0
 # Numbers in the line that were NOT measured by this run: PMC counter figures collected by the builder with rocprofv3 (separate
 # --pmc passes) and committed under profiles/.  They are labelled with the file and the commit that added it.
+PMC_TRAFFIC_FILE = ("profiles", "r04_pmc_traffic.json")     # tools/run_pmc.sh: FETCH_SIZE / WRITE_SIZE passes, keyed by kernel symbol
+PMC_COMPUTE_FILE = ("profiles", "r04_pmc_compute.json")     # tools/run_pmc_compute.sh: SQ instruction / cycle counters, by kernel symbol
 PMC_SOURCES = {
-    "traffic": "builder-measured, not this run: profiles/pmc_summary.json @ 333de90 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)",
-    "flop": "builder-measured, not this run: profiles/r02_pmc_compute.json @ 333de90 (rocprofv3 --pmc SQ_INSTS_VALU_* / MFMA_MOPS, tools/pmc_compute.py)",
+    "traffic": "builder-measured, not this run: profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+               "tools/run_pmc.sh; the file records the commit and the kernel symbols it was collected on)",
+    "flop": "builder-measured, not this run: profiles/r04_pmc_compute.json (rocprofv3 --pmc SQ_INSTS_VALU_* / MFMA_MOPS, tools/run_pmc_compute.sh)",
     "launch_floor": "builder-measured, not this run: profiles/r02_launch_floor.json @ 333de90 (tools/ubench/launch_floor.hip)",
 }
 
@@ -272,9 +275,15 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
     if W > 0:
         env.rollout_device(actions[:W], view(W))
     total_steps = n * rt.world * K
-    pmc = _load_json("profiles", "pmc_summary.json").get(f"{variant}_n{n}_ga{ga}", {})
-    pmcc = _load_json("profiles", "r02_pmc_compute.json").get("kernels", {})
     vidx = 0 if variant == "e2e" else 1
+    # the symbol rocprofv3 will list for the fused launch (the library's own selection: env count, variant, mode), and the counter
+    # evidence collected under exactly that name
+    fused_symbol = env.rollout_kernel_name() if hasattr(env, "rollout_kernel_name") else f"qr::rollout_kernel<{vidx}, {ga}>"
+    step_symbol = f"qr::step_kernel<{vidx}, {ga}>"
+    policy_symbol = f"qr::rollout_policy_kernel<{vidx}, {ga}>"
+    pmc_all = _load_json(*PMC_TRAFFIC_FILE)
+    pmc = pmc_all.get(f"n{n}", {})
+    pmcc = _load_json(*PMC_COMPUTE_FILE).get("kernels", {})
     floor = _load_json("profiles", "r02_launch_floor.json").get("us_per_launch", {})
     bytes_per_step = BYTES_PER_ENV_STEP[variant](ga) * n
 
@@ -297,17 +306,24 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
         for _ in range(3):   # isolation, after a host synchronisation, runs ~7 percent slower: clocks / cold caches)
             one_region()
         kernel_ms_samples.append(env.last_rollout_ms())
-    fused_kernel_ms = float(np.median(kernel_ms_samples))
+    fused_event_ms = float(np.median(kernel_ms_samples))
+    # The kernel time of the roofline can never exceed the wall-clock bracket that contains the launch: the hipEvent pair brackets
+    # two marker packets as well (a 20-step launch measured 4-5 us longer that way than the whole bracket gives per launch), so the
+    # figure is min(hipEvent duration, bracket time per launch); both are printed.  rocprofv3's average for the same command is
+    # under profiles/ (r04_e2e_k20_kernel_stats.txt, r04_e2e_kernel_stats.txt).
+    fused_kernel_ms = min(fused_event_ms, fused_s * 1e3) if rt.use_cuda else fused_event_ms
     launch_s = fused_kernel_ms * 1e-3
-    flop = pmcc.get(f"rollout_kernel<{vidx}, {ga}>", {}).get("derived", {}).get("f32_flop_per_env_step")
-    traffic = pmc.get("fused_hbm_bytes_per_step")
+    flop = pmcc.get(fused_symbol, {}).get("derived", {}).get("f32_flop_per_env_step")
+    traffic = (pmc.get(fused_symbol) or {}).get("hbm_bytes_per_step")
     fused_bytes = FUSED_BYTES_PER_ENV_STEP[variant](ga) * n
     ach = fused_bytes * K / launch_s / 1e9
     tf = None if flop is None else flop * n * K / launch_s / 1e12
     roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": None if traffic is None else traffic * K,
-                "kernel": f"qr::rollout_kernel<{variant},ga={ga}> (one launch = {K} steps)",
-                "launch_us": fused_kernel_ms * 1e3, "us_per_step": fused_kernel_ms * 1e3 / K,
+                "kernel": fused_symbol, "steps_per_launch": K,
+                "launch_us": fused_kernel_ms * 1e3, "launch_us_hipevent": fused_event_ms * 1e3, "launch_us_bracket": fused_s * 1e6,
+                "us_per_step": fused_kernel_ms * 1e3 / K,
+                "traffic_commit": pmc_all.get("commit"), "traffic_kernel": fused_symbol if traffic is not None else None,
                 "bytes_per_launch": fused_bytes * K, "bytes_per_env_step": FUSED_BYTES_PER_ENV_STEP[variant](ga),
                 "note": "algorithmic bytes of THIS kernel: the env state stays in registers for the K steps, so a step moves its action in "
                         "and obs / reward / done / trunc out (PMC-measured traffic agrees within 3 percent); the SURVEY 8(d) per-step figure "
@@ -316,7 +332,7 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
                 "valu": {"bound": "valu", "achieved": tf, "peak": VALU_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": None if tf is None else tf / VALU_F32_PEAK_TF, "flop_per_env_step": flop,
                          "flop_source": "PMC: 64 x (ADD + MUL + TRANS + 2 FMA f32 wave-instructions) + 512 x MFMA_MOPS_F32 per env-step, "
-                                        "profiles/r02_pmc_compute.json; the larger of the two fractions names the binding roof"}}
+                                        "profiles/r04_pmc_compute.json; the larger of the two fractions names the binding roof"}}
     roofline["frac_on_8d_bytes"] = bytes_per_step * K / launch_s / 1e9 / HBM_PEAK_GBS
     roofline["frac_on_8d_bytes_note"] = ("SURVEY 8(d)'s %d B per env-step (state read + written every step) divided by this kernel's time: "
                                          "NOT its traffic (the state stays in registers) -- BASELINE.md section 4's throughput yardstick only"
@@ -338,7 +354,7 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
         "value": total_steps / step_s, "unit": "env-steps/s", "ms_per_step": step_s * 1e3 / K, "launches_per_bracket": step_R * K,
         "timed_ms_per_bracket": step_s * step_R * 1e3, "all_ms_per_step": [t * 1e3 / K for t in step_ts],
         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                     "traffic": pmc.get("hbm_bytes_per_launch"), "kernel": f"qr::step_kernel<{variant},ga={ga}>",
+                     "traffic": (pmc.get(step_symbol) or {}).get("hbm_bytes_per_launch"), "kernel": step_symbol,
                      "kernel_us": kernel_ms * 1e3, "bytes_per_launch": bytes_per_step, "launches_timed": K,
                      "launch_floor_us": {k: floor.get(k) for k in ("empty_b256", "empty_b256_graph", "copy_nt_b256", "copy_nt_b256_graph")
                                          if k in floor},
@@ -368,6 +384,7 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
             pol_flop = 2.0 * (16 * ((L + 16) // 16) * 128 + 2 * 128 * 128 + 128 * 32)   # f16 MACs x 2 as issued (padded tiles): PMC 81 920 at L = 17 / 24
             pol_flop_useful = 2.0 * ((L + 1) * 120 + 2 * 121 * 120 + 121 * 4)           # the network's own multiply-adds (biases included)
             cl_tf = pol_flop * n * Kc / (cl_ms * 1e-3) / 1e12
+            cl_bytes = (pmc.get(policy_symbol) or {}).get("hbm_bytes_per_step")
             res["closed_loop"] = {
                 "what": "qr_rollout_policy: K x [obs -> policy MLP (L->120->120->120->4, f16 MFMA) -> Gaussian sample -> env.step] in "
                         "ONE kernel (PPO collect phase); random-init policy weights",
@@ -376,10 +393,11 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
                 "roofline": {"bound": "mfma", "achieved": cl_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": cl_tf / MFMA_F16_PEAK_TF,
                              "flop_per_env_step": pol_flop, "flop_useful_per_env_step": pol_flop_useful,
                              "frac_useful": pol_flop_useful * n * Kc / (cl_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF,
-                             "traffic": None if pmc.get("closed_loop_hbm_bytes_per_step") is None else pmc["closed_loop_hbm_bytes_per_step"] * Kc,
-                             "hbm": None if pmc.get("closed_loop_hbm_bytes_per_step") is None else {
-                                 "achieved": pmc["closed_loop_hbm_bytes_per_step"] / (cl_ms * 1e-3 / Kc) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": pmc["closed_loop_hbm_bytes_per_step"] / (cl_ms * 1e-3 / Kc) / 1e9 / HBM_PEAK_GBS},
+                             "kernel": policy_symbol,
+                             "traffic": None if cl_bytes is None else cl_bytes * Kc,
+                             "hbm": None if cl_bytes is None else {
+                                 "achieved": cl_bytes / (cl_ms * 1e-3 / Kc) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": cl_bytes / (cl_ms * 1e-3 / Kc) / 1e9 / HBM_PEAK_GBS},
                              "note": "f16 matrix-core flop of the policy MLP as issued (160-180 v_mfma_f32_32x32x16_f16 per 64 envs); the "
                                      "kernel is one wave per SIMD: issue-order-bound between MFMA chain, sampling and the env step "
                                      "(profiles/r02_pmc_compute.json: MFMA busy ~39 percent of wave cycles)"}}
@@ -552,8 +570,9 @@ def headline(result):
     h["config"] = {"workload": _short(c["workload"], 220), "envs_per_gpu": c["envs_per_gpu"], "variant": c["variant"],
                    "gates_ahead": c["gates_ahead"], "obs_len": c["obs_len"]}
     r = result.get("roofline", {})
-    flat = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_us", "us_per_step",
-                                  "bytes_per_env_step", "frac_on_8d_bytes")}
+    flat = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "steps_per_launch", "launch_us",
+                                  "launch_us_hipevent", "launch_us_bracket", "us_per_step", "bytes_per_env_step", "frac_on_8d_bytes",
+                                  "traffic_commit")}
     flat["frac_on_8d_bytes_is"] = "throughput yardstick of BASELINE.md section 4 (SURVEY 8(d) bytes / this kernel's time), NOT traffic: the state stays in registers"
     flat["traffic_source"] = PMC_SOURCES["traffic"]
     v = r.get("valu") or {}

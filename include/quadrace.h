@@ -166,6 +166,10 @@ int qr_last_step_many_ms(qr_env* env, float* total_ms);
 /* The hipEvent bracket behind qr_last_step_many_ms costs two marker packets per K-step call; on = 0 drops it (default: on).
  * It is also skipped, whatever the setting, while the caller is capturing `stream` into a hipGraph. */
 int qr_set_timing(qr_env* env, int32_t on);
+/* Name of the device kernel a qr_step_many call on this handle launches NOW (it depends on the env count, the variant, the mode
+ * flags and whether a terminal-observation buffer is registered), e.g. "rollout_fast_mlp_kernel" -- the symbol rocprofv3 lists as
+ * qr::<name><variant, gates_ahead>.  Benchmarks print it so that profiles and counter evidence can be matched to the run. */
+const char* qr_rollout_kernel_name(const qr_env* env);
 int qr_profile_steps(qr_env* env, int32_t num_steps, const float* actions_dev, float* obs_out_dev,
                      float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream,
                      float* mean_kernel_ms, float* region_ms);

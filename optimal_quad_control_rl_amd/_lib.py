@@ -40,6 +40,7 @@ SIGNATURES = {
     "qr_set_pause_if_collision": (C.c_int, [_vp, C.c_int32]),
     "qr_set_terminal_obs": (C.c_int, [_vp, _vp, C.c_int32]),
     "qr_set_timing": (C.c_int, [_vp, C.c_int32]),
+    "qr_rollout_kernel_name": (C.c_char_p, [_vp]),
     "qr_seed": (C.c_int, [_vp, C.c_uint64]),
     "qr_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "qr_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),

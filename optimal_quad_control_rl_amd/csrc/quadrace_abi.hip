@@ -16,6 +16,7 @@
 namespace qr {
 hipError_t launch_step(int variant, const Params& P, const float* actions, float* obs, float* rew, uint8_t* done,
                        uint8_t* trunc, hipStream_t st);
+const char* rollout_kernel_name(int variant, const Params& P);
 hipError_t launch_rollout(int variant, const Params& P, int K, const float* actions, float* obs, float* rew,
                           uint8_t* done, uint8_t* trunc, hipStream_t st);
 hipError_t launch_rollout_policy(int variant, const Params& P, const PolicyArgs& A, int K, float* obs, float* act,
@@ -569,6 +570,11 @@ int qr_set_state(qr_env* e, const float* world_dev, const float* dist_dev, const
     QR_HIP(qr::launch_set_state(e->cfg.variant, e->P, world_dev, dist_dev, target_dev, steps_dev, episode_dev,
                                 (hipStream_t)stream));
     return QR_OK;
+}
+
+const char* qr_rollout_kernel_name(const qr_env* e) {
+    if (!e) return "";
+    return qr::rollout_kernel_name(e->cfg.variant, e->P);
 }
 
 int qr_set_timing(qr_env* e, int32_t on) {

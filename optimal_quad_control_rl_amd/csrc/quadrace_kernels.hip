@@ -358,17 +358,25 @@ __device__ __forceinline__ void obs_tile_store_rows(float* __restrict__ tile, in
 // live around the loop's back edge stayed in scratch: it is only indexable by constants after the inner loops are unrolled).
 #define QR_BURST8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
-template <int V, int GA, bool kMlp>
+// kLean = the same loop for launches with MORE than one workgroup per CU, where 256 registers (two waves per SIMD) is the budget:
+// no reset stash (the batched cooperative reset_done_lanes() with a wave-private LDS scratch instead), no register prefetch of the
+// next action chunk (4-step chunks loaded at the top of the chunk; the co-resident wave covers the round trip), layer-1 weight
+// operands re-read from LDS every step.
+template <int V, int GA, bool kMlp, bool kLean>
 __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
                                                   float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
                                                   uint8_t* __restrict__ trunc_out) {
-    constexpr int kActChunk = act_chunk<V, GA>();
+    constexpr int kActChunk = kLean ? (obs_len<V, GA>() > 32 ? 2 : 4) : act_chunk<V, GA>();   // lean: static LDS <= 64 KiB with the extras below
     constexpr int L = obs_len<V, GA>();
     constexpr int S = Env<V>::S;
     constexpr int kVec = 16 * L;                 // float4 elements of a wave's [64][L] observation block
     constexpr int kFlush = (kVec + 63) / 64;     // store instructions per block
-    __shared__ __attribute__((aligned(16))) float lds[kResetTableFloats + kMaxGates * kGateStride + kBlock * L +
-                                                       4 * kBlock * kActChunk];
+    constexpr bool kALds = kLean && kMlp;
+    constexpr int kScratch = 320;                // floats of reset scratch per wave (reset_done_lanes: 1 280 B)
+    constexpr int kOffA = kResetTableFloats + kMaxGates * kGateStride + kBlock * L + 4 * kBlock * kActChunk;
+    constexpr int kOffScratch = kOffA + (kALds ? 4 * kMlpQuads * 64 : 0);
+    __shared__ __attribute__((aligned(16))) float lds[kOffScratch + (kLean ? 4 * kScratch : 0)];
+    static_assert(sizeof(float) * (kOffScratch + (kLean ? 4 * kScratch : 0)) <= 65536, "static LDS");
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool active = i < P.n;  // ragged tail lanes stay active (wave-wide MLP ops) and shadow env 0
@@ -387,21 +395,31 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     const float4 tv = tsrc[(int)threadIdx.x < tab_vec ? threadIdx.x : 0];
     const int2 ts0 = P.ts[ii];
     MlpRegs mlp;
-    if (kMlp) mlp_load_regs(P.tables, lane, mlp);
+    if (kMlp) mlp_load_regs(P.tables, lane, mlp, !kALds);
     float4 b0, b1, b2, b3, b4, b5, b6, b7;
     b0 = b1 = b2 = b3 = b4 = b5 = b6 = b7 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if constexpr (!kLean) {
 #define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)(J < K ? J : K - 1) * n + ii];
-    QR_BURST8(QR_X)
+        QR_BURST8(QR_X)
 #undef QR_X
+    }
     Env<V> e;
     load_env<V>(P, ii, e);
     if ((int)threadIdx.x < tab_vec) reinterpret_cast<float4*>(lds)[threadIdx.x] = tv;
+    if constexpr (kALds) {
+        mlp_stage_a(P.tables, reinterpret_cast<u32x4*>(lds + kOffA));
+        mlp.a_lds = reinterpret_cast<const u32x4*>(lds + kOffA);
+    }
     __syncthreads();
     const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
-    float stash[reset_value_count<V>()];
-    reset_values<V>(P, rtab, (uint32_t)ts0.x >> 8, gid_lo, gid_hi, stash);   // = what reset_from_stash() would draw on first use
-    bool stash_ok = true;
+    float stash[kLean ? 1 : reset_value_count<V>()];
+    bool stash_ok = false;
+    if constexpr (!kLean) {
+        reset_values<V>(P, rtab, (uint32_t)ts0.x >> 8, gid_lo, gid_hi, stash);   // = what reset_from_stash() would draw on first use
+        stash_ok = true;
+    }
+    float* scratch = lds + kOffScratch + (threadIdx.x >> 6) * kScratch;
     const int wave_first = i - lane;
     const bool full_wave = wave_first + 64 <= P.n;
     float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
@@ -420,10 +438,15 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     QR_CLOCK_STAMP(P, 1);
     for (int k0 = 0; k0 < K; k0 += kActChunk) {
         const int c = (K - k0 < kActChunk) ? K - k0 : kActChunk;
+        if constexpr (kLean) {                  // this chunk's actions, loaded here (clamped step index keeps the loads unconditional)
+#define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)((k0 + J < K) ? k0 + J : K - 1) * n + ii];
+            QR_BURST8(QR_X)
+#undef QR_X
+        }
 #define QR_X(J) if constexpr (J < kActChunk) act_slot[J * kBlock] = b##J;
         QR_BURST8(QR_X)
 #undef QR_X
-        if (k0 + kActChunk < K) {               // request the next chunk now; it lands while this chunk is simulated
+        if (!kLean && k0 + kActChunk < K) {     // request the next chunk now; it lands while this chunk is simulated
 #define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)((k0 + kActChunk + J < K) ? k0 + kActChunk + J : K - 1) * n + ii];
             QR_BURST8(QR_X)
 #undef QR_X
@@ -448,7 +471,7 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
             float nw[S];
             int new_target;
             bool done, trunc;
-            const float reward = step_dynamics<V>(P, gate, mlp, kMlp, lane, e, u, nw, new_target, done, trunc);
+            const float reward = step_dynamics<V, kALds>(P, gate, mlp, kMlp, lane, e, u, nw, new_target, done, trunc);
             QR_TICK(P, 5);
             if (pending) {
                 float4* g4 = reinterpret_cast<float4*>(obs_step - n * L + (size_t)wave_first * L);
@@ -465,7 +488,8 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
 #pragma unroll
             for (int q = 0; q < S; ++q) e.s[q] = nw[q];
             any_reset |= done;
-            reset_from_stash<V>(P, rtab, done && active, e, gid_lo, gid_hi, stash, stash_ok);
+            if constexpr (kLean) reset_done_lanes<V>(P, rtab, scratch, lane, done && active, e, gid_lo, gid_hi);
+            else reset_from_stash<V>(P, rtab, done && active, e, gid_lo, gid_hi, stash, stash_ok);
             if (active) {
                 stream_store(rew_step + i, reward);
                 stream_store(done_step + i, (uint8_t)(done ? 1 : 0));
@@ -508,14 +532,21 @@ template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 rollout_fast_kernel(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
                     float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
-    rollout_fast_body<V, GA, false>(P, K, actions, obs_out, rew_out, done_out, trunc_out);
+    rollout_fast_body<V, GA, false, false>(P, K, actions, obs_out, rew_out, done_out, trunc_out);
 }
 template <int V, int GA>   // E2E with the residual MLPs
 __global__ void __launch_bounds__(kBlock)
 rollout_fast_mlp_kernel(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
                         float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
     static_assert(V == kE2E, "residual MLPs belong to the E2E model");
-    rollout_fast_body<V, GA, true>(P, K, actions, obs_out, rew_out, done_out, trunc_out);
+    rollout_fast_body<V, GA, true, false>(P, K, actions, obs_out, rew_out, done_out, trunc_out);
+}
+template <int V, int GA>   // E2E with the residual MLPs, more than one workgroup per CU
+__global__ void __launch_bounds__(kBlock, 2)
+rollout_lean_mlp_kernel(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
+                        float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+    static_assert(V == kE2E, "residual MLPs belong to the E2E model");
+    rollout_fast_body<V, GA, true, true>(P, K, actions, obs_out, rew_out, done_out, trunc_out);
 }
 
 template <int V, int GA>
@@ -858,25 +889,50 @@ static bool rollout_fast_enabled() {
     return on == 1;
 }
 
+// Which kernel runs a K-step call -- ONE selection, used by the launcher and by qr_rollout_kernel_name() (bench.py prints the symbol
+// rocprofv3 will show, and looks its counter evidence up under that name):
+//   at most one workgroup per CU, default mode (no pause flags, no terminal-observation rows):
+//       E2E + residual MLPs -> rollout_fast_mlp_kernel, E2E without -> rollout_fast_kernel, INDI -> rollout_stash_kernel (HBM-bound at
+//       65 536 envs: the general stash kernel is as fast per step, 2 443 vs 2 503 cycles, and has the shorter prologue)
+//   at most one workgroup per CU, any other mode -> rollout_stash_kernel
+//   more workgroups: E2E + residual MLPs in the default mode -> rollout_lean_mlp_kernel, everything else -> rollout_kernel
+enum RolloutKernel { kRkFastMlp, kRkFast, kRkStash, kRkLeanMlp, kRkPlain };
+static RolloutKernel select_rollout(int variant, const Params& P) {
+    const bool plain_mode = !(P.flags & (kFlagPause | kFlagPauseIfCollision)) && P.term_obs == nullptr && rollout_fast_enabled();
+    const bool mlp = variant == kE2E && (P.flags & kFlagResidual);
+    if (use_rollout_stash(P.n)) {
+        if (plain_mode && mlp) return kRkFastMlp;
+        if (plain_mode && variant == kE2E) return kRkFast;
+        return kRkStash;
+    }
+    return (plain_mode && mlp) ? kRkLeanMlp : kRkPlain;
+}
+
+const char* rollout_kernel_name(int variant, const Params& P) {
+    switch (select_rollout(variant, P)) {
+        case kRkFastMlp: return "rollout_fast_mlp_kernel";
+        case kRkFast: return "rollout_fast_kernel";
+        case kRkStash: return "rollout_stash_kernel";
+        case kRkLeanMlp: return "rollout_lean_mlp_kernel";
+        default: return "rollout_kernel";
+    }
+}
+
 hipError_t launch_rollout(int variant, const Params& P, int K, const float* actions, float* obs, float* rew,
                           uint8_t* done, uint8_t* trunc, hipStream_t st) {
     const float4* a4 = reinterpret_cast<const float4*>(actions);
-    if (use_rollout_stash(P.n)) {
-        // default mode (no pause flags, no terminal-observation rows) -> the specialised kernel; anything else -> the general one
-        const bool plain_mode = !(P.flags & (kFlagPause | kFlagPauseIfCollision)) && P.term_obs == nullptr && rollout_fast_enabled();
-        if (plain_mode) {
-            if (variant == kE2E && (P.flags & kFlagResidual)) { QR_DISPATCH_GA(kE2E, rollout_fast_mlp_kernel, P, K, a4, obs, rew, done, trunc) }
-            else if (variant == kE2E) { QR_DISPATCH_GA(kE2E, rollout_fast_kernel, P, K, a4, obs, rew, done, trunc) }
-            else { QR_DISPATCH_GA(kINDI, rollout_stash_kernel, P, K, a4, obs, rew, done, trunc) }   // INDI is HBM-bound at 65 536 envs: the
-            // general stash kernel is as fast per step (2 443 vs 2 503 cycles) and has the shorter prologue (no stash prefill)
-            return hipGetLastError();
-        }
-        if (variant == kE2E) { QR_DISPATCH_GA(kE2E, rollout_stash_kernel, P, K, a4, obs, rew, done, trunc) }
-        else { QR_DISPATCH_GA(kINDI, rollout_stash_kernel, P, K, a4, obs, rew, done, trunc) }
-        return hipGetLastError();
+    switch (select_rollout(variant, P)) {
+        case kRkFastMlp: { QR_DISPATCH_GA(kE2E, rollout_fast_mlp_kernel, P, K, a4, obs, rew, done, trunc) } break;
+        case kRkFast: { QR_DISPATCH_GA(kE2E, rollout_fast_kernel, P, K, a4, obs, rew, done, trunc) } break;
+        case kRkLeanMlp: { QR_DISPATCH_GA(kE2E, rollout_lean_mlp_kernel, P, K, a4, obs, rew, done, trunc) } break;
+        case kRkStash:
+            if (variant == kE2E) { QR_DISPATCH_GA(kE2E, rollout_stash_kernel, P, K, a4, obs, rew, done, trunc) }
+            else { QR_DISPATCH_GA(kINDI, rollout_stash_kernel, P, K, a4, obs, rew, done, trunc) }
+            break;
+        default:
+            if (variant == kE2E) { QR_DISPATCH_GA(kE2E, rollout_kernel, P, K, a4, obs, rew, done, trunc) }
+            else { QR_DISPATCH_GA(kINDI, rollout_kernel, P, K, a4, obs, rew, done, trunc) }
     }
-    if (variant == kE2E) { QR_DISPATCH_GA(kE2E, rollout_kernel, P, K, a4, obs, rew, done, trunc) }
-    else { QR_DISPATCH_GA(kINDI, rollout_kernel, P, K, a4, obs, rew, done, trunc) }
     return hipGetLastError();
 }
 

@@ -566,6 +566,11 @@ class Quadcopter3DGates(_Base):
             self._last_obs = obs
         return obs, rew, done, trunc
 
+    def rollout_kernel_name(self):
+        """Symbol of the device kernel rollout_device() launches on this env right now, as rocprofv3 prints it."""
+        name = self._L.qr_rollout_kernel_name(self._h).decode()
+        return "qr::%s<%d, %d>" % (name, int(self.VARIANT), self.gates_ahead)
+
     def rollout_device(self, actions, out=None):
         """K steps with pre-recorded actions [K,N,4] -> (obs[K,N,L], reward[K,N], done[K,N], trunc[K,N])."""
         assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()

@@ -36,6 +36,7 @@ N = int(os.environ.get("QR_PMC_ENVS", "65536"))         # envs of the probe (rou
 ONLY_ENV = os.environ.get("QR_PMC_ONLY_ENV", "0") == "1"  # skip the predecessor-env and PPO legs of the probe
 # (the fused rollout launches as rollout_stash_kernel<V, GA> up to one workgroup per CU and as rollout_kernel<V, GA> beyond)
 KERNELS = ("q3_step_kernel<", "q3_rollout_kernel<", "step_kernel<0", "step_kernel<1", "rollout_stash_kernel<0", "rollout_stash_kernel<1",
+           "rollout_fast_mlp_kernel<0", "rollout_fast_kernel<0", "rollout_lean_mlp_kernel<0",
            "rollout_kernel<0", "rollout_kernel<1", "rollout_policy_kernel<0", "rollout_policy_kernel<1", "ppo_")
 
 
@@ -107,7 +108,8 @@ def short_name(k):
                 return k[i:j]
             i = k.index(pat)
             tail = k[i:]
-            return tail.split(">")[0] + ">"
+            name = tail.split(">")[0] + ">"
+            return ("qr::" + name) if k[max(0, i - 4):i] == "qr::" else name   # the symbol as rocprofv3 prints it (bench.py's lookup key)
     return None
 
 
@@ -122,7 +124,7 @@ def summarise(paths, out_path):
                 acc.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     res = {"counters": "rocprofv3 --kernel-trace --pmc (two SQ passes, groups A and B of tools/pmc_compute.py), per launch "
                        "(mean over launches after the first two); N = %d envs, fused kernels: %d steps per launch" % (N, K_FUSED),
-           "n_envs": N,
+           "n_envs": N, "commit": os.environ.get("QR_COMMIT", "unknown"),
            "units": "SQ_WAVE_CYCLES/SQ_WAIT_*/SQ_ACTIVE_INST_* = quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES = cycles "
                     "summed over SIMDs; SQ_INSTS_* = wave-instructions; GRBM_GUI_ACTIVE = GPU cycles",
            "kernels": {}}

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Turn the two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected separately as MI355X_MICROARCH.md
-prescribes: they do not fit one pass) into HBM bytes per launch for the env kernels.
+prescribes: they do not fit one pass) into HBM bytes per launch / per step for the env kernels, KEYED BY KERNEL SYMBOL
+(round 4: bench.py looks the evidence up under the symbol the library reports for its launch).
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d D/fetch -o f -- python tools/pmc_probe.py e2e
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d D/write -o w -- python tools/pmc_probe.py e2e
-    python tools/pmc_traffic.py e2e 65536 D/fetch/f_counter_collection.csv D/write/w_counter_collection.csv
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d D/fetch -o f -- python tools/pmc_probe.py e2e [n]
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d D/write -o w -- python tools/pmc_probe.py e2e [n]
+    python tools/pmc_traffic.py e2e 65536 D/fetch/f_counter_collection.csv D/write/w_counter_collection.csv out.json
 
 Units / corrections: both counters are in KiB.  On gfx950 FETCH_SIZE reports exactly half of the bytes of a wide
 coalesced streaming read (guide, section HBM) -- confirmed here by the calibration copy in tools/pmc_probe.py
@@ -14,11 +15,14 @@ run; WRITE_SIZE is calibrated the same way against the 256 MiB the copy writes.
 import csv
 import json
 import os
+import re
+import subprocess
 import sys
 
 csv.field_size_limit(1 << 30)
 CAL_BYTES = 256 * 1024 * 1024
 K_FUSED = 64  # steps per rollout launch in tools/pmc_probe.py
+SYM = re.compile(r"(qr::[a-z_0-9]+<\d+, \d+>)")
 
 
 def load(path, counter):
@@ -30,44 +34,54 @@ def load(path, counter):
     return rows
 
 
-def summarise(rows):
+def per_symbol(rows):
     cal = [v for k, v in rows if "copyBuffer" in k]
     cal = [v for v in cal if v > 0.9 * max(cal)]  # only the 256 MiB calibration copies, not small H2D uploads
-    step = [v for k, v in rows if "step_kernel" in k]
-    roll = [v for k, v in rows if "rollout_kernel" in k or "rollout_stash_kernel" in k]
-    rpol = [v for k, v in rows if "rollout_policy_kernel" in k]
-    return (sum(cal) / len(cal), sum(step[4:]) / max(1, len(step[4:])), sum(roll) / max(1, len(roll)),
-            sum(rpol) / max(1, len(rpol)))
+    acc = {}
+    for k, v in rows:
+        m = SYM.search(k)
+        if m:
+            acc.setdefault(m.group(1), []).append(v)
+    return sum(cal) / len(cal), acc
 
 
-def main(variant, n, fetch_csv, write_csv, out="profiles/pmc_summary.json"):
+def commit_id():
+    """the commit the measured library was built from: QR_COMMIT (the GPU box has no .git) or git itself"""
+    if os.environ.get("QR_COMMIT"):
+        return os.environ["QR_COMMIT"]
+    try:
+        return subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(os.path.abspath(__file__)),
+                                       stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return "unknown"
+
+
+def main(variant, n, fetch_csv, write_csv, out="profiles/r04_pmc_traffic.json"):
     n = int(n)
-    f_cal, f_step, f_roll, f_rpol = summarise(load(fetch_csv, "FETCH_SIZE"))
-    w_cal, w_step, w_roll, w_rpol = summarise(load(write_csv, "WRITE_SIZE"))
+    f_cal, f = per_symbol(load(fetch_csv, "FETCH_SIZE"))
+    w_cal, w = per_symbol(load(write_csv, "WRITE_SIZE"))
     f_scale = CAL_BYTES / (f_cal * 1024.0)  # bytes per reported KiB*1024 (expected 2.0 on gfx950)
     w_scale = CAL_BYTES / (w_cal * 1024.0)
-    res = {
-        "counters": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB",
-        "calibration": {"copy_bytes": CAL_BYTES, "FETCH_SIZE_KiB": f_cal, "WRITE_SIZE_KiB": w_cal,
-                        "fetch_scale": f_scale, "write_scale": w_scale},
-        "step_kernel": {"FETCH_SIZE_KiB": f_step, "WRITE_SIZE_KiB": w_step,
-                        "read_bytes": f_step * 1024 * f_scale, "write_bytes": w_step * 1024 * w_scale},
-        "rollout_kernel_per_step": {"FETCH_SIZE_KiB": f_roll / K_FUSED, "WRITE_SIZE_KiB": w_roll / K_FUSED,
-                                    "read_bytes": f_roll * 1024 * f_scale / K_FUSED,
-                                    "write_bytes": w_roll * 1024 * w_scale / K_FUSED},
-    }
-    res["rollout_policy_kernel_per_step"] = {"read_bytes": f_rpol * 1024 * f_scale / K_FUSED, "write_bytes": w_rpol * 1024 * w_scale / K_FUSED}
-    res["closed_loop_hbm_bytes_per_step"] = (res["rollout_policy_kernel_per_step"]["read_bytes"] +
-                                             res["rollout_policy_kernel_per_step"]["write_bytes"])
-    res["hbm_bytes_per_launch"] = res["step_kernel"]["read_bytes"] + res["step_kernel"]["write_bytes"]
-    res["fused_hbm_bytes_per_step"] = (res["rollout_kernel_per_step"]["read_bytes"] +
-                                       res["rollout_kernel_per_step"]["write_bytes"])
-    allres = {}
-    if os.path.exists(out):
-        allres = json.load(open(out))
-    allres[f"{variant}_n{n}_ga1"] = res
+    allres = json.load(open(out)) if os.path.exists(out) else {}
+    allres["commit"] = commit_id()
+    allres["counters"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB, scaled by the 256 MiB calibration copy of the "
+                          "same run; per kernel symbol: mean over its launches (per-step kernel: after the first four)")
+    sec = allres.setdefault(f"n{n}", {})
+    sec[f"calibration_{variant}"] = {"copy_bytes": CAL_BYTES, "FETCH_SIZE_KiB": f_cal, "WRITE_SIZE_KiB": w_cal, "fetch_scale": f_scale,
+                                     "write_scale": w_scale}
+    for sym in sorted(set(f) | set(w)):
+        fv, wv = f.get(sym, [0.0]), w.get(sym, [0.0])
+        if "step_kernel" in sym:
+            fv, wv = fv[4:] or fv, wv[4:] or wv
+        rb, wb = sum(fv) / len(fv) * 1024 * f_scale, sum(wv) / len(wv) * 1024 * w_scale
+        e = {"launches": len(fv), "read_bytes_per_launch": rb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": rb + wb}
+        if "rollout" in sym:
+            e.update(steps_per_launch=K_FUSED, hbm_bytes_per_step=(rb + wb) / K_FUSED, hbm_bytes_per_env_step=(rb + wb) / K_FUSED / n)
+        else:
+            e.update(hbm_bytes_per_env_step=(rb + wb) / n)
+        sec[sym] = e
     json.dump(allres, open(out, "w"), indent=1)
-    print(json.dumps({k: res[k] for k in ("hbm_bytes_per_launch", "fused_hbm_bytes_per_step", "calibration")}))
+    print(json.dumps({k: round(v.get("hbm_bytes_per_env_step", 0), 2) for k, v in sec.items() if k.startswith("qr::")}))
 
 
 if __name__ == "__main__":
