@@ -421,6 +421,10 @@ __device__ __forceinline__ void mlp_stage_a(const float* __restrict__ tab, u32x4
 }
 
 __device__ __forceinline__ void mlp_load_regs(const float* __restrict__ tab, int lane, MlpRegs& m, bool a_in_regs = true) {
+    // MODE.DX10_CLAMP = 0 for the rest of the wave's life: the ReLU below is a CLAMP modifier, and with the (default) DX10 treatment a
+    // NaN pre-activation would clamp to 0 -- the reference's torch ReLU propagates NaN (an env with a NaN state component gets NaN
+    // residual forces and moments, fixture F11).  With the bit clear the clamp passes NaN through; finite values are unaffected.
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 8, 1), 0");
     if (a_in_regs) {
         const u32x4* a4 = reinterpret_cast<const u32x4*>(tab + kOffTabA) + lane;
 #pragma unroll
@@ -463,8 +467,8 @@ __device__ __forceinline__ void unpack_f16(uint32_t p, float& a, float& b) {
 // |x| < 2^40 the upper clamp never acts and the power-of-two scaling is exact, so the result is max(x, 0) * 2^-40 exactly; the
 // output-layer weights are stored pre-multiplied by 2^40 (host side, exact), and the fused multiply-add rounds w' * t + s =
 // w * max(x, 0) + s once -- bit for bit what fmaf(w, max(x, 0), s) gives.  (A hidden pre-activation of 1e12 does not occur: inputs
-// are motor commands in [-1, 1], body velocities and rates the out-of-bounds guard keeps below 1000; NaN clamps to 0 like the
-// v_max form.)  There is no v_pk_max_f32 on gfx950: the v_max form cost 64 single-lane-pair instructions per env step, this
+// are motor commands in [-1, 1], body velocities and rates the out-of-bounds guard keeps below 1000; a NaN pre-activation stays
+// NaN like torch's ReLU: mlp_load_regs() clears MODE.DX10_CLAMP.)  There is no v_pk_max_f32 on gfx950: the v_max form cost 64 single-lane-pair instructions per env step, this
 // costs 32.  fmaxf() would cost two each: LLVM first canonicalises an operand it cannot prove quiet.
 // MFMA -> VALU read hazards: the wait states after a matrix instruction are inserted by the compiler's hazard recogniser,
 // which does not look inside inline asm.  `ready` is the result of acc_ready(): a compiler-visible VALU read of the same
@@ -784,7 +788,11 @@ __device__ __forceinline__ float step_dynamics(const Params& P, const GateRow& g
     const float nx = nw[0] - g0.x, ny = nw[1] - g0.y, nz = nw[2] - g0.z;
     const float d2g_old = fast_sqrt(fmaf(ox, ox, fmaf(oy, oy, oz * oz)));  // R:522-525
     const float d2g_new = fast_sqrt(fmaf(nx, nx, fmaf(ny, ny, nz * nz)));
-    float reward = d2g_old - d2g_new;
+    // R:524-525: rewards = d2g_old - d2g_new - rat_penalty with rat_penalty = 0 * 0.01 * |new rates| -- zero for finite rates, NaN when a
+    // new rate is NaN or inf (0 * NaN, 0 * inf): the reward of an env with NaN attitude or rates is NaN although its position is finite
+    // (fixture F11).  0 * (sum of squares) is NaN / zero under exactly the same conditions as 0 * the float32 norm.
+    const float rat_penalty = 0.0f * fmaf(nw[9], nw[9], fmaf(nw[10], nw[10], nw[11] * nw[11]));
+    float reward = (d2g_old - d2g_new) - rat_penalty;
     const float proj_old = fmaf(ox, cs.x, oy * cs.y);               // R:528-532
     const float proj_new = fmaf(nx, cs.x, ny * cs.y);
     const bool crossed = (proj_old < 0.0f) && (proj_new > 0.0f);

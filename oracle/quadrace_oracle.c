@@ -164,7 +164,7 @@ static void mlp_forward(const float* W1, const float* b1, const float* W2, const
         float acc = 0.0f;
         for (int i = 0; i < n_in; ++i) acc += W1[j * n_in + i] * x[i];
         acc += b1[j];
-        h[j] = acc > 0.0f ? acc : 0.0f;
+        h[j] = acc < 0.0f ? 0.0f : acc; /* torch.nn.ReLU (R:244-245) propagates NaN: relu(NaN) = NaN -- pinned by fixture F11 */
     }
     for (int o = 0; o < n_out; ++o) {
         float acc = 0.0f;

@@ -128,3 +128,66 @@ def free_run(env, traj, prefix, has_dist, horizon=100, tol=TOL_FREE_RUN):
         rep.passes += int((g("reward")[k] > 1).sum())
     assert rep.max_state <= tol, f"free-run drift {rep.max_state} > {tol} over {horizon} steps"
     return rep
+
+
+def check_edges(env_factory, variant_id, vname, residual_blob):
+    """F11 (tools/gen_golden.py gen_f11_edges): one step of the reference from states at the edges the other fixtures miss.
+      * NaN / inf components: the NaN / inf PATTERN of the new state, the observation and the reward is the reference's, the finite
+        components agree at the usual one-step tolerance, `done` is the reference's (a NaN env stays alive until max_steps);
+      * body rates bracketing the 1000 rad/s guard: the rows one rad/s inside / outside must agree exactly; the two rows on
+        consecutive float32 values around the reference's own flip may differ only if the new rate is within 1e-3 of the guard;
+      * theta within 1e-3 of +-pi/2: the Euler kinematics multiply by 1/cos(theta) ~ 1e3-1e4, so phi and psi inherit the rounding of
+        cos(theta) (7e-8 absolute for every float32 cosine, the reference's NumPy one included) amplified by that factor: they are
+        compared with the tolerance scaled by 1/|cos theta|, everything else at the usual one;
+      * |psi| ~ 1e4: usual tolerances (argument reduction of sin / cos, yaw wrap of the observation).
+    Rows with a ~1000 rad/s rate feed the residual MLPs inputs a thousand times their usual size: the float32 rounding of the MLP output
+    (a few 1e-7 of sum |w h| ~ 10, summation order differs between torch's sgemm and any other implementation) reaches the angular
+    accelerations through 1 / I = 1104 / 805 / 487, i.e. ~4e-6 on a rate after dt -- the three rates (and their observation columns)
+    of those rows are compared at 10 x the usual tolerance."""
+    d = load("f11_edges")
+    names = [str(x) for x in d[vname + "_names"]]
+    n = len(names)
+    a = env_factory(variant_id, n, tracks()["zigzag"], gates_ahead=1, residual=residual_blob)
+    w0 = d[vname + "_world0"]
+    a.set_state(w0, np.zeros((n, 6), np.float32), d[vname + "_target0"], d[vname + "_steps0"])
+    with np.errstate(all="ignore"):
+        obs, rew, done, trunc = a.step(d[vname + "_actions"])
+    w, _, t, s = a.get_state()
+    ref_done = d[vname + "_done"].astype(bool)
+    knife = np.array([nm.endswith("last_alive") or nm.endswith("first_oob") for nm in names])
+    mism = done != ref_done
+    assert not (mism & ~knife).any(), [names[i] for i in np.nonzero(mism & ~knife)[0]]
+    for i in np.nonzero(mism)[0]:   # a knife-edge row: justified only by a new rate within 1e-3 of the guard
+        rates = np.abs(np.asarray(d[vname + "_world"][i] if not ref_done[i] else w[i], np.float64)[9:12])
+        assert np.abs(rates - 1000.0).min() < 1e-3, (names[i], rates)
+    ok = ~mism
+    np.testing.assert_array_equal(t[ok], d[vname + "_target"][ok])
+    np.testing.assert_array_equal(s[ok], d[vname + "_steps"][ok])
+    assert trunc[names.index("nan_x_at_max_steps")] and done[names.index("nan_x_at_max_steps")]
+    # rewards: NaN where the reference's is NaN, equal otherwise
+    ref_rew = d[vname + "_reward"]
+    np.testing.assert_array_equal(np.isnan(rew[ok]), np.isnan(ref_rew[ok]))
+    fin = ok & ~np.isnan(ref_rew)
+    assert np.abs(rew[fin] - ref_rew[fin]).max() < TOL_STEP_REWARD
+    live = ok & ~ref_done            # rows the reference did not reset
+    ref_w, ref_o = d[vname + "_world"], d[vname + "_obs"]
+    np.testing.assert_array_equal(np.isnan(w[live]), np.isnan(ref_w[live]))
+    np.testing.assert_array_equal(np.isinf(w[live]), np.isinf(ref_w[live]))
+    np.testing.assert_array_equal(np.isnan(obs[live]), np.isnan(ref_o[live]))
+    tol_w = np.full(ref_w.shape, TOL_STEP_STATE)
+    tol_o = np.full(ref_o.shape, TOL_STEP_OBS)
+    for i, nm in enumerate(names):
+        if nm.startswith("theta_"):
+            amp = 1.0 / abs(np.cos(np.float64(w0[i, 7])))
+            tol_w[i, 6] *= amp; tol_w[i, 8] *= amp
+            tol_o[i, 6] *= amp; tol_o[i, 8] *= amp
+        if nm.startswith("rate_"):
+            tol_w[i, 9:12] *= 10.0
+            tol_o[i, 9:12] *= 10.0
+    fw = np.isfinite(ref_w) & live[:, None]
+    assert (rel_err(np.where(fw, w, 0), np.where(fw, ref_w, 0)) <= tol_w).all(), \
+        [(names[i], j) for i, j in zip(*np.nonzero(rel_err(np.where(fw, w, 0), np.where(fw, ref_w, 0)) > tol_w))]
+    fo = np.isfinite(ref_o) & live[:, None]
+    eo = obs_err(np.where(fo, obs, 0), np.where(fo, ref_o, 0), world=np.where(np.isfinite(ref_w), ref_w, 0))
+    assert (eo <= tol_o).all(), [(names[i], j, eo[i, j]) for i, j in zip(*np.nonzero(eo > tol_o))]
+    return dict(rows=n, knife_edge_mismatches=int(mism.sum()))

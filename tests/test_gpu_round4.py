@@ -23,3 +23,14 @@ def test_bench_gpus_n_on_a_smaller_box_fails_loudly():
     assert r.returncode != 0
     assert f"--gpus {want} needs {want} visible GPUs" in r.stderr, r.stderr[-1000:]
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]       # no JSON line at all
+
+
+@pytest.mark.parametrize("variant,vname", [(0, "e2e"), (1, "indi")])
+def test_edge_states_f11(variant, vname, residual_blob):
+    """the reference's own step() from states at the edges -- NaN / inf components (alive until max_steps, NaN
+    pattern identical), rates bracketing the 1000 rad/s guard on consecutive float32 values, theta within 1e-3 of +-pi/2, |psi| ~ 1e4
+    -- replayed on the HIP path (tests/parity.py check_edges; the CPU suite holds the oracle to the same fixture)."""
+    import parity as P
+    from product_adapter import ProductAdapter
+
+    print(P.check_edges(ProductAdapter, variant, vname, residual_blob))

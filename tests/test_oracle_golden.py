@@ -184,6 +184,12 @@ def test_branches(variant, vname, residual_blob):
     assert abs(rew[i] - 9.95) < 1e-4 and t[i] == 1
 
 
+# ---- F11: edge states (NaN / inf components, rates at the 1000 rad/s guard, theta at +-pi/2, |psi| ~ 1e4) ----------
+@pytest.mark.parametrize("variant,vname", [(O.E2E, "e2e"), (O.INDI, "indi")])
+def test_edge_states(variant, vname, residual_blob):
+    print(P.check_edges(OracleAdapter, variant, vname, residual_blob))
+
+
 # ---- F8: INDI trajectories ----------------------------------------------------------------------------
 @pytest.mark.parametrize("key", ["zigzag", "square", "single"])
 def test_indi_teacher_forced(key):

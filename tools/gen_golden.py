@@ -373,6 +373,105 @@ def gen_f7_branches(ns_e2e, ns_indi):
     save("f7_branches", **out)
 
 
+def gen_f11_edges(ns_e2e, ns_indi):
+    """F11: one step of the reference from states at the edges the other fixtures miss -- a NaN / inf component
+    (a NaN env stays alive until max_steps), body rates within +-1.5 of the 1000 rad/s guard, theta within 1e-3 of
+    +-pi/2 (tan / 1/cos of the Euler kinematics blow up), |psi| ~ 1e4 (argument reduction of sin / cos, the yaw wrap of the
+    observation).  Arrays only: pre-step state, action, and what the reference's step() returned."""
+    out = {}
+    hp = np.float32(np.pi / 2)
+    for variant, ns, S in (("e2e", ns_e2e, 16), ("indi", ns_indi, 13)):
+        gp, gy, sp = zigzag_track()
+        cases = []
+
+        def ws(**kw):
+            s = np.zeros(S, dtype=np.float32)
+            s[0:3] = [-3.0, -1.0, -1.5]
+            s[3:6] = [0.3, 0.5, -0.1]
+            s[6:9] = [0.05, -0.04, 0.3]
+            s[9:12] = [0.2, -0.1, 0.15]
+            if S == 16:
+                s[12:16] = [0.1, 0.12, 0.08, 0.11]
+            else:
+                s[12] = 0.2
+            for k, v in kw.items():
+                s[int(k[1:])] = v
+            return s
+
+        nan, inf = np.float32(np.nan), np.float32(np.inf)
+        for idx, nm in ((0, "x"), (2, "z"), (5, "vz"), (6, "phi"), (8, "psi"), (9, "p"), (12, "w1_or_T")):
+            cases.append(("nan_" + nm, ws(**{"s%d" % idx: nan}), 0, 3))
+        cases.append(("inf_vx", ws(s3=inf), 0, 3))
+        cases.append(("nan_x_at_max_steps", ws(s0=nan), 0, 1199))
+        cases.append(("nan_all", np.full(S, nan, np.float32), 0, 3))
+        # body rates whose NEW value lands next to the 1000 rad/s guard (R:549-550 tests the post-step rates): the pre-step value
+        # where the reference's own `done` flips is bracketed on a grid, then on consecutive float32 values
+        def edge_of(idx, sign):
+            def dones(vals):
+                np.random.seed(5)
+                e = ns["Quadcopter3DGates"](num_envs=len(vals), gates_pos=gp, gate_yaw=gy, start_pos=sp, gates_ahead=1)
+                e.reset()
+                e.world_states = np.stack([ws(**{"s%d" % idx: np.float32(v)}) for v in vals]).astype(np.float32)
+                e.target_gates = np.zeros(len(vals), int)
+                e.step_counts = np.full(len(vals), 3)
+                if variant == "e2e":
+                    e.disturbances = np.zeros((len(vals), 6), np.float32)
+                e.update_states()
+                with np.errstate(all="ignore"):
+                    return e.step(np.tile(act_row, (len(vals), 1)))[2]
+            grid = (sign * np.linspace(900.0, 2500.0, 6401)).astype(np.float32)
+            d = dones(grid)
+            k = int(np.argmax(d))
+            assert d[k] and not d[k - 1], (variant, idx, sign)
+            lo, hi = grid[k - 1], grid[k]
+            while np.nextafter(lo, hi) != hi:      # bisect on float32 values
+                mid = np.float32((np.float64(lo) + np.float64(hi)) / 2)
+                if mid == lo or mid == hi:
+                    break
+                if dones(np.array([mid, mid], np.float32))[0]:
+                    hi = mid
+                else:
+                    lo = mid
+            return lo, hi
+
+        act_row = (np.array([[0.124, 0.2, 0.05, 0.15]], np.float32) if variant == "e2e"
+                   else np.array([[0.1, -0.2, 0.05, 0.22625]], np.float32))
+        for idx, nm in ((9, "p"), (10, "q"), (11, "r")):
+            for sign in (1.0, -1.0):
+                lo, hi = edge_of(idx, sign)
+                for tag, v in (("last_alive", lo), ("first_oob", hi), ("alive-1", np.float32(lo - sign * 1.0)), ("oob+1", np.float32(hi + sign * 1.0))):
+                    cases.append(("rate_%s%s_%s" % ("+" if sign > 0 else "-", nm, tag), ws(**{"s%d" % idx: v}), 0, 3))
+        for v, nm in ((hp - np.float32(1e-3), "hp-1e-3"), (hp - np.float32(1e-4), "hp-1e-4"), (-hp + np.float32(1e-3), "-hp+1e-3"),
+                      (hp + np.float32(1e-3), "hp+1e-3")):
+            cases.append(("theta_" + nm, ws(s7=v), 0, 3))
+        for v in (1.0e4, -1.0e4, 12345.678, -9876.543, 31415.926):
+            cases.append(("psi_%g" % v, ws(s8=np.float32(v)), 0, 3))
+        n = len(cases)
+        np.random.seed(11)
+        env = ns["Quadcopter3DGates"](num_envs=n, gates_pos=gp, gate_yaw=gy, start_pos=sp, gates_ahead=1)
+        env.reset()
+        env.world_states = np.stack([c[1] for c in cases]).astype(np.float32)
+        env.target_gates = np.array([c[2] for c in cases])
+        env.step_counts = np.array([c[3] for c in cases])
+        if variant == "e2e":
+            env.disturbances = np.zeros((n, 6), np.float32)
+        acts = np.tile(act_row, (n, 1))
+        env.update_states()
+        key = variant + "_"
+        out.update({key + "world0": env.world_states.copy(), key + "target0": env.target_gates.astype(np.int32),
+                    key + "steps0": env.step_counts.astype(np.int32), key + "obs0": env.states.copy(), key + "actions": acts})
+        with np.errstate(all="ignore"):
+            obs, rew, done, infos = env.step(acts)
+        out[key + "reward"] = rew
+        out[key + "done"] = done.astype(np.uint8)
+        out[key + "target"] = env.target_gates.astype(np.int32)
+        out[key + "steps"] = env.step_counts.astype(np.int32)
+        out[key + "world"] = env.world_states.copy()   # post-reset for done rows
+        out[key + "obs"] = obs.copy()
+        out[key + "names"] = np.array([c[0] for c in cases])
+    save("f11_edges", **out)
+
+
 def gen_f8_indi_traj(ns, rng):
     """F8: INDI variant trajectories (config 3 shape, small N)."""
     out = {}
@@ -492,6 +591,10 @@ def gen_f10_policy(rng):
 
 def main():
     assert ref_import.reference_available(), "reference not mounted"
+    if "--only-f11" in sys.argv:    # round 4 added F11; the other fixtures are unchanged (regenerating them is byte-identical)
+        os.makedirs(OUT, exist_ok=True)
+        gen_f11_edges(ref_import.load_e2e(), ref_import.load_indi())
+        return
     os.makedirs(OUT, exist_ok=True)
     print("importing reference notebooks ...")
     ns_e2e = ref_import.load_e2e()
@@ -509,6 +612,7 @@ def main():
     gen_f9_modes(ns_e2e, ns_indi, rng)
     gen_reset_stats(ns_e2e, ns_indi)
     gen_f10_policy(rng)
+    gen_f11_edges(ns_e2e, ns_indi)
     print("done")
 
 
