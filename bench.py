@@ -493,6 +493,26 @@ def config5_probe(n, iters=3, mb=16384):
             "us_per_update": (dt - tc) / updates * 1e6, "updates_applied": applied, "updates_skipped": skipped}
 
 
+def cpu_quota():
+    """CPU bandwidth the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown.  The
+    affinity mask can list every core of the box while the cgroup grants a few: threads beyond the quota only add contention (round 3:
+    43.9 M env-steps/s at 16 threads, 0.3 M at 256 on a box whose affinity mask said 256)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(variant, n, ga, seconds):
     """The oracle (C port of the reference, parity-pinned against reference fixtures) on this box's host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -500,7 +520,9 @@ def cpu_baseline(variant, n, ga, seconds):
     from optimal_quad_control_rl_amd import TRAIN_DISTURBANCE_RANGES, square_track, zigzag_track
     from optimal_quad_control_rl_amd.vec_env import default_residual_blob
 
-    cores = len(os.sched_getaffinity(0))
+    affinity = len(os.sched_getaffinity(0))
+    quota = cpu_quota()
+    cores = affinity if quota is None else max(1, min(affinity, int(math.ceil(quota))))   # the thread sweep stops at the quota
     trk = zigzag_track() if variant == "e2e" else square_track()
     env = O.OracleEnv(O.E2E if variant == "e2e" else O.INDI, n, *trk, gates_ahead=ga)
     if variant == "e2e":
@@ -528,7 +550,8 @@ def cpu_baseline(variant, n, ga, seconds):
             "sample": f"{out[best_threads][1]} steps x {n} envs of the same workload ({variant}, random actions) on "
                       f"oracle/quadrace_oracle.c (C port of the reference, OpenMP over envs); thread sweep "
                       + ", ".join(f"{t}t: {v[0]/1e6:.1f}M/s" for t, v in sorted(out.items())),
-            "value_1core": out[1][0], "host_cores": cores}
+            "value_1core": out[1][0], "host_cores": affinity, "cpu_quota_cores": quota,
+            "threads_swept_up_to": cores}
 
 
 def rccl_report(rt, local_ms_per_step):
@@ -590,7 +613,8 @@ def headline(result):
     h["roofline"] = flat
     cb = result.get("cpu_baseline")
     if cb:
-        h["cpu_baseline"] = {k: _short(cb.get(k), 200) for k in ("value", "unit", "cores", "kind", "sample", "value_1core", "host_cores")}
+        h["cpu_baseline"] = {k: _short(cb.get(k), 200) for k in ("value", "unit", "cores", "kind", "sample", "value_1core", "host_cores",
+                                                                    "cpu_quota_cores", "threads_swept_up_to")}
     o = result.get("indi") or result.get("e2e") or {}
     if o and "error" not in o:
         orr, ops = o.get("roofline") or {}, (o.get("per_step_launch") or {})
@@ -711,8 +735,6 @@ def run(args, rt, env_factory=make_env, closed_loop=True):
                 mo.pop("_buffers")
                 mo["unit"] = "env-steps/s"
                 mo["config"] = {"workload": workload_text(other, n, ga), "variant": other}
-                if not args.no_cpu_baseline:
-                    mo["cpu_baseline"] = cpu_baseline(other, n, ga, min(args.cpu_seconds, 6.0))
                 result[other] = mo
                 env_o.close()
             except Exception as ex:  # pragma: no cover
@@ -735,8 +757,14 @@ def run(args, rt, env_factory=make_env, closed_loop=True):
                 result["host_numpy_path"] = host_path_probe(args.variant, n, ga)
             except Exception as ex:  # pragma: no cover
                 result["host_numpy_path"] = {"error": repr(ex)}
+        # CPU legs LAST: the oracle's OpenMP workers spin for a while after every parallel region, and a host-launched GPU measurement
+        # right behind them is starved of its launch thread (that is what the 884 us / 557 us "stream_launch_us_per_update" outliers
+        # of the r03 / early r04 lines were: the PPO leg ran straight after the other variant's CPU baseline)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.variant, n, ga, args.cpu_seconds)
+            other = "indi" if args.variant == "e2e" else "e2e"
+            if not args.no_extras and isinstance(result.get(other), dict) and "error" not in result[other]:
+                result[other]["cpu_baseline"] = cpu_baseline(other, n, ga, min(args.cpu_seconds, 6.0))
         if not args.no_cpu_baseline and not args.no_extras:
             try:  # the predecessor envs of "3D quad.ipynb" (include/quad3d.h), short measurement
                 from bench_quad3d import measure as q3_measure
@@ -785,6 +813,7 @@ def spawn_ranks(args, argv):
 
 
 def main(argv=None):
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # the CPU baseline's OpenMP workers sleep between regions instead of spinning
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
