@@ -625,7 +625,8 @@ def headline(result):
                               "cpu_baseline_value": (o.get("cpu_baseline") or {}).get("value")}
     pu, c5, c5b = result.get("ppo_update") or {}, result.get("config5") or {}, result.get("config5_mb65536") or {}
     if pu or c5:
-        h["ppo"] = {"update_us_per_16384_rows": pu.get("epoch_us"), "update_useful_TFLOPs": pu.get("epoch_useful_TFLOPs"),
+        h["ppo"] = {"dtype": "f16 matrix-core operands, f32 accumulation / parameters / Adam (precision='f32' = float32 via torch: A/B mode, not timed here)",
+                    "update_us_per_16384_rows": pu.get("epoch_us"), "update_useful_TFLOPs": pu.get("epoch_useful_TFLOPs"),
                     "update_mfma_frac": None if pu.get("epoch_useful_TFLOPs") is None else pu["epoch_useful_TFLOPs"] / MFMA_F16_PEAK_TF,
                     "update_launch": "qr_ppo_epoch: one replayed graph per epoch (what training calls)",
                     "stream_launch_us_per_update": pu.get("native_us"), "torch_us": pu.get("torch_us"),
@@ -645,7 +646,7 @@ def headline(result):
                 h[k]["exchange_GBps_in_per_gpu"] = result[k]["exchange"]["GBps_in_per_gpu"]
     h["full_object"] = result.get("_full_path")
     # stay under 4 KB whatever the run produced (eight ranks add per-rank lists): shed explanatory strings first, then optional objects
-    shed = [("roofline", "frac_on_8d_bytes_is"), ("roofline", "valu_flop_source"), ("ppo", "config5_what"), ("ppo", "update_launch"),
+    shed = [("roofline", "frac_on_8d_bytes_is"), ("roofline", "valu_flop_source"), ("ppo", "config5_what"), ("ppo", "update_launch"), ("ppo", "dtype"),
             ("cpu_baseline", "sample"), ("config", "workload"), ("roofline", "traffic_source"), ("parity", None), ("other_variant", None),
             ("ppo", None), ("exchange", None), ("config4", None)]
     for obj, key in shed:

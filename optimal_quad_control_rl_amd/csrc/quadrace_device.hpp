@@ -1,10 +1,11 @@
 // quadrace_device.hpp -- gfx950 device code of the vectorised quadrotor race environment.
 //
-// One lane simulates one environment.  The step is float32 elementwise ODE work (~570 VALU instructions per env-step)
-// plus ONE small per-wave GEMM: the first layer of the residual thrust / moment MLPs runs on the f32 matrix core
-// (20 x v_mfma_f32_32x32x2_f32 per wave-step, bit-exactly a k-ordered fmaf chain; see residual_mlp() for the measurements
-// that led there).  The layout rules that matter are coalesced 16-byte-per-lane accesses, LDS-resident constant tables
-// and MLP weights held once per wave in registers.
+// One lane simulates one environment.  The step is float32 elementwise ODE work (~550 VALU instructions per env-step)
+// plus ONE small per-wave GEMM: the first layer of the residual thrust / moment MLPs runs on the matrix core -- since round 4
+// as 10 x v_mfma_f32_32x32x16_f16 per wave-step with both operands split into two f16 pieces (exact products, f32
+// accumulation: as accurate as the float32 fmaf chain / f32 matrix instruction of rounds 1-3, at a fifth of its cycles; see
+// residual_mlp() for the measurements that led there).  The layout rules that matter are coalesced 16-byte-per-lane accesses,
+// LDS-resident constant tables and MLP weights held once per wave in registers.
 //
 // Behavioural contract = the reference's Quadcopter3DGates (R: "3D quad race.ipynb",
 // I: "3D quad race INDI inner loop.ipynb"; raw .ipynb line numbers):

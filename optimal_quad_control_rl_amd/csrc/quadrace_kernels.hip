@@ -4,8 +4,8 @@
 // = one per CU; larger N simply adds workgroups (block b lands on XCD b % 8, and consecutive blocks touch
 // consecutive 4 KiB slabs of every plane, so each XCD's L2 sees disjoint, fully-used lines).
 // Per workgroup the gate table (indexed per lane by the env's target gate) is staged once into LDS; each wave
-// also owns an LDS tile for coalesced observation stores.  Residual-MLP weights live in registers (one float per
-// lane per MFMA K-step, see quadrace_device.hpp).
+// also owns an LDS tile for coalesced observation stores.  Residual-MLP weights live in registers (layer 1: five MFMA A operands
+// of eight f16 per lane; layer 2: 64 floats per lane half; see quadrace_device.hpp).
 #include "quadrace_device.hpp"
 #include "quadrace_policy.hpp"
 

@@ -34,3 +34,36 @@ def test_edge_states_f11(variant, vname, residual_blob):
     from product_adapter import ProductAdapter
 
     print(P.check_edges(ProductAdapter, variant, vname, residual_blob))
+
+
+def test_split_mlp_is_as_close_to_float64_as_the_float32_chain(residual_blob):
+    """Round 4 moved layer 1 of the residual MLPs from the f32 matrix instruction (a k-ordered fmaf chain) to f16 matrix instructions
+    with both operands split in two (x = X0 + X1, w = W0 + W1, three exact products).  The claim that keeps `dtype: f32` honest: against
+    the float64 value of the networks the kernel's outputs are as close as the float32 chain's (here: the CPU oracle) -- both within
+    ~1e-6 -- on the reference's 257 fixture rows and on 4 096 random states with inputs up to the magnitudes a live env can reach."""
+    import parity as P
+    from oracle import oracle as O
+    from product_adapter import ProductAdapter
+
+    b = residual_blob
+    W1t, b1t, W2t, b2t = b[0:224].reshape(32, 7), b[224:256], b[256:288].reshape(1, 32), b[288:289]
+    W1m, b1m, W2m, b2m = b[289:609].reshape(32, 10), b[609:641], b[641:737].reshape(3, 32), b[737:740]
+    rng = np.random.default_rng(5)
+    s_rand = np.zeros((4096, 16), np.float32)
+    s_rand[:, 3:6] = rng.uniform(-15, 15, (4096, 3)); s_rand[:, 6:9] = rng.uniform(-1.2, 1.2, (4096, 3))
+    s_rand[:, 9:12] = rng.uniform(-30, 30, (4096, 3)); s_rand[:, 12:16] = rng.uniform(-1, 1, (4096, 4))
+    for states in (P.load("f1_residual")["states"], s_rand):
+        n = states.shape[0]
+        a = ProductAdapter(0, n, P.tracks()["zigzag"], gates_ahead=0, residual=b)
+        a.set_state(states, np.zeros((n, 6), np.float32), np.zeros(n, np.int32), np.zeros(n, np.int32))
+        out = a.env.probe_residual().cpu().numpy().astype(np.float64)      # [vb(3), thrust, moment(3)]
+        vb = out[:, 0:3]
+        x = np.concatenate([states[:, 12:16].astype(np.float64), vb, states[:, 9:12].astype(np.float64)], axis=1)
+        ht = np.maximum(x[:, :7] @ W1t.T.astype(np.float64) + b1t, 0); hm = np.maximum(x @ W1m.T.astype(np.float64) + b1m, 0)
+        exact = np.concatenate([ht @ W2t.T.astype(np.float64) + b2t, hm @ W2m.T.astype(np.float64) + b2m], axis=1)   # float64, same vb
+        t_o, m_o = O.residual(b, states)                                    # the oracle's float32 chain on the same rows
+        orc = np.concatenate([t_o, m_o], axis=1).astype(np.float64)
+        scale = np.maximum(1.0, np.abs(exact))
+        e_gpu, e_chain = (np.abs(out[:, 3:7] - exact) / scale).max(), (np.abs(orc - exact) / scale).max()
+        print(f"rows {n}: split-f16 kernel vs float64 {e_gpu:.2e}; float32 chain (oracle) vs float64 {e_chain:.2e}")
+        assert e_gpu < 4e-6 and e_gpu < 3.0 * max(e_chain, 5e-7)
