@@ -145,6 +145,36 @@ template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ obs_out,
             float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+#ifdef QR_STEP_MLP_VIA_LDS   /* A/B: rounds 2-3's prologue -- the MLP table staged through LDS with the reset / gate rows */
+    constexpr int kTab = (V == kE2E) ? kMlpTableFloats : 0;
+    __shared__ __attribute__((aligned(16))) float lds[kTab + kResetTableFloats + kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool active = i < P.n;
+    const int ii = active ? i : 0;
+    QR_TICK(P, 0);
+    const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
+    float* rtab = lds + kTab;                 // [reset table | gate rows | obs tiles]
+    float* gates = rtab + kResetTableFloats;
+    const int tab_off = use_mlp ? 0 : kOffResetImage;
+    const int tab_vec = ((use_mlp ? kOffGatesImage : kResetTableFloats) + P.num_gates * kGateStride) / 4;  // <= 476
+    const float4* tsrc = reinterpret_cast<const float4*>(P.tables + tab_off);
+    float4* tdst = reinterpret_cast<float4*>(use_mlp ? lds : rtab);
+    const int t0 = threadIdx.x, t1 = threadIdx.x + kBlock;
+    const float4 tv0 = tsrc[t0 < tab_vec ? t0 : 0];
+    const float4 tv1 = tsrc[t1 < tab_vec ? t1 : 0];
+    Env<V> e;
+    load_env<V>(P, ii, e);
+    const float4 act = actions[ii];
+    QR_TICK(P, 1);
+    tdst[t0] = tv0;
+    tdst[t1] = tv1;
+    __syncthreads();
+    MlpRegs mlp;
+    if (use_mlp) mlp_load_regs(lds, lane, mlp);
+    float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * obs_len<V, GA>();
+    QR_TICK(P, 2);
+#else
     __shared__ __attribute__((aligned(16))) float lds[kResetTableFloats + kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -175,6 +205,7 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
     float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * obs_len<V, GA>();
     QR_TICK(P, 2);
 
+#endif
     const float u[4] = {act.x, act.y, act.z, act.w};
     const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
