@@ -145,14 +145,23 @@ template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ obs_out,
             float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
-#ifdef QR_STEP_MLP_VIA_LDS   /* A/B: rounds 2-3's prologue -- the MLP table staged through LDS with the reset / gate rows */
+#ifndef QR_STEP_MLP_FROM_GLOBAL   /* the MLP table is staged through LDS with the reset / gate rows (two 16-byte loads per thread), then 22 LDS
+                                   reads per lane fill the weight registers behind the barrier.  A/B (round 4, tools/step_probe.py, same box):
+                                   loading the registers straight from global memory instead -- 22 loads per lane through the texture
+                                   path -- costs 0.84 us per launch: 6.60 vs 5.77 us. */
     constexpr int kTab = (V == kE2E) ? kMlpTableFloats : 0;
     __shared__ __attribute__((aligned(16))) float lds[kTab + kResetTableFloats + kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    // Lanes past the end of a ragged batch stay ACTIVE (they shadow env 0) because the residual MLP uses
+    // wave-wide operations (MFMA, permlane swap); only their stores are suppressed.
     const bool active = i < P.n;
     const int ii = active ? i : 0;
     QR_TICK(P, 0);
+    // Prologue ordering (one wave per SIMD at N = 65 536: every exposed latency is paid in full).  Loads return in
+    // issue order (one vmcnt counter), so the table loads -- L2 hits, needed first: they go through LDS and a
+    // workgroup barrier -- are issued BEFORE the lane's state loads (HBM round trip): the LDS writes, the barrier and
+    // the 22 LDS reads that fill the residual-MLP weight registers all complete in the shadow of the state loads.
     const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
     float* rtab = lds + kTab;                 // [reset table | gate rows | obs tiles]
     float* gates = rtab + kResetTableFloats;
@@ -184,10 +193,7 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
     const int ii = active ? i : 0;
     QR_TICK(P, 0);
 
-    // Prologue ordering (one wave per SIMD at N = 65 536: every exposed latency is paid in full).  Loads return in issue order
-    // (one vmcnt counter), so they are issued in the order their data is needed: the reset / gate table (L2 hits; through LDS and a
-    // workgroup barrier) -> the residual-MLP weight registers (L2 hits, straight into registers: round 4 -- they used to be staged
-    // through LDS with the tables, 22 LDS reads behind the barrier) -> the lane's state and action (HBM round trip).
+    // (A/B form, -DQR_STEP_MLP_FROM_GLOBAL) weight registers loaded straight from global memory: SLOWER, see above
     const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
     float* rtab = lds;                        // [reset table | gate rows | obs tiles]
     float* gates = rtab + kResetTableFloats;
@@ -424,9 +430,20 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     const int tab_vec = (kResetTableFloats + P.num_gates * kGateStride) / 4;   // <= 120 float4: one load per thread
     const float4* tsrc = reinterpret_cast<const float4*>(P.tables + kOffResetImage);
     const float4 tv = tsrc[(int)threadIdx.x < tab_vec ? threadIdx.x : 0];
+    // (the non-lean form stages the MLP table through the action-slot area, which nothing uses before the first chunk: two 16-byte
+    // loads per thread + LDS reads instead of 22 global loads per lane -- the per-step kernel measured 0.84 us for that difference)
+    constexpr bool kMlpViaLds = kMlp && !kLean;
+    constexpr int kMlpVec = kMlpTableFloats / 4;   // 356 float4
+    static_assert(!kMlpViaLds || 4 * kBlock * kActChunk >= kMlpTableFloats, "the action-slot area holds the MLP table");
+    const float4* msrc = reinterpret_cast<const float4*>(P.tables);
+    float4 mv0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), mv1 = mv0;
+    if constexpr (kMlpViaLds) {
+        mv0 = msrc[threadIdx.x];
+        mv1 = msrc[(int)threadIdx.x + kBlock < kMlpVec ? threadIdx.x + kBlock : 0];
+    }
     const int2 ts0 = P.ts[ii];
     MlpRegs mlp;
-    if (kMlp) mlp_load_regs(P.tables, lane, mlp, !kALds);
+    if (kMlp && !kMlpViaLds) mlp_load_regs(P.tables, lane, mlp, !kALds);
     float4 b0, b1, b2, b3, b4, b5, b6, b7;
     b0 = b1 = b2 = b3 = b4 = b5 = b6 = b7 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if constexpr (!kLean) {
@@ -441,7 +458,16 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
         mlp_stage_a(P.tables, reinterpret_cast<u32x4*>(lds + kOffA));
         mlp.a_lds = reinterpret_cast<const u32x4*>(lds + kOffA);
     }
+    if constexpr (kMlpViaLds) {
+        float4* mdst = reinterpret_cast<float4*>(lds + kResetTableFloats + kMaxGates * kGateStride + kBlock * L);   // = the action slots
+        mdst[threadIdx.x] = mv0;
+        if ((int)threadIdx.x + kBlock < kMlpVec) mdst[threadIdx.x + kBlock] = mv1;
+    }
     __syncthreads();
+    if constexpr (kMlpViaLds) {
+        mlp_load_regs(lds + kResetTableFloats + kMaxGates * kGateStride + kBlock * L, lane, mlp);
+        __syncthreads();   // every wave has its weight registers: the area is free for the action slots
+    }
     const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
     float stash[kLean ? 1 : reset_value_count<V>()];

@@ -67,3 +67,49 @@ def test_split_mlp_is_as_close_to_float64_as_the_float32_chain(residual_blob):
         e_gpu, e_chain = (np.abs(out[:, 3:7] - exact) / scale).max(), (np.abs(orc - exact) / scale).max()
         print(f"rows {n}: split-f16 kernel vs float64 {e_gpu:.2e}; float32 chain (oracle) vs float64 {e_chain:.2e}")
         assert e_gpu < 4e-6 and e_gpu < 3.0 * max(e_chain, 5e-7)
+
+
+def test_rollout_kernel_selection_is_reported_and_every_kernel_agrees(residual_blob):
+    """qr_rollout_kernel_name reports the kernel a K-step call launches (bench.py prints it and looks its PMC evidence up under it):
+    specialised kernels in the default mode, the general ones with a pause flag or a terminal-observation buffer -- and the choice never
+    changes the results: the same env, seed and actions give bit-identical rollouts through QR_ROLLOUT_FAST=0's kernels (a subprocess:
+    the switch is read once per process)."""
+    import torch
+    from optimal_quad_control_rl_amd import Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES, square_track, zigzag_track
+
+    env = Quadcopter3DGates(4096, *zigzag_track(), gates_ahead=1, seed=3, infos_mode="none")
+    env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+    assert env.rollout_kernel_name() == "qr::rollout_fast_mlp_kernel<0, 1>"
+    env.pause_if_collision = True
+    assert env.rollout_kernel_name() == "qr::rollout_stash_kernel<0, 1>"
+    env.pause_if_collision = False
+    buf = torch.zeros((8, 4096, env.state_len), device=env.device)
+    env.set_terminal_obs_buffer(buf)
+    assert env.rollout_kernel_name() == "qr::rollout_stash_kernel<0, 1>"
+    env.set_terminal_obs_buffer(None)
+    assert env.rollout_kernel_name() == "qr::rollout_fast_mlp_kernel<0, 1>"
+    nores = Quadcopter3DGates(4096, *zigzag_track(), gates_ahead=2, seed=3, infos_mode="none", residual=None)
+    assert nores.rollout_kernel_name() == "qr::rollout_fast_kernel<0, 2>"
+    indi = Quadcopter3DGatesINDI(4096, *square_track(), gates_ahead=1, seed=3, infos_mode="none")
+    assert indi.rollout_kernel_name() == "qr::rollout_stash_kernel<1, 1>"
+    big = Quadcopter3DGates(131072, *zigzag_track(), gates_ahead=1, seed=3, infos_mode="none")
+    assert big.rollout_kernel_name() == "qr::rollout_lean_mlp_kernel<0, 1>"
+    # the same rollout through the general kernels of another process
+    code = (
+        "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+        "from optimal_quad_control_rl_amd import Quadcopter3DGates, TRAIN_DISTURBANCE_RANGES, zigzag_track\n"
+        "env = Quadcopter3DGates(4096, *zigzag_track(), gates_ahead=1, seed=3, infos_mode='none'); env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES\n"
+        "print(env.rollout_kernel_name()); env.reset_device()\n"
+        "a = torch.rand((40, 4096, 4), device='cuda', generator=torch.Generator(device='cuda').manual_seed(1)) * 2 - 1\n"
+        "o, r, d, t = env.rollout_device(a); np.save(sys.argv[1], np.concatenate([o.cpu().numpy().reshape(40, -1), r.cpu().numpy(), d.cpu().numpy().astype(np.float32)], axis=1))\n"
+    ) % ROOT
+    import tempfile
+    outs = []
+    for fast in ("1", "0"):
+        f = tempfile.mktemp(suffix=".npy")
+        env_vars = dict(os.environ, QR_ROLLOUT_FAST=fast)
+        r = subprocess.run([sys.executable, "-c", code, f], env=env_vars, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("rollout_fast_mlp_kernel" if fast == "1" else "rollout_stash_kernel") in r.stdout
+        outs.append(np.load(f))
+    assert np.array_equal(outs[0], outs[1], equal_nan=True)
