@@ -46,6 +46,8 @@ import torch  # noqa: E402
 from optimal_quad_control_rl_amd import _lib  # noqa: E402
 import bench  # noqa: E402
 
+if os.environ.get("QR_PROBE_OLD_ABI") == "1":   # a build of the round-3 sources: it has no qr_rollout_kernel_name yet
+    _lib.SIGNATURES.pop("qr_rollout_kernel_name", None)
 L = _lib.load()
 L.qr_debug_set_ticks.argtypes = [C.c_void_p, C.c_void_p]
 print(f"# {variant} K={K} stash={os.environ.get('QR_ROLLOUT_STASH', 'auto')} flags={extra}")

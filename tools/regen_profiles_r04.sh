@@ -22,8 +22,8 @@ tools/ubench/bin/valu_rate 2>&1 | grep -v amdgpu.ids > $O/${T}_valu_rate.txt
 tools/ubench/bin/mfma_f16_denorm 2>&1 | grep -v amdgpu.ids > $O/${T}_mfma_f16_denorm.txt
 export QR_PROBE_NOBUILD=1
 (echo "## round-3 sources (f32-MFMA residual layer, rollout_stash_kernel / rollout_kernel), built with -DQR_CLOCK_PROBE"
- QR_PROBE_TAG=_orig python tools/clock_probe.py e2e 200 65536,131072,1048576
- QR_PROBE_TAG=_orig python tools/clock_probe.py e2e 20 65536
+ QR_PROBE_OLD_ABI=1 QR_PROBE_TAG=_orig python tools/clock_probe.py e2e 200 65536,131072,1048576
+ QR_PROBE_OLD_ABI=1 QR_PROBE_TAG=_orig python tools/clock_probe.py e2e 20 65536
  echo "## this build (split-f16 residual layer, rollout_fast_mlp_kernel / rollout_lean_mlp_kernel)"
  python tools/clock_probe.py e2e 200 65536,131072,1048576
  python tools/clock_probe.py e2e 20 65536
