@@ -49,7 +49,7 @@ extern "C" {
 /* libquadrace.so is built with -fvisibility=hidden: only what this header declares is exported */
 #pragma GCC visibility push(default)
 
-#define QR_ABI_VERSION 3
+#define QR_ABI_VERSION 3   /* additive since 3 (no signature changed): qr_rollout_kernel_name (round 4; a benchmark / profiling hook) */
 
 enum {
     QR_OK = 0,
