@@ -488,7 +488,15 @@ __device__ __forceinline__ uint32_t acc_ready(const Acc& acc) {
 // dot(w[0..15], relu(acc[0..15])) over this lane's 16 hidden rows as four independent chains (two packed pairs), in 4-row chunks
 struct DotAcc {
     f32x2v s01 = {0.0f, 0.0f}, s23 = {0.0f, 0.0f};
-    __device__ __forceinline__ float sum() const { return (s01.x + s01.y) + (s23.x + s23.y); }
+    // (s01.x + s23.x) + (s01.y + s23.y): one packed add and one scalar add.  The scalar add is inline asm on purpose: written in C++,
+    // the SLP vectoriser pairs the final adds of DIFFERENT dot products into v_pk_add_f32 and pays for it with three v_mov per pair
+    // (18 moves + 12 packed adds for the eight sums of a step; now 8 + 8 instructions)
+    __device__ __forceinline__ float sum() const {
+        const f32x2v t = s01 + s23;
+        float r;
+        asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(t.x), "v"(t.y));
+        return r;
+    }
 };
 __device__ __forceinline__ void dot_chunk(const float* w, const f32x16& acc, int r, DotAcc& d, uint32_t ready) {
     const f32x2v down = {kReluDown, kReluDown};
