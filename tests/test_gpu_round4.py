@@ -94,22 +94,36 @@ def test_rollout_kernel_selection_is_reported_and_every_kernel_agrees(residual_b
     assert indi.rollout_kernel_name() == "qr::rollout_stash_kernel<1, 1>"
     big = Quadcopter3DGates(131072, *zigzag_track(), gates_ahead=1, seed=3, infos_mode="none")
     assert big.rollout_kernel_name() == "qr::rollout_lean_mlp_kernel<0, 1>"
-    # the same rollout through the general kernels of another process
+    # the same rollouts through the other kernels of other processes (the switches are read once per process): for every number of
+    # gates ahead, specialised (fast / lean: more than one workgroup per CU, forced here with QR_ROLLOUT_STASH=0) and general forms
     code = (
         "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
-        "from optimal_quad_control_rl_amd import Quadcopter3DGates, TRAIN_DISTURBANCE_RANGES, zigzag_track\n"
-        "env = Quadcopter3DGates(4096, *zigzag_track(), gates_ahead=1, seed=3, infos_mode='none'); env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES\n"
-        "print(env.rollout_kernel_name()); env.reset_device()\n"
-        "a = torch.rand((40, 4096, 4), device='cuda', generator=torch.Generator(device='cuda').manual_seed(1)) * 2 - 1\n"
-        "o, r, d, t = env.rollout_device(a); np.save(sys.argv[1], np.concatenate([o.cpu().numpy().reshape(40, -1), r.cpu().numpy(), d.cpu().numpy().astype(np.float32)], axis=1))\n"
+        "from optimal_quad_control_rl_amd import Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES, zigzag_track\n"
+        "rows = []\n"
+        "for ga in (0, 1, 2, 3, 4, 11):\n"
+        "    env = (Quadcopter3DGatesINDI if ga == 11 else Quadcopter3DGates)(4096, *zigzag_track(), gates_ahead=ga %% 10, seed=3, infos_mode='none')\n"
+        "    if ga != 11: env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES\n"
+        "    print(env.rollout_kernel_name()); env.reset_device()\n"
+        "    a = torch.rand((43, 4096, 4), device='cuda', generator=torch.Generator(device='cuda').manual_seed(1)) * 2 - 1\n"
+        "    o, r, d, t = env.rollout_device(a)\n"
+        "    rows.append(np.concatenate([o.cpu().numpy().reshape(43, -1), r.cpu().numpy(), d.cpu().numpy().astype(np.float32), t.cpu().numpy().astype(np.float32)], axis=1).ravel())\n"
+        "np.save(sys.argv[1], np.concatenate(rows))\n"
     ) % ROOT
     import tempfile
     outs = []
-    for fast in ("1", "0"):
+    expected = {("1", None): "rollout_fast_mlp_kernel", ("0", None): "rollout_stash_kernel", ("1", "0"): "rollout_lean_mlp_kernel",
+                ("0", "0"): "rollout_kernel"}
+    for (fast, stash), kernel in expected.items():
         f = tempfile.mktemp(suffix=".npy")
         env_vars = dict(os.environ, QR_ROLLOUT_FAST=fast)
+        env_vars.pop("QR_ROLLOUT_STASH", None)
+        if stash is not None:
+            env_vars["QR_ROLLOUT_STASH"] = stash
         r = subprocess.run([sys.executable, "-c", code, f], env=env_vars, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        assert ("rollout_fast_mlp_kernel" if fast == "1" else "rollout_stash_kernel") in r.stdout
+        names = r.stdout.strip().splitlines()
+        assert len(names) == 6 and all(("qr::%s<0, %d>" % (kernel, ga)) in r.stdout for ga in range(5)), r.stdout
+        assert names[5] == ("qr::rollout_stash_kernel<1, 1>" if stash is None else "qr::rollout_kernel<1, 1>"), r.stdout
         outs.append(np.load(f))
-    assert np.array_equal(outs[0], outs[1], equal_nan=True)
+    for other in outs[1:]:
+        assert np.array_equal(outs[0], other, equal_nan=True)
