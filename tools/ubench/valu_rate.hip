@@ -87,6 +87,18 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* cyc, in
 #undef S
         } else if (MODE == 15) {  // 1 f32 MFMA then 15 v_fma, INDEPENDENT accumulators over 2 MFMAs (no dep stall)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, h[0], acc, 0, 0, 0);
+        } else if (MODE == 16) {  // integer multiplies (Philox): low half
+#define S(j) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(h[j]) : "v"(x));
+            REP16(S) REP16(S) REP16(S) REP16(S)
+#undef S
+        } else if (MODE == 17) {  // high half
+#define S(j) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(h[j]) : "v"(x));
+            REP16(S) REP16(S) REP16(S) REP16(S)
+#undef S
+        } else if (MODE == 18) {  // both halves in one instruction
+#define S(j) asm volatile("v_mad_u64_u32 %0, %2, %1, %3, 0" : "+v"(p[j]), "+v"(h[j]), "=s"(msk) : "v"(x));
+            REP16(S) REP16(S) REP16(S) REP16(S)
+#undef S
         } else if (MODE == 9) {   // dependent v_fma chain
 #define S(j) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(h[0]) : "v"(x));
             REP16(S) REP16(S) REP16(S) REP16(S)
@@ -136,6 +148,9 @@ int main() {
     run<2>("64 indep v_mul_f32", out, cyc, 64);
     run<3>("64 indep v_add_u32", out, cyc, 64);
     run<4>("64 indep v_cndmask_b32", out, cyc, 64);
+    run<16>("64 indep v_mul_lo_u32", out, cyc, 64);
+    run<17>("64 indep v_mul_hi_u32", out, cyc, 64);
+    run<18>("64 indep v_mad_u64_u32", out, cyc, 64);
     run<9>("64 DEPENDENT v_fma_f32", out, cyc, 64);
     run<10>("64 v_permlane32_swap", out, cyc, 64);
     run<5>("4 dependent v_mfma_f32_32x32x2_f32 (per MFMA)", out, cyc, 4);
