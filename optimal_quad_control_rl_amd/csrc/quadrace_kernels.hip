@@ -395,25 +395,69 @@ __device__ __forceinline__ void obs_tile_store_rows(float* __restrict__ tile, in
 // live around the loop's back edge stayed in scratch: it is only indexable by constants after the inner loops are unrolled).
 #define QR_BURST8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
-// kLean = the same loop for launches with MORE than one workgroup per CU, where 256 registers (two waves per SIMD) is the budget:
-// no reset stash (the batched cooperative reset_done_lanes() with a wave-private LDS scratch instead), no register prefetch of the
-// next action chunk (4-step chunks loaded at the top of the chunk; the co-resident wave covers the round trip), layer-1 weight
-// operands re-read from LDS every step.
+// One step's actions of a wave, HBM -> LDS without passing through registers (gfx950 LDS-DMA): lane l's 16 bytes land at
+// lds_wave_base + 16 l.  M0 carries the LDS base and is compiler-reserved: saved and restored inside the statement.  The compiler does
+// not count this load (its own s_waitcnt values only ever over-wait because of that); the consumer waits with act_ring_wait().
+__device__ __forceinline__ void act_ring_load(const float4* __restrict__ src, uint32_t lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_wave_base) : "memory");
+}
+// Vector-memory operations complete in issue order (vmcnt): "at most N outstanding" means everything older than the last N has
+// landed.  The slot read at step k was requested at step k - R, behind that step's dynamics; a full wave then still issues that
+// step's reward and done stores (2; the observation block of the step before only from step 1 on) and in each of the R - 1 steps in
+// between kFlush observation stores, reward, done and the ring load: N = 2 + (R - 1)(kFlush + 3) operations are certainly younger.
+// The first R steps and ragged waves (which may issue none of these) wait for everything.
+template <int N>
+__device__ __forceinline__ void act_ring_wait(bool counted) {
+    static_assert(N >= 1 && N <= 63, "vmcnt is a 6-bit counter");
+    if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int V, int GA>   // lean form: slots of the action ring (a power of two)
+constexpr int lean_act_chunk() { return obs_len<V, GA>() > 32 ? 2 : 4; }
+template <int V, int GA, bool kMlp>   // floats of (dynamic) LDS of the lean form: tables, observation tiles, action slots, layer-1 operands, reset pool
+constexpr int lean_lds_floats() {
+    return kResetTableFloats + kMaxGates * kGateStride + kBlock * obs_len<V, GA>() + 4 * kBlock * lean_act_chunk<V, GA>() +
+           (kMlp ? 4 * kMlpQuads * 64 : 0) + 4 * 16 + 4 * 64 * reset_value_count<V>();
+}
+
+// kLean = the same loop for launches with MORE than one workgroup per CU, where 256 registers (two waves per SIMD) is the budget
+// and LDS takes over what the registers hold in the other form (73-81 KB per workgroup, dynamic):
+//   * no per-lane reset stash: a POOL of reset draws per wave in LDS, filled eight envs per Philox pass, ahead of need
+//     (reset_pooled(): a pass every ~8 steps instead of the 0.69 passes per step of the batched reset_done_lanes());
+//   * no register prefetch of the next action chunk: a RING of LDS slots filled by LDS-DMA (global_load_lds_dwordx4) R steps ahead --
+//     no registers, and the consumer's counted s_waitcnt never waits behind the wave's own recent stores;
+//   * layer-1 weight operands re-read from LDS every step;
+//   * the observation block of the previous step is read from LDS next to its stores, BEHIND the dynamics: read at the top of the
+//     step (as the other form does, to take the LDS latency off a lone wave's chain) its 24 registers were live through the residual
+//     MLPs and the allocator spilled two address pairs -- and the reload of a spilled value is a vector-memory wait (vmcnt(0)) that
+//     drains the wave's whole queue of outstanding stores once per step.  No scratch now, 240 registers.
+// 1 Mi envs: 36.4 -> 39.9 G env-steps/s with these three changes (pool +5 %, spill-free + ring +4 %).
 template <int V, int GA, bool kMlp, bool kLean>
 __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
                                                   float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
                                                   uint8_t* __restrict__ trunc_out) {
-    constexpr int kActChunk = kLean ? (obs_len<V, GA>() > 32 ? 2 : 4) : act_chunk<V, GA>();   // lean: static LDS <= 64 KiB with the extras below
+    constexpr int kActChunk = kLean ? lean_act_chunk<V, GA>() : act_chunk<V, GA>();
     constexpr int L = obs_len<V, GA>();
     constexpr int S = Env<V>::S;
     constexpr int kVec = 16 * L;                 // float4 elements of a wave's [64][L] observation block
     constexpr int kFlush = (kVec + 63) / 64;     // store instructions per block
     constexpr bool kALds = kLean && kMlp;
-    constexpr int kScratch = 320;                // floats of reset scratch per wave (reset_done_lanes: 1 280 B)
     constexpr int kOffA = kResetTableFloats + kMaxGates * kGateStride + kBlock * L + 4 * kBlock * kActChunk;
-    constexpr int kOffScratch = kOffA + (kALds ? 4 * kMlpQuads * 64 : 0);
-    __shared__ __attribute__((aligned(16))) float lds[kOffScratch + (kLean ? 4 * kScratch : 0)];
-    static_assert(sizeof(float) * (kOffScratch + (kLean ? 4 * kScratch : 0)) <= 65536, "static LDS");
+    constexpr int kOffWho = kOffA + (kALds ? 4 * kMlpQuads * 64 : 0);   // lean: [4 waves][16] dwords, then the reset pool [4][64][NB] float4
+    constexpr int kOffPool = kOffWho + 4 * 16;
+    static_assert(!kLean || kOffPool + 4 * 64 * reset_value_count<V>() == lean_lds_floats<V, GA, kMlp>(), "lean LDS layout");
+    float* lds;
+    if constexpr (kLean) {   // 73-81 KB per workgroup, two workgroups per CU: dynamic LDS (launch_rollout_lean sets the limit)
+        extern __shared__ __attribute__((aligned(16))) float lds_lean[];
+        lds = lds_lean;
+    } else {
+        __shared__ __attribute__((aligned(16))) float lds_fast[kOffWho];
+        static_assert(sizeof(float) * kOffWho <= 65536, "static LDS");
+        lds = lds_fast;
+    }
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool active = i < P.n;  // ragged tail lanes stay active (wave-wide MLP ops) and shadow env 0
@@ -476,7 +520,13 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
         reset_values<V>(P, rtab, (uint32_t)ts0.x >> 8, gid_lo, gid_hi, stash);   // = what reset_from_stash() would draw on first use
         stash_ok = true;
     }
-    float* scratch = lds + kOffScratch + (threadIdx.x >> 6) * kScratch;
+    uint32_t* who = nullptr;
+    float4* pool = nullptr;
+    if constexpr (kLean) {
+        who = reinterpret_cast<uint32_t*>(lds + kOffWho) + (threadIdx.x >> 6) * 16;
+        pool = reinterpret_cast<float4*>(lds + kOffPool) + (threadIdx.x >> 6) * 16 * reset_value_count<V>();
+    }
+    bool pool_ok = false;                     // lean: this lane's pool row holds the draws of its current episode
     const int wave_first = i - lane;
     const bool full_wave = wave_first + 64 <= P.n;
     float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
@@ -493,44 +543,66 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     bool any_reset = false;
     bool pending = false;                      // a tile written by the previous step waits to be streamed out (full waves)
     QR_CLOCK_STAMP(P, 1);
-    for (int k0 = 0; k0 < K; k0 += kActChunk) {
-        const int c = (K - k0 < kActChunk) ? K - k0 : kActChunk;
-        if constexpr (kLean) {                  // this chunk's actions, loaded here (clamped step index keeps the loads unconditional)
-#define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)((k0 + J < K) ? k0 + J : K - 1) * n + ii];
-            QR_BURST8(QR_X)
-#undef QR_X
+    // lean: the actions come through a RING of kActChunk LDS slots filled by LDS-DMA kActChunk steps ahead (no registers, no wait
+    // behind the wave's own stores)
+    const float4* act_src = actions + ii;       // lean: this lane's action of the step the next ring load asks for
+    [[maybe_unused]] const uint32_t ring_base =
+        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(act_slot - lane));   // LDS byte address of the wave's slot 0
+    if constexpr (kLean) {
+#pragma unroll
+        for (int j = 0; j < kActChunk; ++j) {
+            act_ring_load(act_src, ring_base + (uint32_t)j * kBlock * 16u);
+            if (j + 1 < K) act_src += n;        // clamped: past the last step the ring re-reads step K - 1 (never consumed)
         }
+    }
+    for (int k0 = 0; k0 < K; k0 += kActChunk) {   // (lean: a "chunk" is one turn of the ring)
+        const int c = (K - k0 < kActChunk) ? K - k0 : kActChunk;
+        if constexpr (!kLean) {
 #define QR_X(J) if constexpr (J < kActChunk) act_slot[J * kBlock] = b##J;
-        QR_BURST8(QR_X)
-#undef QR_X
-        if (!kLean && k0 + kActChunk < K) {     // request the next chunk now; it lands while this chunk is simulated
-#define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)((k0 + kActChunk + J < K) ? k0 + kActChunk + J : K - 1) * n + ii];
             QR_BURST8(QR_X)
 #undef QR_X
+            if (k0 + kActChunk < K) {           // request the next chunk now; it lands while this chunk is simulated
+#define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)((k0 + kActChunk + J < K) ? k0 + kActChunk + J : K - 1) * n + ii];
+                QR_BURST8(QR_X)
+#undef QR_X
+            }
         }
         for (int j = 0; j < c; ++j) {
 #ifdef QR_PHASE_TIMING
             P.tick_on = (k0 + j == K / 2);
 #endif
             QR_TICK(P, 2);
+            if constexpr (kLean) {
+                constexpr int kYounger = 2 + (kActChunk - 1) * (kFlush + 3);
+                act_ring_wait<(kYounger < 63 ? kYounger : 63)>(full_wave && k0 > 0);
+            }
             const float4 act = act_slot[j * kBlock];
             // stream the previous step's observation block out: LDS reads here, global stores after the rotation matrix
+            // (lean: the reads happen next to the stores, behind the dynamics -- 24 registers that would otherwise be live through the
+            // residual MLPs' peak, where this form has none to spare: they spilled, and every reload of a spilled value is a vector-memory
+            // wait that drains the wave's whole store queue; the co-resident wave covers the LDS latency)
             float4 blk[kFlush];
-            if (pending) {
+            auto read_block = [&]() {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                 for (int t = 0; t < kFlush; ++t) {
                     const int el = t * 64 + lane;
                     blk[t] = tile4[((t + 1) * 64 <= kVec || el < kVec) ? el : 0];
                 }
-            }
+            };
+            if (!kLean && pending) read_block();
             const float u[4] = {act.x, act.y, act.z, act.w};
             float nw[S];
             int new_target;
             bool done, trunc;
             const float reward = step_dynamics<V, kALds>(P, gate, mlp, kMlp, lane, e, u, nw, new_target, done, trunc);
             QR_TICK(P, 5);
+            if constexpr (kLean) {              // the slot just consumed (its read has returned: the dynamics used it) gets step j + R
+                act_ring_load(act_src, ring_base + (uint32_t)j * kBlock * 16u);
+                if (k0 + j + kActChunk + 1 < K) act_src += n;
+            }
             if (pending) {
+                if constexpr (kLean) read_block();
                 float4* g4 = reinterpret_cast<float4*>(obs_step - n * L + (size_t)wave_first * L);
 #pragma unroll
                 for (int t = 0; t < kFlush; ++t) {
@@ -545,7 +617,7 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
 #pragma unroll
             for (int q = 0; q < S; ++q) e.s[q] = nw[q];
             any_reset |= done;
-            if constexpr (kLean) reset_done_lanes<V>(P, rtab, scratch, lane, done && active, e, gid_lo, gid_hi);
+            if constexpr (kLean) reset_pooled<V>(P, rtab, who, pool, lane, done && active, e, gid_lo, gid_hi, pool_ok);
             else reset_from_stash<V>(P, rtab, done && active, e, gid_lo, gid_hi, stash, stash_ok);
             if (active) {
                 stream_store(rew_step + i, reward);
@@ -604,6 +676,13 @@ rollout_lean_mlp_kernel(Params P, int K, const float4* __restrict__ actions, flo
                         float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
     static_assert(V == kE2E, "residual MLPs belong to the E2E model");
     rollout_fast_body<V, GA, true, true>(P, K, actions, obs_out, rew_out, done_out, trunc_out);
+}
+
+template <int V, int GA>   // INDI / E2E without the residual MLPs, more than one workgroup per CU
+__global__ void __launch_bounds__(kBlock, 2)
+rollout_lean_kernel(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
+                    float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+    rollout_fast_body<V, GA, false, true>(P, K, actions, obs_out, rew_out, done_out, trunc_out);
 }
 
 template <int V, int GA>
@@ -921,19 +1000,24 @@ hipError_t launch_step(int variant, const Params& P, const float* actions, float
 
 // the reset stash costs 24 registers for the whole loop: worth it while every workgroup has a CU to itself (then the wave's budget is
 // 512 registers anyway); beyond that the plain form keeps two workgroups per CU.  QR_ROLLOUT_STASH=0 / 1 forces the choice.
-static bool use_rollout_stash(int n) {
-    static int forced = -2, cus = 0;
-    if (forced == -2) {
-        const char* v = getenv("QR_ROLLOUT_STASH");
-        forced = v ? (v[0] == '0' ? 0 : 1) : -1;
-    }
-    if (forced >= 0) return forced == 1;
+static int n_wgs(int n) { return (n + kBlock - 1) / kBlock; }
+static int device_cus() {
+    static int cus = 0;
     if (cus == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
     }
-    return (n + kBlock - 1) / kBlock <= cus;
+    return cus;
+}
+static bool use_rollout_stash(int n) {
+    static int forced = -2;
+    if (forced == -2) {
+        const char* v = getenv("QR_ROLLOUT_STASH");
+        forced = v ? (v[0] == '0' ? 0 : 1) : -1;
+    }
+    if (forced >= 0) return forced == 1;
+    return (n + kBlock - 1) / kBlock <= device_cus();
 }
 
 // QR_ROLLOUT_FAST=0 keeps the round-3 kernels for every launch (A/B switch; the results are bit-identical either way)
@@ -952,8 +1036,10 @@ static bool rollout_fast_enabled() {
 //       E2E + residual MLPs -> rollout_fast_mlp_kernel, E2E without -> rollout_fast_kernel, INDI -> rollout_stash_kernel (HBM-bound at
 //       65 536 envs: the general stash kernel is as fast per step, 2 443 vs 2 503 cycles, and has the shorter prologue)
 //   at most one workgroup per CU, any other mode -> rollout_stash_kernel
-//   more workgroups: E2E + residual MLPs in the default mode -> rollout_lean_mlp_kernel, everything else -> rollout_kernel
-enum RolloutKernel { kRkFastMlp, kRkFast, kRkStash, kRkLeanMlp, kRkPlain };
+//   more workgroups, default mode: E2E + residual MLPs -> rollout_lean_mlp_kernel, INDI / E2E without -> rollout_lean_kernel up to four
+//       workgroups per CU;
+//   more workgroups, anything else -> rollout_kernel
+enum RolloutKernel { kRkFastMlp, kRkFast, kRkStash, kRkLeanMlp, kRkLean, kRkPlain };
 static RolloutKernel select_rollout(int variant, const Params& P) {
     const bool plain_mode = !(P.flags & (kFlagPause | kFlagPauseIfCollision)) && P.term_obs == nullptr && rollout_fast_enabled();
     const bool mlp = variant == kE2E && (P.flags & kFlagResidual);
@@ -962,7 +1048,11 @@ static RolloutKernel select_rollout(int variant, const Params& P) {
         if (plain_mode && variant == kE2E) return kRkFast;
         return kRkStash;
     }
-    return (plain_mode && mlp) ? kRkLeanMlp : kRkPlain;
+    if (plain_mode && mlp) return kRkLeanMlp;
+    // without the MLPs the model is memory-bound, and the lean form's LDS (52 KB: three workgroups per CU) is its occupancy limit where
+    // the general form has four: INDI 61.8 vs 56.4 G env-steps/s at 262 144 envs (4 workgroups of work per CU), 56.4 vs 58.0 at 1 Mi
+    if (plain_mode && (n_wgs(P.n) <= 4 * device_cus())) return kRkLean;
+    return kRkPlain;
 }
 
 const char* rollout_kernel_name(int variant, const Params& P) {
@@ -971,8 +1061,43 @@ const char* rollout_kernel_name(int variant, const Params& P) {
         case kRkFast: return "rollout_fast_kernel";
         case kRkStash: return "rollout_stash_kernel";
         case kRkLeanMlp: return "rollout_lean_mlp_kernel";
+        case kRkLean: return "rollout_lean_kernel";
         default: return "rollout_kernel";
     }
+}
+
+// the lean forms' LDS is dynamic (more than the 64 KB a static array may have): limit set once per device and instantiation
+template <int V, int GA, bool kMlp>
+static hipError_t launch_rollout_lean_vg(const Params& P, int K, const float4* a4, float* obs, float* rew, uint8_t* done,
+                                         uint8_t* trunc, hipStream_t st) {
+    constexpr size_t lds = sizeof(float) * lean_lds_floats<V, GA, kMlp>();
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    static unsigned long long configured = 0;   // per device ordinal
+    if constexpr (kMlp) {
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(rollout_lean_mlp_kernel<V, GA>), lds, configured)) return e;
+        hipLaunchKernelGGL((rollout_lean_mlp_kernel<V, GA>), grid_for(P.n), dim3(kBlock), lds, st, P, K, a4, obs, rew, done, trunc);
+    } else {
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(rollout_lean_kernel<V, GA>), lds, configured)) return e;
+        hipLaunchKernelGGL((rollout_lean_kernel<V, GA>), grid_for(P.n), dim3(kBlock), lds, st, P, K, a4, obs, rew, done, trunc);
+    }
+    return hipGetLastError();
+}
+template <int V, bool kMlp>
+static hipError_t launch_rollout_lean(const Params& P, int K, const float4* a4, float* obs, float* rew, uint8_t* done,
+                                      uint8_t* trunc, hipStream_t st) {
+#ifdef QR_GA_ONLY
+    if (P.gates_ahead != QR_GA_ONLY) return hipErrorInvalidValue;
+    return launch_rollout_lean_vg<V, QR_GA_ONLY, kMlp>(P, K, a4, obs, rew, done, trunc, st);
+#else
+    switch (P.gates_ahead) {
+        case 0: return launch_rollout_lean_vg<V, 0, kMlp>(P, K, a4, obs, rew, done, trunc, st);
+        case 1: return launch_rollout_lean_vg<V, 1, kMlp>(P, K, a4, obs, rew, done, trunc, st);
+        case 2: return launch_rollout_lean_vg<V, 2, kMlp>(P, K, a4, obs, rew, done, trunc, st);
+        case 3: return launch_rollout_lean_vg<V, 3, kMlp>(P, K, a4, obs, rew, done, trunc, st);
+        case 4: return launch_rollout_lean_vg<V, 4, kMlp>(P, K, a4, obs, rew, done, trunc, st);
+        default: return hipErrorInvalidValue;
+    }
+#endif
 }
 
 hipError_t launch_rollout(int variant, const Params& P, int K, const float* actions, float* obs, float* rew,
@@ -981,7 +1106,10 @@ hipError_t launch_rollout(int variant, const Params& P, int K, const float* acti
     switch (select_rollout(variant, P)) {
         case kRkFastMlp: { QR_DISPATCH_GA(kE2E, rollout_fast_mlp_kernel, P, K, a4, obs, rew, done, trunc) } break;
         case kRkFast: { QR_DISPATCH_GA(kE2E, rollout_fast_kernel, P, K, a4, obs, rew, done, trunc) } break;
-        case kRkLeanMlp: { QR_DISPATCH_GA(kE2E, rollout_lean_mlp_kernel, P, K, a4, obs, rew, done, trunc) } break;
+        case kRkLeanMlp: return launch_rollout_lean<kE2E, true>(P, K, a4, obs, rew, done, trunc, st);
+        case kRkLean:
+            if (variant == kE2E) return launch_rollout_lean<kE2E, false>(P, K, a4, obs, rew, done, trunc, st);
+            return launch_rollout_lean<kINDI, false>(P, K, a4, obs, rew, done, trunc, st);
         case kRkStash:
             if (variant == kE2E) { QR_DISPATCH_GA(kE2E, rollout_stash_kernel, P, K, a4, obs, rew, done, trunc) }
             else { QR_DISPATCH_GA(kINDI, rollout_stash_kernel, P, K, a4, obs, rew, done, trunc) }

@@ -94,6 +94,10 @@ def test_rollout_kernel_selection_is_reported_and_every_kernel_agrees(residual_b
     assert indi.rollout_kernel_name() == "qr::rollout_stash_kernel<1, 1>"
     big = Quadcopter3DGates(131072, *zigzag_track(), gates_ahead=1, seed=3, infos_mode="none")
     assert big.rollout_kernel_name() == "qr::rollout_lean_mlp_kernel<0, 1>"
+    big_indi = Quadcopter3DGatesINDI(131072, *square_track(), gates_ahead=1, seed=3, infos_mode="none")
+    assert big_indi.rollout_kernel_name() == "qr::rollout_lean_kernel<1, 1>"
+    big_indi.pause_if_collision = True
+    assert big_indi.rollout_kernel_name() == "qr::rollout_kernel<1, 1>"
     # the same rollouts through the other kernels of other processes (the switches are read once per process): for every number of
     # gates ahead, specialised (fast / lean: more than one workgroup per CU, forced here with QR_ROLLOUT_STASH=0) and general forms
     code = (
@@ -123,7 +127,8 @@ def test_rollout_kernel_selection_is_reported_and_every_kernel_agrees(residual_b
         assert r.returncode == 0, r.stderr[-2000:]
         names = r.stdout.strip().splitlines()
         assert len(names) == 6 and all(("qr::%s<0, %d>" % (kernel, ga)) in r.stdout for ga in range(5)), r.stdout
-        assert names[5] == ("qr::rollout_stash_kernel<1, 1>" if stash is None else "qr::rollout_kernel<1, 1>"), r.stdout
+        indi = "qr::rollout_stash_kernel<1, 1>" if stash is None else ("qr::rollout_lean_kernel<1, 1>" if fast == "1" else "qr::rollout_kernel<1, 1>")
+        assert names[5] == indi, r.stdout
         outs.append(np.load(f))
     for other in outs[1:]:
         assert np.array_equal(outs[0], other, equal_nan=True)
