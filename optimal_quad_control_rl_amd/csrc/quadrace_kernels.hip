@@ -415,6 +415,14 @@ __device__ __forceinline__ void act_ring_wait(bool counted) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// The one-wave form keeps its register prefetch of whole action chunks: with the ring (-DQR_FAST_RING=1) its step takes 4 078 instead of
+// 3 881 cycles in the clock-probe build and + 1 % / +- 2 % (K = 1000 / K = 20) on the wall clock in the production build -- a lone wave
+// pays for the extra scalar work and for the scheduling fences of the asm statements, and the once-per-chunk drain the ring removes costs
+// it little (profiles/r04_ring_ab.txt).
+#ifndef QR_FAST_RING
+#define QR_FAST_RING 0
+#endif
+
 template <int V, int GA>   // lean form: slots of the action ring (a power of two)
 constexpr int lean_act_chunk() { return obs_len<V, GA>() > 32 ? 2 : 4; }
 template <int V, int GA, bool kMlp>   // floats of (dynamic) LDS of the lean form: tables, observation tiles, action slots, layer-1 operands, reset pool
@@ -445,6 +453,7 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     constexpr int kVec = 16 * L;                 // float4 elements of a wave's [64][L] observation block
     constexpr int kFlush = (kVec + 63) / 64;     // store instructions per block
     constexpr bool kALds = kLean && kMlp;
+    constexpr bool kRing = kLean || (QR_FAST_RING != 0);   // actions through the LDS-DMA ring (else: register prefetch of whole chunks)
     constexpr int kOffA = kResetTableFloats + kMaxGates * kGateStride + kBlock * L + 4 * kBlock * kActChunk;
     constexpr int kOffWho = kOffA + (kALds ? 4 * kMlpQuads * 64 : 0);   // lean: [4 waves][16] dwords, then the reset pool [4][64][NB] float4
     constexpr int kOffPool = kOffWho + 4 * 16;
@@ -490,7 +499,7 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     if (kMlp && !kMlpViaLds) mlp_load_regs(P.tables, lane, mlp, !kALds);
     float4 b0, b1, b2, b3, b4, b5, b6, b7;
     b0 = b1 = b2 = b3 = b4 = b5 = b6 = b7 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if constexpr (!kLean) {
+    if constexpr (!kRing) {
 #define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)(J < K ? J : K - 1) * n + ii];
         QR_BURST8(QR_X)
 #undef QR_X
@@ -512,6 +521,22 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
         mlp_load_regs(lds + kResetTableFloats + kMaxGates * kGateStride + kBlock * L, lane, mlp);
         __syncthreads();   // every wave has its weight registers: the area is free for the action slots
     }
+    // kRing: the actions come through a RING of kActChunk LDS slots filled by LDS-DMA kActChunk steps ahead: no registers, no chunk boundary,
+    // and the consumer's counted wait never waits behind the wave's own recent stores.  (With the register prefetch of whole chunks the
+    // compiler waits vmcnt(7..0) for the eight loads at the top of every chunk -- it cannot count the stores of the inner loop -- i.e. the
+    // store queue drains once per chunk.)  First turn requested here (the one-wave form's slot area held the MLP table until the barrier
+    // above).
+    float4* const act_slot = reinterpret_cast<float4*>(lds + kResetTableFloats + kMaxGates * kGateStride + kBlock * L) + threadIdx.x;
+    const float4* act_src = actions + ii;       // this lane's action of the step the next ring load asks for
+    [[maybe_unused]] const uint32_t ring_base =
+        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(act_slot - lane));   // LDS byte address of the wave's slot 0
+    if constexpr (kRing) {
+#pragma unroll
+        for (int j = 0; j < kActChunk; ++j) {
+            act_ring_load(act_src, ring_base + (uint32_t)j * kBlock * 16u);
+            if (j + 1 < K) act_src += n;        // clamped: past the last step the ring re-reads step K - 1 (never consumed)
+        }
+    }
     const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
     float stash[kLean ? 1 : reset_value_count<V>()];
@@ -530,7 +555,6 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     const int wave_first = i - lane;
     const bool full_wave = wave_first + 64 <= P.n;
     float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
-    float4* act_slot = reinterpret_cast<float4*>(gates + kMaxGates * kGateStride + kBlock * L) + threadIdx.x;
     // per-step output rows: scalar bases (advanced by scalar adds) + constant per-lane offsets
     const float4* tile4 = reinterpret_cast<const float4*>(tile);
     float* obs_step = obs_out;                 // row k of [K][n][L]
@@ -543,21 +567,9 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     bool any_reset = false;
     bool pending = false;                      // a tile written by the previous step waits to be streamed out (full waves)
     QR_CLOCK_STAMP(P, 1);
-    // lean: the actions come through a RING of kActChunk LDS slots filled by LDS-DMA kActChunk steps ahead (no registers, no wait
-    // behind the wave's own stores)
-    const float4* act_src = actions + ii;       // lean: this lane's action of the step the next ring load asks for
-    [[maybe_unused]] const uint32_t ring_base =
-        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(act_slot - lane));   // LDS byte address of the wave's slot 0
-    if constexpr (kLean) {
-#pragma unroll
-        for (int j = 0; j < kActChunk; ++j) {
-            act_ring_load(act_src, ring_base + (uint32_t)j * kBlock * 16u);
-            if (j + 1 < K) act_src += n;        // clamped: past the last step the ring re-reads step K - 1 (never consumed)
-        }
-    }
-    for (int k0 = 0; k0 < K; k0 += kActChunk) {   // (lean: a "chunk" is one turn of the ring)
+    for (int k0 = 0; k0 < K; k0 += kActChunk) {   // (ring: a "chunk" is one turn of the ring)
         const int c = (K - k0 < kActChunk) ? K - k0 : kActChunk;
-        if constexpr (!kLean) {
+        if constexpr (!kRing) {
 #define QR_X(J) if constexpr (J < kActChunk) act_slot[J * kBlock] = b##J;
             QR_BURST8(QR_X)
 #undef QR_X
@@ -572,8 +584,10 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
             P.tick_on = (k0 + j == K / 2);
 #endif
             QR_TICK(P, 2);
-            if constexpr (kLean) {
+            if constexpr (kRing) {
                 constexpr int kYounger = 2 + (kActChunk - 1) * (kFlush + 3);
+                // first turn: wait for everything (exact counts per step of the first turn were built and measured: 38.5 instead of
+                // 39.1 G env-steps/s at 1 Mi envs, a tie at K = 32 -- the extra branches cost more than the four early drains)
                 act_ring_wait<(kYounger < 63 ? kYounger : 63)>(full_wave && k0 > 0);
             }
             const float4 act = act_slot[j * kBlock];
@@ -597,7 +611,7 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
             bool done, trunc;
             const float reward = step_dynamics<V, kALds>(P, gate, mlp, kMlp, lane, e, u, nw, new_target, done, trunc);
             QR_TICK(P, 5);
-            if constexpr (kLean) {              // the slot just consumed (its read has returned: the dynamics used it) gets step j + R
+            if constexpr (kRing) {              // the slot just consumed (its read has returned: the dynamics used it) gets step j + R
                 act_ring_load(act_src, ring_base + (uint32_t)j * kBlock * 16u);
                 if (k0 + j + kActChunk + 1 < K) act_src += n;
             }
