@@ -104,11 +104,12 @@ def test_rollout_kernel_selection_is_reported_and_every_kernel_agrees(residual_b
         "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
         "from optimal_quad_control_rl_amd import Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES, zigzag_track\n"
         "rows = []\n"
-        "for ga in (0, 1, 2, 3, 4, 11):\n"
-        "    env = (Quadcopter3DGatesINDI if ga == 11 else Quadcopter3DGates)(4096, *zigzag_track(), gates_ahead=ga %% 10, seed=3, infos_mode='none')\n"
+        "for ga in (0, 1, 2, 3, 4, 11, 21):\n"   # 11: INDI; 21: a ragged env count (part-filled last wave, workgroup with empty waves)
+        "    n = 4096 if ga != 21 else 4096 + 64 + 37\n"
+        "    env = (Quadcopter3DGatesINDI if ga == 11 else Quadcopter3DGates)(n, *zigzag_track(), gates_ahead=ga %% 10, seed=3, infos_mode='none')\n"
         "    if ga != 11: env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES\n"
         "    print(env.rollout_kernel_name()); env.reset_device()\n"
-        "    a = torch.rand((43, 4096, 4), device='cuda', generator=torch.Generator(device='cuda').manual_seed(1)) * 2 - 1\n"
+        "    a = torch.rand((43, n, 4), device='cuda', generator=torch.Generator(device='cuda').manual_seed(1)) * 2 - 1\n"
         "    o, r, d, t = env.rollout_device(a)\n"
         "    rows.append(np.concatenate([o.cpu().numpy().reshape(43, -1), r.cpu().numpy(), d.cpu().numpy().astype(np.float32), t.cpu().numpy().astype(np.float32)], axis=1).ravel())\n"
         "np.save(sys.argv[1], np.concatenate(rows))\n"
@@ -126,7 +127,8 @@ def test_rollout_kernel_selection_is_reported_and_every_kernel_agrees(residual_b
         r = subprocess.run([sys.executable, "-c", code, f], env=env_vars, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         names = r.stdout.strip().splitlines()
-        assert len(names) == 6 and all(("qr::%s<0, %d>" % (kernel, ga)) in r.stdout for ga in range(5)), r.stdout
+        assert len(names) == 7 and all(("qr::%s<0, %d>" % (kernel, ga)) in r.stdout for ga in range(5)), r.stdout
+        assert names[6] == "qr::%s<0, 1>" % kernel, r.stdout
         indi = "qr::rollout_stash_kernel<1, 1>" if stash is None else ("qr::rollout_lean_kernel<1, 1>" if fast == "1" else "qr::rollout_kernel<1, 1>")
         assert names[5] == indi, r.stdout
         outs.append(np.load(f))
