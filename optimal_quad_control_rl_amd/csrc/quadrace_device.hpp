@@ -556,10 +556,13 @@ struct DotAcc {
     // (s01.x + s23.x) + (s01.y + s23.y): one packed add and one scalar add.  The scalar add is inline asm on purpose: written in C++,
     // the SLP vectoriser pairs the final adds of DIFFERENT dot products into v_pk_add_f32 and pays for it with three v_mov per pair
     // (18 moves + 12 packed adds for the eight sums of a step; now 8 + 8 instructions)
+    // (The add itself stays VISIBLE to the compiler -- its result feeds v_permlane32_swap, and a VALU write -> permlane read needs wait
+    // states that the hazard recogniser only inserts for instructions it can see; as `asm("v_add_f32 ...")`, the first form, nothing
+    // guaranteed them.  The empty asm only makes the RESULT opaque, which is enough to keep the vectoriser from pairing the adds.)
     __device__ __forceinline__ float sum() const {
         const f32x2v t = s01 + s23;
-        float r;
-        asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(t.x), "v"(t.y));
+        float r = t.x + t.y;
+        asm("" : "+v"(r));
         return r;
     }
 };

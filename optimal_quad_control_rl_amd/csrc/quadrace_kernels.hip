@@ -415,12 +415,17 @@ __device__ __forceinline__ void act_ring_wait(bool counted) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// The one-wave form keeps its register prefetch of whole action chunks: with the ring (-DQR_FAST_RING=1) its step takes 4 078 instead of
-// 3 881 cycles in the clock-probe build and + 1 % / +- 2 % (K = 1000 / K = 20) on the wall clock in the production build -- a lone wave
-// pays for the extra scalar work and for the scheduling fences of the asm statements, and the once-per-chunk drain the ring removes costs
-// it little (profiles/r04_ring_ab.txt).
+// A/B switches of the action path (defaults = what ships).  The one-wave form with the ring (-DQR_FAST_RING=1): 4 078 instead of 3 881
+// cycles per step in the clock-probe build, + 1 % / +- 2 % (K = 1000 / K = 20) on the wall clock in the production build
+// (profiles/r04_ring_ab.txt) -- never enabled.  The lean form: see the note at rollout_fast_body.
 #ifndef QR_FAST_RING
 #define QR_FAST_RING 0
+#endif
+#ifndef QR_LEAN_RING
+#define QR_LEAN_RING 0
+#endif
+#ifndef QR_LEAN_PREFETCH
+#define QR_LEAN_PREFETCH 1
 #endif
 
 template <int V, int GA>   // lean form: slots of the action ring (a power of two)
@@ -435,14 +440,26 @@ constexpr int lean_lds_floats() {
 // and LDS takes over what the registers hold in the other form (73-81 KB per workgroup, dynamic):
 //   * no per-lane reset stash: a POOL of reset draws per wave in LDS, filled eight envs per Philox pass, ahead of need
 //     (reset_pooled(): a pass every ~8 steps instead of the 0.69 passes per step of the batched reset_done_lanes());
-//   * no register prefetch of the next action chunk: a RING of LDS slots filled by LDS-DMA (global_load_lds_dwordx4) R steps ahead --
-//     no registers, and the consumer's counted s_waitcnt never waits behind the wave's own recent stores;
 //   * layer-1 weight operands re-read from LDS every step;
 //   * the observation block of the previous step is read from LDS next to its stores, BEHIND the dynamics: read at the top of the
 //     step (as the other form does, to take the LDS latency off a lone wave's chain) its 24 registers were live through the residual
 //     MLPs and the allocator spilled two address pairs -- and the reload of a spilled value is a vector-memory wait (vmcnt(0)) that
-//     drains the wave's whole queue of outstanding stores once per step.  No scratch now, 240 registers.
-// 1 Mi envs: 36.4 -> 39.9 G env-steps/s with these three changes (pool +5 %, spill-free + ring +4 %).
+//     drains the wave's whole queue of outstanding stores once per step;
+//   * 4-step action chunks, the next chunk requested into 16 registers a chunk ahead (as in the other form).
+// 1 Mi envs: 36.4 -> 38 G env-steps/s (A/B on one box: + 4-5 %).
+//
+// WHAT IS NOT IN IT, and why (profiles/r04_lean_ab.txt, tests/test_gpu_round4.py::test_lean_forms_agree...under_full_chip_load):
+// an action RING filled by LDS-DMA (-DQR_LEAN_RING=1: global_load_lds_dwordx4 R steps ahead, consumer waiting with a counted
+// s_waitcnt) was + 4 % on top (39-40 G at 1 Mi envs) and passed every test of the suite as it stood -- all of which run at most one
+// workgroup per CU.  With TWO workgroups per CU (131 072 envs and more) it loses the reward stores of lanes 48-63 of a wave in rare
+// steps (16-96 of 4e7 values per 40-step rollout at 1 Mi envs; observations and done flags stay right; never at one workgroup per
+// CU; nondeterministic).  The same happens -- massively, observations included -- with the chunk's actions loaded at the top of the
+// chunk (-DQR_LEAN_PREFETCH=0, plain C++, no asm), and NOT with the batched reset in place of the pool, nor with the pool's store
+// made unconditional, nor with this form (0 mismatches in 26 rollouts of 40 steps at 131 072 ... 2 Mi envs, all gate counts, both
+// variants, against K x step_kernel).  The failing lanes are the last quarter of the wave, the failing steps are steps in which
+// the wave resets nothing, two co-resident workgroups are necessary: a hardware-level ordering effect that depends on the code
+// around it, whose cause was NOT established in the time left.  What ships is the form that passes, guarded by that test; the
+// switches stay for whoever picks this up.
 template <int V, int GA, bool kMlp, bool kLean>
 __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
                                                   float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
@@ -453,7 +470,8 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     constexpr int kVec = 16 * L;                 // float4 elements of a wave's [64][L] observation block
     constexpr int kFlush = (kVec + 63) / 64;     // store instructions per block
     constexpr bool kALds = kLean && kMlp;
-    constexpr bool kRing = kLean || (QR_FAST_RING != 0);   // actions through the LDS-DMA ring (else: register prefetch of whole chunks)
+    constexpr bool kRing = kLean ? (QR_LEAN_RING != 0) : (QR_FAST_RING != 0);   // actions through the LDS-DMA ring (A/B builds only)
+    constexpr bool kPrefetch = !kRing && (!kLean || (QR_LEAN_PREFETCH != 0));       // next chunk requested into registers a chunk ahead
     constexpr int kOffA = kResetTableFloats + kMaxGates * kGateStride + kBlock * L + 4 * kBlock * kActChunk;
     constexpr int kOffWho = kOffA + (kALds ? 4 * kMlpQuads * 64 : 0);   // lean: [4 waves][16] dwords, then the reset pool [4][64][NB] float4
     constexpr int kOffPool = kOffWho + 4 * 16;
@@ -499,7 +517,7 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     if (kMlp && !kMlpViaLds) mlp_load_regs(P.tables, lane, mlp, !kALds);
     float4 b0, b1, b2, b3, b4, b5, b6, b7;
     b0 = b1 = b2 = b3 = b4 = b5 = b6 = b7 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if constexpr (!kRing) {
+    if constexpr (kPrefetch) {
 #define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)(J < K ? J : K - 1) * n + ii];
         QR_BURST8(QR_X)
 #undef QR_X
@@ -521,11 +539,11 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
         mlp_load_regs(lds + kResetTableFloats + kMaxGates * kGateStride + kBlock * L, lane, mlp);
         __syncthreads();   // every wave has its weight registers: the area is free for the action slots
     }
-    // kRing: the actions come through a RING of kActChunk LDS slots filled by LDS-DMA kActChunk steps ahead: no registers, no chunk boundary,
-    // and the consumer's counted wait never waits behind the wave's own recent stores.  (With the register prefetch of whole chunks the
-    // compiler waits vmcnt(7..0) for the eight loads at the top of every chunk -- it cannot count the stores of the inner loop -- i.e. the
-    // store queue drains once per chunk.)  First turn requested here (the one-wave form's slot area held the MLP table until the barrier
-    // above).
+    // kRing (A/B builds only, see above): the actions come through a RING of kActChunk LDS slots filled by LDS-DMA kActChunk steps ahead:
+    // no registers, no chunk boundary, and the consumer's counted wait never waits behind the wave's own recent stores.  (With the
+    // register prefetch of whole chunks the compiler waits vmcnt(7..0) for the loads at the top of every chunk -- it cannot count the
+    // stores of the inner loop -- i.e. the store queue drains once per chunk.)  First turn requested here (the one-wave form's slot
+    // area held the MLP table until the barrier above).
     float4* const act_slot = reinterpret_cast<float4*>(lds + kResetTableFloats + kMaxGates * kGateStride + kBlock * L) + threadIdx.x;
     const float4* act_src = actions + ii;       // this lane's action of the step the next ring load asks for
     [[maybe_unused]] const uint32_t ring_base =
@@ -569,11 +587,16 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     QR_CLOCK_STAMP(P, 1);
     for (int k0 = 0; k0 < K; k0 += kActChunk) {   // (ring: a "chunk" is one turn of the ring)
         const int c = (K - k0 < kActChunk) ? K - k0 : kActChunk;
+        if constexpr (!kRing && !kPrefetch) {   // this chunk's actions, loaded here (clamped step index keeps the loads unconditional)
+#define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)((k0 + J < K) ? k0 + J : K - 1) * n + ii];
+            QR_BURST8(QR_X)
+#undef QR_X
+        }
         if constexpr (!kRing) {
 #define QR_X(J) if constexpr (J < kActChunk) act_slot[J * kBlock] = b##J;
             QR_BURST8(QR_X)
 #undef QR_X
-            if (k0 + kActChunk < K) {           // request the next chunk now; it lands while this chunk is simulated
+            if (kPrefetch && k0 + kActChunk < K) {   // request the next chunk now; it lands while this chunk is simulated
 #define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)((k0 + kActChunk + J < K) ? k0 + kActChunk + J : K - 1) * n + ii];
                 QR_BURST8(QR_X)
 #undef QR_X
@@ -1084,8 +1107,9 @@ const char* rollout_kernel_name(int variant, const Params& P) {
 template <int V, int GA, bool kMlp>
 static hipError_t launch_rollout_lean_vg(const Params& P, int K, const float4* a4, float* obs, float* rew, uint8_t* done,
                                          uint8_t* trunc, hipStream_t st) {
-    constexpr size_t lds = sizeof(float) * lean_lds_floats<V, GA, kMlp>();
-    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    constexpr size_t lds_need = sizeof(float) * lean_lds_floats<V, GA, kMlp>();
+    static_assert(2 * lds_need <= 160 * 1024, "two workgroups per CU");
+    constexpr size_t lds = lds_need;
     static unsigned long long configured = 0;   // per device ordinal
     if constexpr (kMlp) {
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(rollout_lean_mlp_kernel<V, GA>), lds, configured)) return e;

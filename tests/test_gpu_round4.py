@@ -1,5 +1,6 @@
 """GPU: round-4 tests -- bench.py's own rank launcher on a box with too few GPUs, the edge-case fixture F11 (NaN states, rates at the
 1000 rad/s guard, theta at +-pi/2, huge psi) and whatever else round 4 adds."""
+import json
 import os
 import subprocess
 import sys
@@ -134,3 +135,41 @@ def test_rollout_kernel_selection_is_reported_and_every_kernel_agrees(residual_b
         outs.append(np.load(f))
     for other in outs[1:]:
         assert np.array_equal(outs[0], other, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_lean_forms_agree_with_the_general_kernels_under_full_chip_load():
+    """Every test above runs at most one workgroup per CU.  The lean fused forms exist for MORE, and an earlier version of them
+    (actions through an LDS-DMA ring, or loaded at the top of each chunk) lost the reward stores of lanes 48-63 of a wave in rare steps
+    -- only with two workgroups per CU, nondeterministically, passing everything else (csrc/quadrace_kernels.hip, note at
+    rollout_fast_body; tools/lean_stress.py).  So: 1 Mi envs E2E (16 waves per SIMD queued, the memory system saturated by the stores)
+    and 262 144 envs INDI, three 40-step rollouts each: digests of every output and a strided sample must equal those of the general
+    kernels (QR_ROLLOUT_FAST=0, another process)."""
+    code = (
+        "import sys, json, torch; sys.path.insert(0, %r)\n"
+        "from optimal_quad_control_rl_amd import Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES, square_track\n"
+        "res = {}\n"
+        "for name, cls, n in (('e2e', Quadcopter3DGates, 1 << 20), ('indi', Quadcopter3DGatesINDI, 1 << 18)):\n"
+        "    env = cls(n, *square_track(), gates_ahead=1, seed=5, infos_mode='none')\n"
+        "    if name == 'e2e': env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES\n"
+        "    env.reset_device()\n"
+        "    a = torch.rand((40, n, 4), device='cuda', generator=torch.Generator(device='cuda').manual_seed(2)) * 2 - 1\n"
+        "    digs = []\n"
+        "    for rep in range(3):\n"
+        "        o, r, d, t = env.rollout_device(a)\n"
+        "        digs.append([int(o.view(torch.int32).to(torch.int64).sum()), int(r.view(torch.int32).to(torch.int64).sum()), int(d.sum()), int(t.sum()),\n"
+        "           int((o.view(torch.int32).flatten()[::4099].to(torch.int64) * torch.arange(1, o.numel() // 4099 + 2, device='cuda')[: (o.numel() + 4098) // 4099]).sum())])\n"
+        "    res[name] = [env.rollout_kernel_name(), digs, int(torch.isfinite(o).all())]\n"
+        "print(json.dumps(res))\n"
+    ) % ROOT
+    outs = {}
+    for fast in ("1", "0"):
+        env_vars = dict(os.environ, QR_ROLLOUT_FAST=fast)
+        env_vars.pop("QR_ROLLOUT_STASH", None)
+        r = subprocess.run([sys.executable, "-c", code], env=env_vars, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[fast] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert outs["1"]["e2e"][0] == "qr::rollout_lean_mlp_kernel<0, 1>" and outs["0"]["e2e"][0] == "qr::rollout_kernel<0, 1>"
+    assert outs["1"]["indi"][0] == "qr::rollout_lean_kernel<1, 1>" and outs["0"]["indi"][0] == "qr::rollout_kernel<1, 1>"
+    for name in ("e2e", "indi"):
+        assert outs["1"][name][1] == outs["0"][name][1], (name, outs)
