@@ -574,9 +574,14 @@ __device__ __forceinline__ void dot_chunk(const float* w, const f32x16& acc, int
     d.s23 = __builtin_elementwise_fma(w23, relu2_scaled(a23, down, ready), d.s23);
 }
 
-template <bool kALds = false>   // kALds: layer-1 weight operands from MlpRegs::a_lds (re-read every call) instead of MlpRegs::a
+// kMode: 0 = layer-1 weight operands in registers (MlpRegs::a), for kernels that are NEVER co-resident with another wave on their SIMD
+//            (at most one workgroup per CU by construction: the one-wave fused forms, the closed-loop kernel);
+//        1 = operands re-read from LDS (MlpRegs::a_lds) every call, GUARDED;  2 = operands in registers, GUARDED (the per-step kernel).
+// GUARDED = safe with two waves per SIMD, see the statement behind the matrix instructions below.
+template <int kMode = 0>
 __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const float x[10], float& thrust,
                                              float moment[3]) {
+    constexpr bool kALds = (kMode == 1), kGuard = (kMode >= 1);
     // ---- split the inputs: P0 = f16 pairs of x, P1 = f16 pairs of x - X0 (exact difference) ----
     const uint32_t p0_01 = pack_f16(x[0], x[1]), p0_23 = pack_f16(x[2], x[3]), p0_45 = pack_f16(x[4], x[5]);
     const uint32_t p0_6o = pack_f16(x[6], 1.0f);   // k-slot 7 multiplies the bias
@@ -621,6 +626,27 @@ __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const f
     // (Tried in round 4 and dropped: sched_group_barrier patterns "one MFMA, then 4 / 7 VALU instructions" to pull the MLP-independent
     // part of the step between the ten matrix instructions -- 4 176 instead of 3 997 cycles per fused step: the compiler's own
     // back-to-back issue with the VALU work behind it is the better schedule here.)
+    // ---- GUARD for kernels that can share a SIMD with another wave (two workgroups per CU and more) -------------------------------
+    // Found with tools/lean_stress.py / the full-chip-load test: in those kernels -- and only from 131 072 envs up,
+    // never at one workgroup per CU -- the last quarter of a wave's lanes (48-63) came out wrong in rare steps, in whatever value the
+    // register allocator had placed next to the matrix block: a reward, one observation element, the MLP output itself; which build
+    // failed, and how often (16 values per 4e7 ... 2e6 per 1e9), moved with unrelated code changes.  Two things together make every
+    // build pass (0 mismatches in > 60 full-load rollouts over all variants that failed before):
+    //   (1) nothing reads an accumulator until all ten matrix instructions have been issued and 32 wait states have passed (the
+    //       compiler otherwise interleaves the first ReLUs with the last matrix instructions at exactly the architectural minimum
+    //       distance behind each accumulator's writer);
+    //   (2) nothing WRITES a register that a matrix instruction of the block reads (A, B operands) before that point either (the
+    //       compiler otherwise recycles them one instruction after the matrix instruction -- legal by the published hazard tables).
+    // (1) alone fixed the lean builds and broke the general kernel, whose allocation then put a constant into the last matrix
+    // instruction's B registers one instruction behind it; (1) + (2) fixed that too.  The reading that fits all of it: with a second
+    // wave's matrix instructions in the SIMD's pipe, a matrix instruction fetches its operands (last lane quarter last) and delivers
+    // its result later than the static wait-state model assumes.  Cost: 36 registers live 32 wait states longer -- spills in the
+    // register-starved forms (lean - 13 %, general kernel - 22 % at 1 Mi envs), which is why the forms that own their SIMD
+    // (kMode 0) do not carry it.
+    if constexpr (kGuard) {
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(hT0), "+v"(hM0), "+v"(hT1), "+v"(hM1));
+        asm volatile("" :: "v"(o1[0]), "v"(o1[1]), "v"(o2[0]), "v"(o2[1]), "v"(aq0), "v"(aq1), "v"(aq2), "v"(aq3), "v"(aq4));
+    }
     DotAcc dT0, dT1, dM0[3], dM1[3];
     const uint32_t rT0 = acc_ready(hT0);
 #pragma unroll
@@ -831,7 +857,7 @@ __device__ __forceinline__ void observe(const Params& P, const float* __restrict
 // for the terminal observation SB3 bootstraps time-limit truncations from (R:589-594).
 // `do_reset(need)` performs the auto-reset of the lanes with `need` (all lanes call it); the default is reset_done_lanes().
 // the arithmetic of one step from the pre-step state: new state `nw`, reward, flags, the target after the step
-template <int V, bool kALds = false>
+template <int V, int kMode = 0>
 __device__ __forceinline__ float step_dynamics(const Params& P, const GateRow& gate, const MlpRegs& mlp, bool use_mlp, int lane,
                                                const Env<V>& e, const float u[4], float* nw, int& new_target, bool& done,
                                                bool& trunc) {
@@ -849,7 +875,7 @@ __device__ __forceinline__ float step_dynamics(const Params& P, const GateRow& g
         if (use_mlp) {  // R:502-509: residual evaluated on the PRE-step state
             const float x[10] = {e.s[12], e.s[13], e.s[14], e.s[15], vb[0], vb[1], vb[2], e.s[9], e.s[10], e.s[11]};
             float thrust, moment[3];
-            residual_mlp<kALds>(mlp, lane, x, thrust, moment);
+            residual_mlp<kMode>(mlp, lane, x, thrust, moment);
             M[0] += moment[0]; M[1] += moment[1]; M[2] += moment[2];
             F[2] += thrust;
         }
@@ -893,7 +919,7 @@ __device__ __forceinline__ float step_dynamics(const Params& P, const GateRow& g
     return reward;
 }
 
-template <int V, bool kALds = false, class BeforeReset, class DoReset>
+template <int V, int kMode = 0, class BeforeReset, class DoReset>
 __device__ __forceinline__ float step_env(const Params& P, const float* __restrict__ gates,
                                           const float* __restrict__ rtab, float* __restrict__ tile, const MlpRegs& mlp,
                                           int lane, bool active, Env<V>& e, const float u[4], uint32_t gid_lo,
@@ -903,7 +929,7 @@ __device__ __forceinline__ float step_env(const Params& P, const float* __restri
     float nw[S];
     int new_target;
     const GateRow gate = read_gate_row(gates, e.target);
-    const float reward = step_dynamics<V, kALds>(P, gate, mlp, (V == kE2E) && (P.flags & kFlagResidual), lane, e, u, nw, new_target, done, trunc);
+    const float reward = step_dynamics<V, kMode>(P, gate, mlp, (V == kE2E) && (P.flags & kFlagResidual), lane, e, u, nw, new_target, done, trunc);
     e.target = new_target;
     e.steps = e.steps + 1;
     did_reset = false;
@@ -924,13 +950,13 @@ __device__ __forceinline__ float step_env(const Params& P, const float* __restri
     }
     return reward;
 }
-template <int V, class BeforeReset>
+template <int V, int kMode = 0, class BeforeReset>
 __device__ __forceinline__ float step_env(const Params& P, const float* __restrict__ gates,
                                           const float* __restrict__ rtab, float* __restrict__ tile, const MlpRegs& mlp,
                                           int lane, bool active, Env<V>& e, const float u[4], uint32_t gid_lo,
                                           uint32_t gid_hi, bool& done, bool& trunc, bool& did_reset,
                                           BeforeReset&& before_reset) {
-    return step_env<V, false>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc, did_reset,
+    return step_env<V, kMode>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc, did_reset,
                        static_cast<BeforeReset&&>(before_reset),
                        [&](bool need) { reset_done_lanes<V>(P, rtab, tile, lane, need, e, gid_lo, gid_hi); });
 }

@@ -216,8 +216,8 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
     const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
     bool done, trunc, did_reset;
-    const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc, did_reset,
-                                     [&](bool fin) { store_terminal_obs<V, GA>(P, gates, e, 0, i, fin && active); });
+    const float reward = step_env<V, 2>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc, did_reset,   // 2: guarded (any env count)
+                                        [&](bool fin) { store_terminal_obs<V, GA>(P, gates, e, 0, i, fin && active); });
     if (active) {
         stream_store(rew_out + i, reward);
         stream_store(done_out + i, (uint8_t)(done ? 1 : 0));
@@ -326,7 +326,7 @@ __device__ __forceinline__ void rollout_body(Params P, int K, const float4* __re
             const float4 act = act_slot[j * kBlock];
             const float u[4] = {act.x, act.y, act.z, act.w};
             bool done, trunc, did_reset;
-            const float reward = step_env<V, kALds>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc,
+            const float reward = step_env<V, kALds ? 1 : 0>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc,
                                              did_reset, [&](bool fin) {
                                                  store_terminal_obs<V, GA>(P, gates, e, (size_t)k * n, i, fin && active);
                                              }, [&](bool need) {
@@ -408,6 +408,12 @@ __device__ __forceinline__ void act_ring_load(const float4* __restrict__ src, ui
 // step's reward and done stores (2; the observation block of the step before only from step 1 on) and in each of the R - 1 steps in
 // between kFlush observation stores, reward, done and the ring load: N = 2 + (R - 1)(kFlush + 3) operations are certainly younger.
 // The first R steps and ragged waves (which may issue none of these) wait for everything.
+// NOTE -- the counted wait is a MARGIN, not an architectural guarantee: operations of different kinds do not retire strictly in issue
+// order under load.  The no-MLP lean form, whose four steps take ~3 us, read slots the ring load had not reached yet (from step ~30 of
+// a 262 144-env rollout on; tools/lean_stress.py e2e_nores) -- so that form does NOT use the ring (it has the registers for the
+// prefetch).  The MLP form's four steps take ~13 us, 4-5 x the worst load-to-landing time seen anywhere in these kernels, and the
+// full-chip-load test checks it; a poisoned-slot handshake that turns the margin into a guarantee was built and measured (reader
+// re-reads behind vmcnt(0) when it still finds the poison: correct on every form, - 10 % on this one) and is not in.
 template <int N>
 __device__ __forceinline__ void act_ring_wait(bool counted) {
     static_assert(N >= 1 && N <= 63, "vmcnt is a 6-bit counter");
@@ -422,7 +428,7 @@ __device__ __forceinline__ void act_ring_wait(bool counted) {
 #define QR_FAST_RING 0
 #endif
 #ifndef QR_LEAN_RING
-#define QR_LEAN_RING 0
+#define QR_LEAN_RING 1
 #endif
 #ifndef QR_LEAN_PREFETCH
 #define QR_LEAN_PREFETCH 1
@@ -470,7 +476,7 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     constexpr int kVec = 16 * L;                 // float4 elements of a wave's [64][L] observation block
     constexpr int kFlush = (kVec + 63) / 64;     // store instructions per block
     constexpr bool kALds = kLean && kMlp;
-    constexpr bool kRing = kLean ? (QR_LEAN_RING != 0) : (QR_FAST_RING != 0);   // actions through the LDS-DMA ring (A/B builds only)
+    constexpr bool kRing = kLean ? (kMlp && QR_LEAN_RING != 0) : (QR_FAST_RING != 0);   // actions through the LDS-DMA ring: the MLP lean form only
     constexpr bool kPrefetch = !kRing && (!kLean || (QR_LEAN_PREFETCH != 0));       // next chunk requested into registers a chunk ahead
     constexpr int kOffA = kResetTableFloats + kMaxGates * kGateStride + kBlock * L + 4 * kBlock * kActChunk;
     constexpr int kOffWho = kOffA + (kALds ? 4 * kMlpQuads * 64 : 0);   // lean: [4 waves][16] dwords, then the reset pool [4][64][NB] float4
@@ -632,7 +638,7 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
             float nw[S];
             int new_target;
             bool done, trunc;
-            const float reward = step_dynamics<V, kALds>(P, gate, mlp, kMlp, lane, e, u, nw, new_target, done, trunc);
+            const float reward = step_dynamics<V, kALds ? 1 : 0>(P, gate, mlp, kMlp, lane, e, u, nw, new_target, done, trunc);
             QR_TICK(P, 5);
             if constexpr (kRing) {              // the slot just consumed (its read has returned: the dynamics used it) gets step j + R
                 act_ring_load(act_src, ring_base + (uint32_t)j * kBlock * 16u);

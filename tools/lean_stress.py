@@ -18,7 +18,8 @@ def mk():
     if variant == "indi":
         e = Quadcopter3DGatesINDI(n, *square_track(), gates_ahead=ga, seed=5, infos_mode='none')
     else:
-        e = Quadcopter3DGates(n, *square_track(), gates_ahead=ga, seed=5, infos_mode='none'); e.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+        kw = dict(residual=None) if variant == "e2e_nores" else {}
+        e = Quadcopter3DGates(n, *square_track(), gates_ahead=ga, seed=5, infos_mode='none', **kw); e.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
     e.reset_device(); return e
 a = torch.rand((K, n, 4), device='cuda', generator=torch.Generator(device='cuda').manual_seed(2)) * 2 - 1
 A = mk(); print(A.rollout_kernel_name())
