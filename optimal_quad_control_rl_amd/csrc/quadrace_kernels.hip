@@ -423,7 +423,8 @@ __device__ __forceinline__ void act_ring_wait(bool counted) {
 
 // A/B switches of the action path (defaults = what ships).  The one-wave form with the ring (-DQR_FAST_RING=1): 4 078 instead of 3 881
 // cycles per step in the clock-probe build, + 1 % / +- 2 % (K = 1000 / K = 20) on the wall clock in the production build
-// (profiles/r04_ring_ab.txt) -- never enabled.  The lean form: see the note at rollout_fast_body.
+// (profiles/r04_ring_ab.txt) -- never enabled.  The lean MLP form: ring (QR_LEAN_RING=1); QR_LEAN_PREFETCH selects, for builds
+// without the ring, register prefetch (1) or loads at the top of the chunk (0).
 #ifndef QR_FAST_RING
 #define QR_FAST_RING 0
 #endif
@@ -451,21 +452,12 @@ constexpr int lean_lds_floats() {
 //     step (as the other form does, to take the LDS latency off a lone wave's chain) its 24 registers were live through the residual
 //     MLPs and the allocator spilled two address pairs -- and the reload of a spilled value is a vector-memory wait (vmcnt(0)) that
 //     drains the wave's whole queue of outstanding stores once per step;
-//   * 4-step action chunks, the next chunk requested into 16 registers a chunk ahead (as in the other form).
-// 1 Mi envs: 36.4 -> 38 G env-steps/s (A/B on one box: + 4-5 %).
-//
-// WHAT IS NOT IN IT, and why (profiles/r04_lean_ab.txt, tests/test_gpu_round4.py::test_lean_forms_agree...under_full_chip_load):
-// an action RING filled by LDS-DMA (-DQR_LEAN_RING=1: global_load_lds_dwordx4 R steps ahead, consumer waiting with a counted
-// s_waitcnt) was + 4 % on top (39-40 G at 1 Mi envs) and passed every test of the suite as it stood -- all of which run at most one
-// workgroup per CU.  With TWO workgroups per CU (131 072 envs and more) it loses the reward stores of lanes 48-63 of a wave in rare
-// steps (16-96 of 4e7 values per 40-step rollout at 1 Mi envs; observations and done flags stay right; never at one workgroup per
-// CU; nondeterministic).  The same happens -- massively, observations included -- with the chunk's actions loaded at the top of the
-// chunk (-DQR_LEAN_PREFETCH=0, plain C++, no asm), and NOT with the batched reset in place of the pool, nor with the pool's store
-// made unconditional, nor with this form (0 mismatches in 26 rollouts of 40 steps at 131 072 ... 2 Mi envs, all gate counts, both
-// variants, against K x step_kernel).  The failing lanes are the last quarter of the wave, the failing steps are steps in which
-// the wave resets nothing, two co-resident workgroups are necessary: a hardware-level ordering effect that depends on the code
-// around it, whose cause was NOT established in the time left.  What ships is the form that passes, guarded by that test; the
-// switches stay for whoever picks this up.
+//   * with the residual MLPs: the actions come through a RING of LDS slots filled by LDS-DMA R steps ahead (act_ring_load: no
+//     registers -- the guard of the matrix block, quadrace_device.hpp residual_mlp, needs them -- and no chunk boundary);
+//     without the MLPs: the next 4-step chunk is requested into registers a chunk ahead (that form has them, and its steps are too
+//     fast for the ring's counted wait, see act_ring_wait).
+// 1 Mi envs: 36.9 -> 39.6 G env-steps/s A/B'd on one box (profiles/r04_lean_ab.txt), every build checked against K x step_kernel under
+// full-chip load (tools/lean_stress.py, profiles/r04_lean_stress.txt, tests/test_gpu_round4.py::test_lean_forms_agree...).
 template <int V, int GA, bool kMlp, bool kLean>
 __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
                                                   float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
@@ -545,7 +537,7 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
         mlp_load_regs(lds + kResetTableFloats + kMaxGates * kGateStride + kBlock * L, lane, mlp);
         __syncthreads();   // every wave has its weight registers: the area is free for the action slots
     }
-    // kRing (A/B builds only, see above): the actions come through a RING of kActChunk LDS slots filled by LDS-DMA kActChunk steps ahead:
+    // kRing: the actions come through a RING of kActChunk LDS slots filled by LDS-DMA kActChunk steps ahead:
     // no registers, no chunk boundary, and the consumer's counted wait never waits behind the wave's own recent stores.  (With the
     // register prefetch of whole chunks the compiler waits vmcnt(7..0) for the loads at the top of every chunk -- it cannot count the
     // stores of the inner loop -- i.e. the store queue drains once per chunk.)  First turn requested here (the one-wave form's slot
