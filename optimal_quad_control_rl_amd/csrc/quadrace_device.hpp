@@ -638,9 +638,9 @@ __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const f
     //   (2) nothing WRITES a register that a matrix instruction of the block reads (A, B operands) before that point either (the
     //       compiler otherwise recycles them one instruction after the matrix instruction -- legal by the published hazard tables).
     // (1) alone fixed the lean builds and broke the general kernel, whose allocation then put a constant into the last matrix
-    // instruction's B registers one instruction behind it; (1) + (2) fixed that too.  The reading that fits all of it: with a second
-    // wave's matrix instructions in the SIMD's pipe, a matrix instruction fetches its operands (last lane quarter last) and delivers
-    // its result later than the static wait-state model assumes.  Cost: 36 registers live 32 wait states longer -- spills in the
+    // instruction's B registers one instruction behind it; (1) + (2) fixed that too.  The mechanism is NOT established (a bare block of
+    // the ten matrix instructions with B overwritten one wait state later does not fail: tools/ubench/mfma_war.hip) -- the guard rests on
+    // the build matrix of profiles/r04_lean_stress.txt and DESIGN section 4.  Cost: 36 registers live 32 wait states longer -- spills in the
     // register-starved forms (lean - 13 %, general kernel - 22 % at 1 Mi envs), which is why the forms that own their SIMD
     // (kMode 0) do not carry it.
     if constexpr (kGuard) {

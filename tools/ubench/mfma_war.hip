@@ -1,0 +1,87 @@
+// Micro-benchmark (MI355X): is it safe to overwrite a matrix instruction's B operand registers d wait states after issuing it --
+// (a) with the SIMD to itself, (b) with a second wave of the same SIMD issuing matrix instructions too?  And is an accumulator readable
+// at the compiler's minimum distance in both cases?  Ten v_mfma_f32_32x32x16_f16 on four accumulators (the residual-MLP block of
+// quadrace_device.hpp), explicit registers, one asm statement per variant; the reference result comes from the same block with a long
+// sleep in front of the overwrite / the read.
+//   hipcc --offload-arch=gfx950 -O3 -o bin/mfma_war mfma_war.hip && bin/mfma_war
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define STR2(x) #x
+#define STR(x) STR2(x)
+// A = v[4:7], B = v[8:11], garbage = v12, accumulators v[16:31] v[32:47] v[48:63] v[64:79]
+#define BLOCK                                                                  \
+    "v_mfma_f32_32x32x16_f16 v[16:31], v[4:7], v[8:11], 0\n"                   \
+    "v_mfma_f32_32x32x16_f16 v[32:47], v[4:7], v[8:11], 0\n"                   \
+    "v_mfma_f32_32x32x16_f16 v[48:63], v[4:7], v[8:11], 0\n"                   \
+    "v_mfma_f32_32x32x16_f16 v[64:79], v[4:7], v[8:11], 0\n"                   \
+    "v_mfma_f32_32x32x16_f16 v[16:31], v[4:7], v[8:11], v[16:31]\n"            \
+    "v_mfma_f32_32x32x16_f16 v[32:47], v[4:7], v[8:11], v[32:47]\n"            \
+    "v_mfma_f32_32x32x16_f16 v[48:63], v[4:7], v[8:11], v[48:63]\n"            \
+    "v_mfma_f32_32x32x16_f16 v[64:79], v[4:7], v[8:11], v[64:79]\n"            \
+    "v_mfma_f32_32x32x16_f16 v[48:63], v[4:7], v[8:11], v[48:63]\n"            \
+    "v_mfma_f32_32x32x16_f16 v[64:79], v[4:7], v[8:11], v[64:79]\n"
+#define OVERWRITE "v_mov_b32 v8, v12\nv_mov_b32 v9, v12\nv_mov_b32 v10, v12\nv_mov_b32 v11, v12\n"
+#define DRAIN "s_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\n"
+#define CLOB "v4","v5","v6","v7","v8","v9","v10","v11","v12","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31", \
+    "v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63", \
+    "v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79"
+// MODE 0: reference (sleep before the overwrite).  MODE 1..: overwrite B after PAD wait states.  MODE 100+: read v64 (last accumulator) after PAD wait states.
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) k(unsigned* bad, unsigned* badq, int iters, float* sink) {
+    extern __shared__ float lds[];   // sized by the host so that exactly one / two workgroups fit a CU
+    const int lane = threadIdx.x & 63;
+    unsigned mism = 0, q[4] = {0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+        const unsigned a0 = 0x3c003c00u, b0 = 0x38003800u + ((unsigned)(lane * 7 + it) & 0x3ff);   // f16 pairs: A = 1.0, B = 0.5 + small
+        float r[2][4];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {   // pass 0: reference, pass 1: the variant
+            float o0, o1, o2, o3;
+            if (pass == 0 || MODE == 0) {
+                asm volatile("v_mov_b32 v4, %4\nv_mov_b32 v5, %4\nv_mov_b32 v6, %4\nv_mov_b32 v7, %4\nv_mov_b32 v8, %5\nv_mov_b32 v9, %5\nv_mov_b32 v10, %5\nv_mov_b32 v11, %5\nv_mov_b32 v12, 0x7fc00000\ns_nop 4\n"
+                             BLOCK "s_sleep 16\n" OVERWRITE DRAIN
+                             "v_mov_b32 %0, v16\nv_mov_b32 %1, v47\nv_mov_b32 %2, v50\nv_mov_b32 %3, v79\n"
+                             : "=v"(o0), "=v"(o1), "=v"(o2), "=v"(o3) : "v"(a0), "v"(b0) : CLOB);
+            } else if (MODE < 100) {
+                asm volatile("v_mov_b32 v4, %4\nv_mov_b32 v5, %4\nv_mov_b32 v6, %4\nv_mov_b32 v7, %4\nv_mov_b32 v8, %5\nv_mov_b32 v9, %5\nv_mov_b32 v10, %5\nv_mov_b32 v11, %5\nv_mov_b32 v12, 0x7fc00000\ns_nop 4\n"
+                             BLOCK "s_nop " STR(PADV) "\n" OVERWRITE DRAIN
+                             "v_mov_b32 %0, v16\nv_mov_b32 %1, v47\nv_mov_b32 %2, v50\nv_mov_b32 %3, v79\n"
+                             : "=v"(o0), "=v"(o1), "=v"(o2), "=v"(o3) : "v"(a0), "v"(b0) : CLOB);
+            } else {
+                asm volatile("v_mov_b32 v4, %4\nv_mov_b32 v5, %4\nv_mov_b32 v6, %4\nv_mov_b32 v7, %4\nv_mov_b32 v8, %5\nv_mov_b32 v9, %5\nv_mov_b32 v10, %5\nv_mov_b32 v11, %5\nv_mov_b32 v12, 0x7fc00000\ns_nop 4\n"
+                             BLOCK "s_nop " STR(PADV) "\n"
+                             "v_mov_b32 %3, v79\nv_mov_b32 %2, v50\n" DRAIN "v_mov_b32 %0, v16\nv_mov_b32 %1, v47\n"
+                             : "=v"(o0), "=v"(o1), "=v"(o2), "=v"(o3) : "v"(a0), "v"(b0) : CLOB);
+            }
+            r[pass][0] = o0; r[pass][1] = o1; r[pass][2] = o2; r[pass][3] = o3;
+        }
+        bool ne = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ne |= (__float_as_uint(r[0][j]) != __float_as_uint(r[1][j]));
+        if (ne) { ++mism; ++q[lane >> 4]; }
+    }
+    if (mism) { atomicAdd(bad, mism); for (int j = 0; j < 4; ++j) if (q[j]) atomicAdd(badq + j, q[j]); }
+    if (lds[threadIdx.x] == 12345.0f) sink[0] = 1.0f;
+}
+int main() {
+    unsigned *bad, *badq; float* sink;
+    hipMalloc(&bad, 4); hipMalloc(&badq, 16); hipMalloc(&sink, 4);
+    const int iters = 2000;
+    for (int two = 0; two < 2; ++two) {
+        const size_t lds = two ? 70 * 1024 : 120 * 1024;   // one (120 KB) or two (70 KB) workgroups per CU
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipMemset(bad, 0, 4); hipMemset(badq, 0, 16);
+        hipLaunchKernelGGL(k<1>, dim3(two ? 512 : 256), dim3(256), lds, 0, bad, badq, iters, sink);
+        hipDeviceSynchronize();
+        unsigned h, hq[4]; hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost); hipMemcpy(hq, badq, 16, hipMemcpyDeviceToHost);
+        printf("variant %s, s_nop %d behind the block, %s per CU: %u mismatching lane-results of %u  (by lane quarter: %u %u %u %u)\n",
+#ifdef READ_TEST
+               "READ of the last accumulator",
+#else
+               "OVERWRITE of the B operand",
+#endif
+               PADV, two ? "two workgroups" : "one workgroup", h, (two ? 512u : 256u) * 256u * iters, hq[0], hq[1], hq[2], hq[3]);
+    }
+    return 0;
+}
