@@ -139,10 +139,11 @@ def test_rollout_kernel_selection_is_reported_and_every_kernel_agrees(residual_b
 
 @pytest.mark.gpu
 def test_lean_forms_agree_with_the_general_kernels_under_full_chip_load():
-    """Every test above runs at most one workgroup per CU.  The lean fused forms exist for MORE, and an earlier version of them
-    (actions through an LDS-DMA ring, or loaded at the top of each chunk) lost the reward stores of lanes 48-63 of a wave in rare steps
-    -- only with two workgroups per CU, nondeterministically, passing everything else (csrc/quadrace_kernels.hip, note at
-    rollout_fast_body; tools/lean_stress.py).  So: 1 Mi envs E2E (16 waves per SIMD queued, the memory system saturated by the stores)
+    """Every test above runs at most one workgroup per CU.  The lean fused forms exist for MORE, and this test -- written for that gap --
+    found unguarded builds of the MLP kernels returning wrong values in a wave's last lane quarter (lanes 48-63: a reward, an observation
+    element, the MLP output) in rare steps, only with two workgroups per CU, nondeterministically, while passing everything else
+    (DESIGN section 4 "A hazard with two waves per SIMD"; the guard is in csrc/quadrace_device.hpp residual_mlp; tools/lean_stress.py is
+    the elementwise version of this check).  So: 1 Mi envs E2E (16 waves per SIMD queued, the memory system saturated by the stores)
     and 262 144 envs INDI, three 40-step rollouts each: digests of every output and a strided sample must equal those of the general
     kernels (QR_ROLLOUT_FAST=0, another process)."""
     code = (
