@@ -645,7 +645,15 @@ __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const f
     // (kMode 0) do not carry it.
     if constexpr (kGuard) {
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(hT0), "+v"(hM0), "+v"(hT1), "+v"(hM1));
-        asm volatile("" :: "v"(o1[0]), "v"(o1[1]), "v"(o2[0]), "v"(o2[1]), "v"(aq0), "v"(aq1), "v"(aq2), "v"(aq3), "v"(aq4));
+#ifndef QR_GUARD_KEEP
+#define QR_GUARD_KEEP 3   /* experiments: 1 = B operands only, 2 = A operands only */
+#endif
+#if QR_GUARD_KEEP & 1
+        asm volatile("" :: "v"(o1[0]), "v"(o1[1]), "v"(o2[0]), "v"(o2[1]));
+#endif
+#if QR_GUARD_KEEP & 2
+        asm volatile("" :: "v"(aq0), "v"(aq1), "v"(aq2), "v"(aq3), "v"(aq4));
+#endif
     }
     DotAcc dT0, dT1, dM0[3], dM1[3];
     const uint32_t rT0 = acc_ready(hT0);

@@ -21,7 +21,11 @@
     "v_mfma_f32_32x32x16_f16 v[64:79], v[4:7], v[8:11], v[64:79]\n"            \
     "v_mfma_f32_32x32x16_f16 v[48:63], v[4:7], v[8:11], v[48:63]\n"            \
     "v_mfma_f32_32x32x16_f16 v[64:79], v[4:7], v[8:11], v[64:79]\n"
+#ifdef OVERWRITE_A
+#define OVERWRITE "v_mov_b32 v4, v12\nv_mov_b32 v5, v12\nv_mov_b32 v6, v12\nv_mov_b32 v7, v12\n"
+#else
 #define OVERWRITE "v_mov_b32 v8, v12\nv_mov_b32 v9, v12\nv_mov_b32 v10, v12\nv_mov_b32 v11, v12\n"
+#endif
 #define DRAIN "s_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\n"
 #define CLOB "v4","v5","v6","v7","v8","v9","v10","v11","v12","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31", \
     "v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63", \
@@ -79,7 +83,11 @@ int main() {
 #ifdef READ_TEST
                "READ of the last accumulator",
 #else
+#ifdef OVERWRITE_A
+               "OVERWRITE of the A operand",
+#else
                "OVERWRITE of the B operand",
+#endif
 #endif
                PADV, two ? "two workgroups" : "one workgroup", h, (two ? 512u : 256u) * 256u * iters, hq[0], hq[1], hq[2], hq[3]);
     }
