@@ -1,0 +1,156 @@
+"""Build-time ISA lint for libquadrace.so: no kernel of the library may contain an instruction form that MI355X executes wrongly.
+
+The one rule so far (root cause of the "two waves per SIMD" corruption of rounds 4-5, reproducer tools/ubench/mfma_pk_hazard.hip):
+
+    A packed-f32 VALU instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) whose SECOND source takes its HIGH dword for the LOW
+    half of the result (op_sel bit 1 set) loses that low-half result in lanes 48-63 when another wave of the same SIMD -- of this
+    kernel, of another kernel of this process, or of another process -- issues an f16 / bf16 matrix (XDL MFMA) instruction at the
+    wrong moment.  The other operand positions, the high-half selectors (op_sel_hi) and v_pk_mov_b32 are not affected.
+
+hipcc (SLP vectoriser + instruction selection) produces the form freely; `build.py` therefore compiles through assembly and rewrites
+every occurrence into an equivalent safe form (`fix_asm_text`), and this module re-checks the FINAL code objects by disassembly, so a
+library that loads is a library without the form -- whatever the compiler did.
+
+    python -m optimal_quad_control_rl_amd.isa_lint [library.so ...]      exit status 1 and a listing if anything is found
+"""
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+_PK = r"v_pk_(?:fma|mul|add)_f32"
+# op_sel:[a,b] or op_sel:[a,b,c] -- position 1 is the second source
+_OPSEL = re.compile(r"\bop_sel:\[([01]),([01])(?:,([01]))?\]")
+_OPSEL_HI = re.compile(r"\bop_sel_hi:\[([01]),([01])(?:,([01]))?\]")
+_INSTR = re.compile(r"^\s*(" + _PK + r")\s+(.*)$")
+
+
+def is_hazardous(line):
+    """True for a packed-f32 arithmetic instruction whose src1 feeds its HIGH dword to the low result half."""
+    m = _INSTR.match(line.split("//")[0].split(";")[0])
+    if not m:
+        return False
+    sel = _OPSEL.search(m.group(2))
+    return bool(sel and sel.group(2) == "1")
+
+
+def _split_operands(rest):
+    """'v[4:5], v[6:7], s[0:1], v[4:5] op_sel:[0,1,0] neg_lo:[...]' -> (['v[4:5]', ...], ' op_sel:[0,1,0] neg_lo:[...]')"""
+    ops, depth, cur, i = [], 0, "", 0
+    while i < len(rest):
+        c = rest[i]
+        if c == "[":
+            depth += 1
+        elif c == "]":
+            depth -= 1
+        if c == "," and depth == 0:
+            ops.append(cur.strip()); cur = ""
+        elif c == " " and depth == 0 and cur.strip() and re.match(r"\s*(op_sel|op_sel_hi|neg_lo|neg_hi|clamp)\b", rest[i:]):
+            ops.append(cur.strip())
+            return ops, rest[i:]
+        else:
+            cur += c
+        i += 1
+    ops.append(cur.strip())
+    return ops, ""
+
+
+def _swap01(mods, rx, nsrc, default):
+    m = rx.search(mods)
+    bits = [m.group(1), m.group(2)] + ([m.group(3)] if m and m.group(3) is not None else []) if m else [default] * nsrc
+    bits[0], bits[1] = bits[1], bits[0]
+    return m, bits
+
+
+def fix_asm_line(line):
+    """Rewrite a hazardous instruction into an equivalent safe one by exchanging its two commutative sources (a*b = b*a, a+b = b+a)
+    together with their op_sel / op_sel_hi / neg bits: the high-dword selection moves to source 0, where the hardware handles it.
+    Returns the line unchanged if it is not hazardous; raises if the exchange is not possible (both sources select the high dword:
+    has not occurred -- such a line must be fixed in the source)."""
+    if not is_hazardous(line):
+        return line
+    body, sep, comment = line.partition(";")
+    m = _INSTR.match(body)
+    indent = body[: len(body) - len(body.lstrip())]
+    ops, mods = _split_operands(m.group(2).rstrip())
+    nsrc = len(ops) - 1
+    sel = _OPSEL.search(mods)
+    if sel.group(1) == "1":
+        raise ValueError("both commutative sources select the high dword, cannot be fixed by an exchange: " + line.strip())
+    ops[1], ops[2] = ops[2], ops[1]
+    out_mods = mods
+    for name, rx, default in (("op_sel", _OPSEL, "0"), ("op_sel_hi", _OPSEL_HI, "1"), ("neg_lo", re.compile(r"\bneg_lo:\[([01]),([01])(?:,([01]))?\]"), "0"),
+                              ("neg_hi", re.compile(r"\bneg_hi:\[([01]),([01])(?:,([01]))?\]"), "0")):
+        mm, bits = _swap01(out_mods, rx, nsrc, default)
+        if mm:
+            out_mods = out_mods[: mm.start()] + "%s:[%s]" % (name, ",".join(bits)) + out_mods[mm.end():]
+    fixed = "%s%s %s%s" % (indent, m.group(1), ", ".join(ops), out_mods)
+    assert not is_hazardous(fixed), fixed
+    return fixed + (" " + sep + comment if sep else "") + ("" if comment.endswith("\n") or not line.endswith("\n") else "\n")
+
+
+def fix_asm_text(text):
+    """Apply fix_asm_line to every line of a device assembly file; returns (new text, number of rewritten instructions)."""
+    out, n = [], 0
+    for ln in text.split("\n"):
+        new = fix_asm_line(ln)
+        n += new != ln
+        out.append(new)
+    return "\n".join(out), n
+
+
+def _code_objects(path):
+    """Every AMDGPU ELF embedded in a host object / shared library (the .hip_fatbin bundles), or the file itself if it is one."""
+    data = open(path, "rb").read()
+    found, pos = [], 0
+    while True:
+        i = data.find(b"\x7fELF", pos)
+        if i < 0:
+            break
+        pos = i + 4
+        if len(data) < i + 64 or data[i + 4] != 2:   # ELF64 only
+            continue
+        e_machine = struct.unpack_from("<H", data, i + 18)[0]
+        if e_machine != 224:   # EM_AMDGPU
+            continue
+        e_shoff, = struct.unpack_from("<Q", data, i + 40)
+        e_shentsize, e_shnum = struct.unpack_from("<HH", data, i + 58)
+        found.append(data[i: i + e_shoff + e_shentsize * e_shnum])
+    return found
+
+
+def lint_library(path):
+    """[(kernel symbol, instruction text)] for every hazardous instruction in the device code of `path`."""
+    bad = []
+    objdump = os.path.join(LLVM_BIN, "llvm-objdump")
+    for blob in _code_objects(path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(blob); f.flush()
+            txt = subprocess.run([objdump, "-d", "--mcpu=gfx950", f.name], check=True, capture_output=True, text=True).stdout
+        sym = "?"
+        for ln in txt.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(.*)>:", ln)
+            if m:
+                sym = m.group(1)
+            elif is_hazardous(ln):
+                bad.append((sym, ln.split("//")[0].strip()))
+    return bad
+
+
+def main(argv):
+    libs = argv or [os.path.join(os.path.dirname(os.path.abspath(__file__)), "libquadrace.so")]
+    rc = 0
+    for lib in libs:
+        bad = lint_library(lib)
+        print("%s: %d hazardous packed-f32 instruction(s)" % (lib, len(bad)))
+        for sym, ins in bad[:40]:
+            print("   %s: %s" % (sym, ins))
+        rc |= bool(bad)
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

@@ -1,0 +1,53 @@
+"""The build's ISA rule (optimal_quad_control_rl_amd/isa_lint.py): no packed-f32 instruction whose second source feeds its high dword
+to the low result half -- the form MI355X computes wrongly in lanes 48-63 next to another wave's matrix instructions (root cause of the
+round-4 "two waves per SIMD" corruption; reproducer tools/ubench/mfma_pk_hazard.hip, evidence profiles/r05_root_cause.txt)."""
+import os
+
+import pytest
+
+from optimal_quad_control_rl_amd import build, isa_lint
+
+BAD = [
+    "\tv_pk_fma_f32 v[4:5], v[6:7], v[140:141], v[4:5] op_sel:[0,1,0] op_sel_hi:[1,0,1]",
+    "\tv_pk_fma_f32 v[4:5], v[6:7], s[0:1], v[4:5] op_sel:[0,1,0]",
+    "\tv_pk_mul_f32 v[38:39], v[20:21], v[4:5] op_sel:[0,1] neg_lo:[0,1]",
+    "\tv_pk_add_f32 v[28:29], v[2:3], v[178:179] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]",
+    "\tv_pk_add_f32 v[16:17], v[16:17], v[16:17] op_sel:[0,1] op_sel_hi:[1,0] ; a comment",
+]
+GOOD = [
+    "\tv_pk_fma_f32 v[4:5], v[6:7], v[140:141], v[4:5]",
+    "\tv_pk_fma_f32 v[4:5], v[6:7], v[140:141], v[4:5] op_sel:[1,0,0] op_sel_hi:[0,1,1]",
+    "\tv_pk_fma_f32 v[4:5], v[6:7], v[140:141], v[4:5] op_sel:[0,0,1] op_sel_hi:[1,1,0]",
+    "\tv_pk_fma_f32 v[12:13], v[8:9], s[36:37], v[10:11] op_sel_hi:[1,0,0]",
+    "\tv_pk_mul_f32 v[6:7], v[138:139], s[0:1] op_sel:[1,0]",
+    "\tv_pk_mov_b32 v[6:7], v[64:65], v[58:59] op_sel:[0,1]",
+    "\tv_fma_f32 v34, v112, v214, 0",
+    "\tv_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[198:201], 0",
+]
+
+
+def test_rule_recognises_exactly_the_hazardous_form():
+    assert all(isa_lint.is_hazardous(l) for l in BAD)
+    assert not any(isa_lint.is_hazardous(l) for l in GOOD)
+
+
+def test_rewrite_exchanges_the_commutative_sources_with_their_modifiers():
+    f = isa_lint.fix_asm_line
+    assert f(BAD[0]) == "\tv_pk_fma_f32 v[4:5], v[140:141], v[6:7], v[4:5] op_sel:[1,0,0] op_sel_hi:[0,1,1]"
+    assert f(BAD[1]) == "\tv_pk_fma_f32 v[4:5], s[0:1], v[6:7], v[4:5] op_sel:[1,0,0]"
+    assert f(BAD[2]) == "\tv_pk_mul_f32 v[38:39], v[4:5], v[20:21] op_sel:[1,0] neg_lo:[1,0]"
+    assert f(BAD[3]) == "\tv_pk_add_f32 v[28:29], v[178:179], v[2:3] op_sel:[1,0] neg_lo:[1,0] neg_hi:[1,0]"
+    assert f(BAD[4]).startswith("\tv_pk_add_f32 v[16:17], v[16:17], v[16:17] op_sel:[1,0] op_sel_hi:[0,1]") and "a comment" in f(BAD[4])
+    for l in GOOD:
+        assert f(l) == l
+    text, n = isa_lint.fix_asm_text("\n".join(BAD + GOOD))
+    assert n == len(BAD) and not any(isa_lint.is_hazardous(l) for l in text.split("\n"))
+    with pytest.raises(ValueError):
+        f("\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,1]")
+
+
+def test_the_built_library_contains_no_hazardous_instruction():
+    """Disassembles every code object of libquadrace.so (what the GPU will run, not what the compiler was asked for)."""
+    lib = build.build_native_locked()
+    assert os.path.exists(lib)
+    assert isa_lint.lint_library(lib) == []

@@ -39,3 +39,18 @@ for name, x, y in (("obs", o, O), ("rew", r, R), ("done", d, D)):
         for ii in idx[:5]:
             print("   ", ii, x[tuple(ii)].item(), y[tuple(ii)].item())
         steps = neq.reshape(K, -1).any(1).nonzero().flatten().tolist(); print("  steps with mismatches:", steps[:40])
+        envs = neq.reshape(K, n, -1).any(2).nonzero()[:, 1]   # which lane quarter of its wave does a mismatching env sit in?
+        print("  mismatching (step, env) pairs by lane quarter:", torch.bincount((envs % 64) // 16, minlength=4).tolist())
+        if x.dim() == 3:
+            print("  by observation column:", neq.reshape(-1, x.shape[-1]).sum(0).tolist())
+            anyk = neq.any(2)                                           # [K, n]
+            bad_env = anyk.any(0).nonzero().flatten()
+            first = anyk[:, bad_env].int().argmax(0)                   # first mismatching step of each bad env
+            cols = neq[first, bad_env]                                  # [bad envs, L] mismatching columns at that step
+            print("  envs that ever mismatch:", bad_env.numel(), " columns mismatching at an env's FIRST bad step:", cols.sum(0).tolist())
+            pat, cnt = torch.unique(cols, dim=0, return_counts=True)
+            for pp, cc in sorted(zip(pat.tolist(), cnt.tolist()), key=lambda t: -t[1])[:6]:
+                print("    pattern", [i for i, v in enumerate(pp) if v], "x", cc)
+            for j in range(min(3, bad_env.numel())):
+                e, k0 = int(bad_env[j]), int(first[j]); c = cols[j].nonzero().flatten().tolist()
+                print("    env", e, "lane", e % 64, "step", k0, "cols", c, "got", [x[k0, e, ci].item() for ci in c], "want", [y[k0, e, ci].item() for ci in c])

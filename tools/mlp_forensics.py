@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Forensics on a failing build (tools/isa_patch.py, tools/lean_stress.py): for every env whose fused-rollout trajectory first leaves the
+per-step kernel's, reconstruct in float64 what the residual moment MLP should have produced from the reference state and ask which
+perturbation of the computation explains the observed error of q (= dt * 805.15 * dMy, the only component that is wrong first).
+    QR_PROBE_LIB=<build> QR_ROLLOUT_STASH=0 python tools/mlp_forensics.py [envs]"""
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from optimal_quad_control_rl_amd import build as B
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.environ.get("QR_PROBE_LIB"):
+    B.LIB = os.path.join(ROOT, os.environ["QR_PROBE_LIB"]); B.needs_build = lambda: False
+from optimal_quad_control_rl_amd import Quadcopter3DGates, TRAIN_DISTURBANCE_RANGES, square_track
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 18
+K = 40
+def mk():
+    e = Quadcopter3DGates(n, *square_track(), gates_ahead=1, seed=5, infos_mode='none'); e.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+    e.reset_device(); return e
+a = torch.rand((K, n, 4), device='cuda', generator=torch.Generator(device='cuda').manual_seed(2)) * 2 - 1
+A = mk(); print(A.rollout_kernel_name())
+o, r, d, t = A.rollout_device(a)
+Bv = mk()
+O = torch.empty_like(o); W = torch.empty((K, n, 16), device='cuda'); R7 = torch.empty((K, n, 7), device='cuda'); Dd = torch.empty((K, n, 6), device='cuda')
+for k in range(K):
+    st = Bv.get_state_tensors(); W[k] = st[0]; Dd[k] = st[1]; R7[k] = Bv.probe_residual()
+    O[k] = Bv.step_device(a[k])[0]
+neq = o.view(torch.int32) != O.view(torch.int32)
+anyk = neq.any(2); bad = anyk.any(0).nonzero().flatten(); first = anyk[:, bad].int().argmax(0)
+print("envs that ever mismatch:", bad.numel(), " lane quarters:", torch.bincount((bad % 64) // 16, minlength=4).tolist())
+ev = sorted(set(zip((bad // 64).tolist(), first.tolist())))
+print("wave events (wave, step):", len(ev), ev[:12])
+blob = np.fromfile(os.path.join(ROOT, "optimal_quad_control_rl_amd", "data", "residual_mlp_f32.bin"), dtype=np.float32).astype(np.float64)
+mW1 = blob[289:289 + 320].reshape(32, 10); mb1 = blob[609:641]; mW2 = blob[641:737].reshape(3, 32); mb2 = blob[737:740]
+f16 = lambda x: np.float16(x).astype(np.float64)
+for j in range(min(12, bad.numel())):
+    e, k0 = int(bad[j]), int(first[j])
+    ws = W[k0, e].double().cpu().numpy(); vb = R7[k0, e, 0:3].double().cpu().numpy(); mom = R7[k0, e, 4:7].double().cpu().numpy()
+    x = np.concatenate([ws[12:16], vb, ws[9:12]])
+    h = mW1 @ x + mb1; c = mW2 * np.maximum(h, 0)[None, :]          # [3, 32] contributions
+    M = c.sum(1) + mb2
+    dq = float(o[k0, e, 10] - O[k0, e, 10]); dMy = dq / (0.01 * 805.152979066023)
+    dp = float(o[k0, e, 9] - O[k0, e, 9]); dr = float(o[k0, e, 11] - O[k0, e, 11])
+    print("env %d lane %d step %d: dq %.3e => dMy %.4e  (dp %.1e dr %.1e)  My f64 %.5e probe %.5e" % (e, e % 64, k0, dq, dMy, dp, dr, M[1], mom[1]))
+    print("   My contributions by hidden row:", " ".join("%.2e" % v for v in c[1]))
+    lane_hi = [jj for jj in range(32) if (jj >> 2) & 1]; lane_lo = [jj for jj in range(32) if not (jj >> 2) & 1]
+    cands = {"-sum(rows of lanes 32-63)": -c[1][lane_hi].sum(), "-sum(rows of lanes 0-31)": -c[1][lane_lo].sum(), "-b2": -mb2[1]}
+    for jj in range(32):
+        cands["-row %d" % jj] = -c[1][jj]
+    # layer-1 pieces: dropping the X0*W1, X1*W0 terms of (p, q, r) or of all inputs
+    x0 = f16(x); x1 = f16(x - x0); W0 = f16(mW1); W1p = f16(mW1 - W0)
+    for name, dh in (("drop X0*W1 of pqr", -(W1p[:, 7:] @ x0[7:])), ("drop X1*W0 of pqr", -(W0[:, 7:] @ x1[7:])), ("drop all pqr terms", -(mW1[:, 7:] @ x[7:])),
+                     ("drop X0*W1 all", -(W1p @ x0)), ("drop X1*W0 all", -(W0 @ x1)), ("drop quad 4 (pqr) rows>=16 only", None)):
+        if dh is None:
+            dh = -(mW1[:, 7:] @ x[7:]); dh[:16] = 0
+        cands[name] = (mW2[1] * np.maximum(h + dh, 0)).sum() - c[1].sum()
+    # stale / misplaced partial sums: My = Plo + Phi + b2 with Plo = rows held by lanes 0-31 (bit 2 of the row clear), Phi = rows of lanes 32-63
+    def parts(k, env):
+        wsx = W[k, env].double().cpu().numpy(); vbx = R7[k, env, 0:3].double().cpu().numpy()
+        xx = np.concatenate([wsx[12:16], vbx, wsx[9:12]]); cc = mW2[1] * np.maximum(mW1 @ xx + mb1, 0)
+        return cc[lane_lo].sum(), cc[lane_hi].sum()
+    plo, phi = parts(k0, e)
+    got_hi = dMy + phi; got_lo = dMy + plo     # what Phi (resp. Plo) must have been if the OTHER half was right
+    base = (e // 64) * 64
+    for kk in (k0, k0 - 1):
+        if kk < 0: continue
+        for e2 in range(base, base + 64):
+            l2, h2 = parts(kk, e2)
+            for nm, v, tgt in (("Phi", h2, got_hi), ("Plo", l2, got_hi), ("Phi", h2, got_lo), ("Plo", l2, got_lo)):
+                if (kk, e2) != (k0, e) and abs(v - tgt) < 2e-7 + 1e-5 * abs(tgt):
+                    print("   MATCH: the %s half behaves as %s of env %d (lane %d) at step %d: %.6e vs %.6e" % ("hi" if tgt is got_hi else "lo", nm, e2, e2 % 64, kk, tgt, v))
+    dist = Dd[k0, e].double().cpu().numpy()
+    print("   dMy %.5e | Plo %.5e Phi %.5e b2 %.5e distMy %.5e distMx %.5e distMz %.5e | Mx %.5e Mz %.5e | q %.4f p %.4f r %.4f" % (dMy, plo, phi, mb2[1], dist[1], dist[0], dist[2], M[0], M[2], ws[10], ws[9], ws[11]))
+    print("   dq / (-0.01*0.924315619967794*p*r) = %.5f" % (dq / (-0.01 * 0.924315619967794 * ws[9] * ws[11])))
+    best = sorted(cands.items(), key=lambda kv: abs(kv[1] - dMy))[:4]
+    print("   closest explanations:", ", ".join("%s: %.4e" % kv for kv in best))

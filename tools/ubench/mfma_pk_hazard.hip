@@ -1,0 +1,208 @@
+// Reproducer (MI355X, gfx950): a packed-f32 VALU instruction whose op_sel / op_sel_hi take a source's halves CROSSED or BROADCAST
+// loses the LOW half of its result in lanes 48-63 when another wave of the same SIMD issues an f16 matrix instruction at the wrong
+// moment.  This is the root cause of the "two waves per SIMD" corruption of DESIGN section 4 (rounds 4-5): in the failing build the SLP
+// vectoriser had packed q_dot / r_dot of the equations of motion into `v_pk_fma_f32 ... op_sel:[0,1,0] op_sel_hi:[1,0,1]`, and in rare
+// steps q_dot came out without its 0.924 p r term in the last lane quarter (tools/isa_patch.py + tools/mlp_forensics.py found it).
+//
+// 512-thread workgroups: waves 0-3 (one per SIMD) are VICTIMS running chains of ONE packed instruction form; waves 4-7 (the second wave
+// of each SIMD) are AGGRESSORS.  Victim results are compared bit for bit with a launch whose aggressors sleep.
+//   hipcc --offload-arch=gfx950 -O3 -o bin/mfma_pk_hazard mfma_pk_hazard.hip && bin/mfma_pk_hazard
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define VICTIMS(X)                                                                                         \
+    X(0, "v_pk_fma_f32 %0, %1, %2, %0", "pk_fma plain")                                                    \
+    X(1, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]", "pk_fma src1 crossed")            \
+    X(2, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]", "pk_fma src0 crossed")            \
+    X(3, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,1] op_sel_hi:[1,1,0]", "pk_fma src2 crossed")            \
+    X(4, "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]", "pk_fma src1 lo,lo")                             \
+    X(5, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]", "pk_fma src1 hi,hi")                                \
+    X(6, "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]", "pk_fma src2 lo,lo")                             \
+    X(7, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,1]", "pk_fma src2 hi,hi")                                \
+    X(8, "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]", "pk_fma src0 lo,lo")                             \
+    X(9, "v_pk_mul_f32 %0, %1, %0 op_sel:[1,0] op_sel_hi:[0,1]", "pk_mul src0 crossed")                    \
+    X(10, "v_pk_add_f32 %0, %1, %0 op_sel:[1,0] op_sel_hi:[0,1]", "pk_add src0 crossed")                   \
+    X(11, "v_pk_mul_f32 %0, %1, %0 op_sel_hi:[0,1]", "pk_mul src0 lo,lo")                                  \
+    X(12, "v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]", "pk_mov (src0.hi, src1.lo)")                             \
+    X(13, "v_pk_fma_f32 %0, %1, %2, %0 neg_lo:[0,1,0] neg_hi:[0,1,0]", "pk_fma plain + neg")               \
+    X(14, "v_fma_f32 %0, %1, %2, %0", "scalar v_fma_f32 on the pair's low register (control)")      \
+    X(15, "v_pk_mul_f32 %0, %0, %1 op_sel:[0,1]", "pk_mul src1 hi,hi")                                     \
+    X(16, "v_pk_add_f32 %0, %0, %1 op_sel:[0,1]", "pk_add src1 hi,hi")                                     \
+    X(17, "v_pk_mul_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]", "pk_mul src1 crossed")                   \
+    X(18, "v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]", "pk_add src1 crossed")                   \
+    X(19, "v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]", "pk_fma src1 crossed, sources EXCHANGED (the fix)") \
+    X(20, "v_pk_mov_b32 %0, %0, %1 op_sel:[0,1]", "pk_mov (src0.lo, src1.hi)")
+
+template <int V>
+__device__ __forceinline__ void victim_op(f32x2& a, const f32x2& x, const f32x2& m) {
+#define X(ID, TXT, NAME) if constexpr (V == ID) { if constexpr (ID == 14) asm volatile(TXT : "+v"(a.x) : "v"(x.x), "v"(m.x)); else asm volatile(TXT : "+v"(a) : "v"(x), "v"(m)); }
+    VICTIMS(X)
+#undef X
+}
+
+// AGGR: 0 sleep; 1 f16 32x32x16 + s_nop GAP; 2 f16 16x16x32 + gap; 3 bf16 32x32x16 + gap; 4 f32 32x32x2 + gap; 5 f16 back to back; 6 f8 32x32x16? (skipped)
+template <int V, int AGGR, int GAP, int SELF>
+__global__ void __launch_bounds__(512) k(float* out, float* sink, int iters) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x16 acc[4] = {};
+    f32x4 acc4[4] = {};
+    f16x8 av, bv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { av[j] = (_Float16)(0.001f * (lane + j)); bv[j] = (_Float16)(0.5f - 0.001f * j); }
+    if (wave < 4) {
+        const int gid = (blockIdx.x * 4 + wave) * 64 + lane;
+        const float seed = 1.0f + 1e-3f * (float)(gid % 977);
+        f32x2 a[8], x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] = f32x2{seed + 0.01f * j, seed - 0.02f * j}; x[j] = f32x2{0.5f + 0.001f * j, 0.25f - 0.001f * j}; }
+        const f32x2 m = {1.0000001f, 0.9999999f};
+        for (int it = 0; it < iters; ++it) {
+            if constexpr (SELF > 0) {   // the victim wave issues the matrix instruction ITSELF, SELF - 1 wait states ahead of the packed chain
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[0], 0, 0, 0);
+                if constexpr (SELF == 99) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
+                else if constexpr (SELF > 1) asm volatile("s_nop %0" :: "n"(SELF - 2));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) victim_op<V>(a[j], x[j], m);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = x[j] * f32x2{0.999f, 1.001f};
+            if (V == 9 || V == 11 || V == 15 || V == 17)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = a[j] * f32x2{0.5f, 0.5f} + f32x2{1.0f, 1.0f};
+        }
+        float s = acc[0][3] * 1e-30f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += a[j].x * 3.0f + a[j].y;
+        out[gid] = s;
+    } else {
+        if (AGGR == 0) {
+            for (int it = 0; it < iters; ++it) __builtin_amdgcn_s_sleep(8);
+        } else {
+            bf16x8 abf, bbf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { abf[j] = (__bf16)(0.001f * (lane + j)); bbf[j] = (__bf16)(0.5f - 0.001f * j); }
+            for (int it = 0; it < iters * 2; ++it) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (AGGR == 1 || AGGR == 5) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[j], 0, 0, 0);
+                    if (AGGR == 2) acc4[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc4[j], 0, 0, 0);
+                    if (AGGR == 3) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(abf, bbf, acc[j], 0, 0, 0);
+                    if (AGGR == 4) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(0.001f * lane, 0.5f, acc[j], 0, 0, 0);
+                    if (AGGR != 5) asm volatile("s_nop %0" :: "n"(GAP));
+                }
+            }
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][15] + acc4[j][0];
+            if (s == 12345.678f) sink[0] = s;
+        }
+    }
+}
+
+// What exactly is lost?  d = {sentinel, sentinel}; d = pk_fma(x, m, c) with src1 hi,hi; compare d.x with the scalar fma.
+__global__ void __launch_bounds__(512) kind_kernel(unsigned* counts, float* sink, int iters) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < 4) {
+        unsigned ok = 0, sentinel = 0, addend = 0, other = 0, hi_bad = 0;
+        f32x2 x = {0.5f + 0.001f * lane, 0.25f}, c = {3.0f, 5.0f};
+        const f32x2 m = {1.5f, 1.25f};
+        for (int it = 0; it < iters * 8; ++it) {
+            f32x2 d = {-7777.0f, -8888.0f};
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "+v"(d) : "v"(x), "v"(m), "v"(c));
+            const float want_lo = fmaf(x.x, m.y, c.x), want_hi = fmaf(x.y, m.y, c.y);
+            if (d.x == want_lo) ++ok; else if (d.x == -7777.0f) ++sentinel; else if (d.x == c.x) ++addend; else ++other;
+            if (d.y != want_hi) ++hi_bad;
+            x.x += 0.001f; c.x += 0.5f;
+        }
+        if (sentinel) atomicAdd(counts + 1, sentinel);
+        if (addend) atomicAdd(counts + 2, addend);
+        if (other) atomicAdd(counts + 3, other);
+        if (hi_bad) atomicAdd(counts + 4, hi_bad);
+        atomicAdd(counts + 0, ok);
+        if (lane >= 48 && (sentinel | addend | other)) atomicAdd(counts + 5, sentinel + addend + other);
+    } else {
+        f32x16 acc[4] = {};
+        f16x8 av, bv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { av[j] = (_Float16)(0.001f * (lane + j)); bv[j] = (_Float16)(0.5f - 0.001f * j); }
+        for (int it = 0; it < iters * 2; ++it) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[j], 0, 0, 0); asm volatile("s_nop 7"); }
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][15];
+        if (s == 12345.678f) sink[0] = s;
+    }
+}
+
+static float *g_out, *g_sink;
+static const char* vname(int v) {
+#define X(ID, TXT, NAME) if (v == ID) return NAME;
+    VICTIMS(X)
+#undef X
+    return "?";
+}
+template <int V, int AGGR, int GAP, int SELF>
+static void launch(std::vector<float>& h, int iters) {
+    const int blocks = 256;
+    hipLaunchKernelGGL((k<V, AGGR, GAP, SELF>), dim3(blocks), dim3(512), 0, 0, g_out, g_sink, iters);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h.data(), g_out, h.size() * 4, hipMemcpyDeviceToHost);
+}
+template <int V, int AGGR, int GAP, int SELF = 0>
+static void row(const char* an) {
+    const int n = 256 * 256, iters = 3000, reps = 12;
+    std::vector<float> ref(n), h(n);
+    launch<V, 0, 0, 0>(ref, iters);
+    if (SELF) launch<V, 0, 0, 99>(ref, iters);   // reference for the self test: the same loop with the matrix instruction 64 wait states ahead of the packed chain
+    unsigned long long bad = 0, q[4] = {0, 0, 0, 0};
+    for (int r = 0; r < reps; ++r) {
+        launch<V, AGGR, GAP, SELF>(h, iters);
+        for (int i = 0; i < n; ++i)
+            if (memcmp(&h[i], &ref[i], 4)) { ++bad; ++q[(i & 63) >> 4]; }
+    }
+    printf("%-44s | %-34s | %8llu of %llu lane-results differ  (lane quarters %llu %llu %llu %llu)\n", vname(V), an, bad, (unsigned long long)n * reps, q[0], q[1], q[2], q[3]);
+    fflush(stdout);
+}
+
+int main() {
+    (void)hipMalloc(&g_out, 256 * 256 * 4); (void)hipMalloc(&g_sink, 4);
+    printf("## victim instruction forms against f16 32x32x16 matrix instructions issued with 8 wait states between them by the SIMD's other wave\n");
+#define X(ID, TXT, NAME) row<ID, 1, 7>("f16 32x32x16, s_nop 7 between");
+    VICTIMS(X)
+#undef X
+    printf("## the src1-crossed form against other aggressors\n");
+    row<1, 5, 0>("f16 32x32x16 back to back");
+    row<1, 1, 0>("f16 32x32x16, s_nop 0 between");
+    row<1, 1, 1>("f16 32x32x16, s_nop 1 between");
+    row<1, 1, 3>("f16 32x32x16, s_nop 3 between");
+    row<1, 1, 15>("f16 32x32x16, s_nop 15 between");
+    row<1, 2, 7>("f16 16x16x32, s_nop 7 between");
+    row<1, 2, 3>("f16 16x16x32, s_nop 3 between");
+    row<1, 3, 7>("bf16 32x32x16, s_nop 7 between");
+    row<1, 4, 7>("f32 32x32x2, s_nop 7 between");
+    row<1, 4, 15>("f32 32x32x2, s_nop 15 between");
+    {
+        unsigned* counts; (void)hipMalloc(&counts, 32); (void)hipMemset(counts, 0, 32);
+        hipLaunchKernelGGL(kind_kernel, dim3(256), dim3(512), 0, 0, counts, g_sink, 3000);
+        (void)hipDeviceSynchronize();
+        unsigned h[8]; (void)hipMemcpy(h, counts, 32, hipMemcpyDeviceToHost);
+        printf("## what is lost (d preset to a sentinel, d = pk_fma(x, m, c) op_sel:[0,1,0], f16 matrix instructions on the other wave):\n"
+               "   low half right %u, low half = SENTINEL (the register write is lost) %u, low half = addend (product lost) %u, other %u; high half wrong %u; wrong results in lanes 48-63: %u\n",
+               h[0], h[1], h[2], h[3], h[4], h[5]);
+    }
+    printf("## ONE wave per SIMD: the victim wave issues the f16 matrix instruction itself, k wait states ahead of eight src1-crossed packed fmas\n");
+    row<1, 0, 0, 1>("self, 0 states between");  row<1, 0, 0, 2>("self, 1 state");   row<1, 0, 0, 3>("self, 2 states");  row<1, 0, 0, 4>("self, 3 states");
+    row<1, 0, 0, 5>("self, 4 states");          row<1, 0, 0, 6>("self, 5 states");  row<1, 0, 0, 7>("self, 6 states");  row<1, 0, 0, 8>("self, 7 states");
+    row<1, 0, 0, 9>("self, 8 states");          row<1, 0, 0, 10>("self, 9 states"); row<1, 0, 0, 11>("self, 10 states"); row<1, 0, 0, 13>("self, 12 states");
+    row<1, 0, 0, 15>("self, 14 states");        row<1, 0, 0, 17>("self, 16 states");
+    return 0;
+}
