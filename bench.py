@@ -93,6 +93,8 @@ def make_env(variant, n, ga, env_id_base, seed=0, residual="default"):
     else:
         env = Quadcopter3DGatesINDI(n, *square_track(), gates_ahead=ga, seed=seed, env_id_base=env_id_base,
                                     infos_mode="none")
+    if os.environ.get("QR_ROLLOUT_FORM"):   # A/B runs of the probe tools: auto | multi_wave | general | general_multi_wave (the library reads no env var)
+        env.set_rollout_form(os.environ["QR_ROLLOUT_FORM"])
     return env
 
 

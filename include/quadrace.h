@@ -49,7 +49,7 @@ extern "C" {
 /* libquadrace.so is built with -fvisibility=hidden: only what this header declares is exported */
 #pragma GCC visibility push(default)
 
-#define QR_ABI_VERSION 3   /* additive since 3 (no signature changed): qr_rollout_kernel_name (round 4; a benchmark / profiling hook) */
+#define QR_ABI_VERSION 3   /* additive since 3 (no signature changed): qr_rollout_kernel_name (round 4), qr_set_rollout_form (round 5) */
 
 enum {
     QR_OK = 0,
@@ -170,6 +170,11 @@ int qr_set_timing(qr_env* env, int32_t on);
  * flags and whether a terminal-observation buffer is registered), e.g. "rollout_fast_mlp_kernel" -- the symbol rocprofv3 lists as
  * qr::<name><variant, gates_ahead>.  Benchmarks print it so that profiles and counter evidence can be matched to the run. */
 const char* qr_rollout_kernel_name(const qr_env* env);
+/* Which family of fused kernels qr_step_many may pick from (all produce bit-identical results; this is a testing / A-B hook, there is
+ * no environment variable): AUTO = by env count and mode; flags MULTI_WAVE = the forms built for more than
+ * one workgroup per CU, at any env count; GENERAL = the general kernels (every mode) for every launch; the two may be or-ed. */
+enum { QR_ROLLOUT_AUTO = 0, QR_ROLLOUT_MULTI_WAVE = 1, QR_ROLLOUT_GENERAL = 2 };
+int qr_set_rollout_form(qr_env* env, int32_t form);
 int qr_profile_steps(qr_env* env, int32_t num_steps, const float* actions_dev, float* obs_out_dev,
                      float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream,
                      float* mean_kernel_ms, float* region_ms);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "qr_set_terminal_obs": (C.c_int, [_vp, _vp, C.c_int32]),
     "qr_set_timing": (C.c_int, [_vp, C.c_int32]),
     "qr_rollout_kernel_name": (C.c_char_p, [_vp]),
+    "qr_set_rollout_form": (C.c_int, [_vp, C.c_int32]),
     "qr_seed": (C.c_int, [_vp, C.c_uint64]),
     "qr_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "qr_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -91,6 +92,9 @@ SIGNATURES = {
 }
 
 
+ADDED_IN_ROUND_5 = ("qr_set_rollout_form",)
+
+
 class QuadraceError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libquadrace error {code}: {msg}")
@@ -115,6 +119,8 @@ def load(build_if_missing=True):
         raise RuntimeError(f"{_build.LIB} is missing: run `python -m optimal_quad_control_rl_amd.build`")
     L = C.CDLL(_build.LIB)
     for name, (rt, at) in SIGNATURES.items():
+        if name in ADDED_IN_ROUND_5 and not hasattr(L, name) and os.environ.get("QR_PROBE_LIB"):
+            continue   # a forensic build of an older source tree (tools/isa_patch.py): ABI 3 is additive, the older library lacks the entry
         fn = getattr(L, name)  # AttributeError here = ABI drift between header and library
         fn.restype, fn.argtypes = rt, at
     if L.qr_abi_version() != 3:

@@ -89,8 +89,9 @@ def needs_build():
     return any(os.path.getmtime(d) > t for s in SOURCES for d in _deps(s))
 
 
-def build_native(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
+def build_native(force=False, verbose=False, extra_flags=(), out=None):
+    """out: link an experiment variant (tools/exp_build.sh) somewhere else than LIB -- same pipeline, same rewrite, same lint."""
+    if out is None and not force and not needs_build():
         return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
     from concurrent.futures import ThreadPoolExecutor
@@ -106,7 +107,8 @@ def build_native(force=False, verbose=False, extra_flags=()):
                 jobs.append(pool.submit(_compile_one, src, obj, [*flags, *extra_flags], verbose))
         for j in jobs:
             j.result()
-    tmp = LIB + ".tmp.%d" % os.getpid()   # link beside the target, then rename: a concurrent dlopen never sees a partial file
+    target = out or LIB
+    tmp = target + ".tmp.%d" % os.getpid()   # link beside the target, then rename: a concurrent dlopen never sees a partial file
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
            "-o", tmp, *objs]
     if verbose:
@@ -116,8 +118,8 @@ def build_native(force=False, verbose=False, extra_flags=()):
     if bad:
         os.unlink(tmp)
         raise RuntimeError("libquadrace.so would contain %d packed-f32 instruction(s) of the hazardous form (isa_lint.py): %s ..." % (len(bad), bad[:3]))
-    os.replace(tmp, LIB)
-    return LIB
+    os.replace(tmp, target)
+    return target
 
 
 def build_native_locked(**kw):

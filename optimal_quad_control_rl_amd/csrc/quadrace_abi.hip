@@ -16,8 +16,8 @@
 namespace qr {
 hipError_t launch_step(int variant, const Params& P, const float* actions, float* obs, float* rew, uint8_t* done,
                        uint8_t* trunc, hipStream_t st);
-const char* rollout_kernel_name(int variant, const Params& P);
-hipError_t launch_rollout(int variant, const Params& P, int K, const float* actions, float* obs, float* rew,
+const char* rollout_kernel_name(int variant, const Params& P, int form);
+hipError_t launch_rollout(int variant, const Params& P, int form, int K, const float* actions, float* obs, float* rew,
                           uint8_t* done, uint8_t* trunc, hipStream_t st);
 hipError_t launch_rollout_policy(int variant, const Params& P, const PolicyArgs& A, int K, float* obs, float* act,
                                  float* logp, float* rew, uint8_t* done, uint8_t* trunc, float* last_obs,
@@ -42,6 +42,7 @@ struct qr_env {
     void* slab = nullptr;       // one HBM allocation holding every state plane
     float* d_tables = nullptr;  // [gate rows | fused MLP table]
     int num_gates = 0;
+    int rollout_form = 0;       // QR_ROLLOUT_AUTO | _MULTI_WAVE | _GENERAL (qr_set_rollout_form)
     int term_rows = 0;          // leading dimension of the registered terminal-observation buffer (K-step calls need K <= rows)
     bool has_track = false;
     std::vector<float> gate_pos, gate_yaw, gate_pos_rel, gate_yaw_rel;
@@ -431,7 +432,7 @@ int qr_step_many(qr_env* e, int32_t K, const float* actions_dev, float* obs_out_
     const bool ev = want_events(e, st);
     if (ev) QR_HIP(hipEventRecord(e->ev0, st));
     // one launch: the fused rollout kernel keeps the env state in registers across the K steps
-    QR_HIP(qr::launch_rollout(e->cfg.variant, e->P, K, actions_dev, obs_out_dev, rew_out_dev, done_out_dev,
+    QR_HIP(qr::launch_rollout(e->cfg.variant, e->P, e->rollout_form, K, actions_dev, obs_out_dev, rew_out_dev, done_out_dev,
                               trunc_out_dev, st));
     if (ev) QR_HIP(hipEventRecord(e->ev1, st));
     e->timing_valid = ev;
@@ -574,7 +575,14 @@ int qr_set_state(qr_env* e, const float* world_dev, const float* dist_dev, const
 
 const char* qr_rollout_kernel_name(const qr_env* e) {
     if (!e) return "";
-    return qr::rollout_kernel_name(e->cfg.variant, e->P);
+    return qr::rollout_kernel_name(e->cfg.variant, e->P, e->rollout_form);
+}
+
+int qr_set_rollout_form(qr_env* e, int32_t form) {
+    if (!e) return fail(QR_E_INVALID, "qr_set_rollout_form: null env");
+    if (form < 0 || form > (QR_ROLLOUT_MULTI_WAVE | QR_ROLLOUT_GENERAL)) return fail(QR_E_INVALID, "qr_set_rollout_form: unknown form");
+    e->rollout_form = form;
+    return QR_OK;
 }
 
 int qr_set_timing(qr_env* e, int32_t on) {

@@ -574,14 +574,12 @@ __device__ __forceinline__ void dot_chunk(const float* w, const f32x16& acc, int
     d.s23 = __builtin_elementwise_fma(w23, relu2_scaled(a23, down, ready), d.s23);
 }
 
-// kMode: 0 = layer-1 weight operands in registers (MlpRegs::a), for kernels that are NEVER co-resident with another wave on their SIMD
-//            (at most one workgroup per CU by construction: the one-wave fused forms, the closed-loop kernel);
-//        1 = operands re-read from LDS (MlpRegs::a_lds) every call, GUARDED;  2 = operands in registers, GUARDED (the per-step kernel).
-// GUARDED = safe with two waves per SIMD, see the statement behind the matrix instructions below.
+// kMode: 0 = layer-1 weight operands in registers (MlpRegs::a);  1 = operands re-read from LDS (MlpRegs::a_lds) every call -- the fused
+//        form for two workgroups per CU, where 256 registers per wave are the budget.
 template <int kMode = 0>
 __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const float x[10], float& thrust,
                                              float moment[3]) {
-    constexpr bool kALds = (kMode == 1), kGuard = (kMode >= 1);
+    constexpr bool kALds = (kMode == 1);
     // ---- split the inputs: P0 = f16 pairs of x, P1 = f16 pairs of x - X0 (exact difference) ----
     const uint32_t p0_01 = pack_f16(x[0], x[1]), p0_23 = pack_f16(x[2], x[3]), p0_45 = pack_f16(x[4], x[5]);
     const uint32_t p0_6o = pack_f16(x[6], 1.0f);   // k-slot 7 multiplies the bias
@@ -626,35 +624,11 @@ __device__ __forceinline__ void residual_mlp(const MlpRegs& m, int lane, const f
     // (Tried in round 4 and dropped: sched_group_barrier patterns "one MFMA, then 4 / 7 VALU instructions" to pull the MLP-independent
     // part of the step between the ten matrix instructions -- 4 176 instead of 3 997 cycles per fused step: the compiler's own
     // back-to-back issue with the VALU work behind it is the better schedule here.)
-    // ---- GUARD for kernels that can share a SIMD with another wave (two workgroups per CU and more) -------------------------------
-    // Found with tools/lean_stress.py / the full-chip-load test: in those kernels -- and only from 131 072 envs up,
-    // never at one workgroup per CU -- the last quarter of a wave's lanes (48-63) came out wrong in rare steps, in whatever value the
-    // register allocator had placed next to the matrix block: a reward, one observation element, the MLP output itself; which build
-    // failed, and how often (16 values per 4e7 ... 2e6 per 1e9), moved with unrelated code changes.  Two things together make every
-    // build pass (0 mismatches in > 60 full-load rollouts over all variants that failed before):
-    //   (1) nothing reads an accumulator until all ten matrix instructions have been issued and 32 wait states have passed (the
-    //       compiler otherwise interleaves the first ReLUs with the last matrix instructions at exactly the architectural minimum
-    //       distance behind each accumulator's writer);
-    //   (2) nothing WRITES a register that a matrix instruction of the block reads (A, B operands) before that point either (the
-    //       compiler otherwise recycles them one instruction after the matrix instruction -- legal by the published hazard tables).
-    // (1) alone fixed the lean builds and broke the general kernel, whose allocation then put a constant into the last matrix
-    // instruction's B registers one instruction behind it; (1) + (2) fixed that too.  The mechanism is NOT established (a bare block of
-    // the ten matrix instructions with B overwritten one wait state later does not fail: tools/ubench/mfma_war.hip) -- the guard rests on
-    // the build matrix of profiles/r04_lean_stress.txt and DESIGN section 4.  Cost: 36 registers live 32 wait states longer -- spills in the
-    // register-starved forms (lean - 13 %, general kernel - 22 % at 1 Mi envs), which is why the forms that own their SIMD
-    // (kMode 0) do not carry it.
-    if constexpr (kGuard) {
-        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(hT0), "+v"(hM0), "+v"(hT1), "+v"(hM1));
-#ifndef QR_GUARD_KEEP
-#define QR_GUARD_KEEP 3   /* experiments: 1 = B operands only, 2 = A operands only */
-#endif
-#if QR_GUARD_KEEP & 1
-        asm volatile("" :: "v"(o1[0]), "v"(o1[1]), "v"(o2[0]), "v"(o2[1]));
-#endif
-#if QR_GUARD_KEEP & 2
-        asm volatile("" :: "v"(aq0), "v"(aq1), "v"(aq2), "v"(aq3), "v"(aq4));
-#endif
-    }
+    // (Rounds 4's "guard" -- 32 wait states and operand keep-alives behind the matrix block for kernels with two waves per SIMD -- is gone:
+    // the corruption it papered over was not in this block at all.  MI355X computes a packed-f32 instruction whose second source feeds
+    // its HIGH dword to the LOW result half wrongly in lanes 48-63 when another wave of the SIMD issues an f16 matrix instruction at
+    // the wrong moment; the SLP vectoriser had produced one such instruction in the equations of motion, and the guard merely shifted
+    // the two waves' phase.  The build now rewrites that instruction form everywhere: isa_lint.py)
     DotAcc dT0, dT1, dM0[3], dM1[3];
     const uint32_t rT0 = acc_ready(hT0);
 #pragma unroll

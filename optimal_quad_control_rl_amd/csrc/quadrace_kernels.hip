@@ -145,10 +145,9 @@ template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
 step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ obs_out,
             float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
-#ifndef QR_STEP_MLP_FROM_GLOBAL   /* the MLP table is staged through LDS with the reset / gate rows (two 16-byte loads per thread), then 22 LDS
-                                   reads per lane fill the weight registers behind the barrier.  A/B (round 4, tools/step_probe.py, same box):
-                                   loading the registers straight from global memory instead -- 22 loads per lane through the texture
-                                   path -- costs 0.84 us per launch: 6.60 vs 5.77 us. */
+    // The MLP table is staged through LDS with the reset / gate rows (two 16-byte loads per thread), then 22 LDS reads per lane fill the
+    // weight registers behind the barrier.  (Round 4 A/B, same box: loading the registers straight from global memory instead -- 22
+    // loads per lane through the texture path -- costs 0.84 us per launch, 6.60 vs 5.77 us; that form is gone.)
     constexpr int kTab = (V == kE2E) ? kMlpTableFloats : 0;
     __shared__ __attribute__((aligned(16))) float lds[kTab + kResetTableFloats + kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -183,40 +182,11 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
     if (use_mlp) mlp_load_regs(lds, lane, mlp);
     float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * obs_len<V, GA>();
     QR_TICK(P, 2);
-#else
-    __shared__ __attribute__((aligned(16))) float lds[kResetTableFloats + kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    // Lanes past the end of a ragged batch stay ACTIVE (they shadow env 0) because the residual MLP uses
-    // wave-wide operations (MFMA, permlane swap); only their stores are suppressed.
-    const bool active = i < P.n;
-    const int ii = active ? i : 0;
-    QR_TICK(P, 0);
-
-    // (A/B form, -DQR_STEP_MLP_FROM_GLOBAL) weight registers loaded straight from global memory: SLOWER, see above
-    const bool use_mlp = (V == kE2E) && (P.flags & kFlagResidual);
-    float* rtab = lds;                        // [reset table | gate rows | obs tiles]
-    float* gates = rtab + kResetTableFloats;
-    const int tab_vec = (kResetTableFloats + P.num_gates * kGateStride) / 4;   // <= 120 float4: one load per thread
-    const float4* tsrc = reinterpret_cast<const float4*>(P.tables + kOffResetImage);
-    const float4 tv0 = tsrc[(int)threadIdx.x < tab_vec ? threadIdx.x : 0];
-    MlpRegs mlp;
-    if (use_mlp) mlp_load_regs(P.tables, lane, mlp);
-    Env<V> e;
-    load_env<V>(P, ii, e);
-    const float4 act = actions[ii];
-    QR_TICK(P, 1);
-    if ((int)threadIdx.x < tab_vec) reinterpret_cast<float4*>(rtab)[threadIdx.x] = tv0;
-    __syncthreads();
-    float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * obs_len<V, GA>();
-    QR_TICK(P, 2);
-
-#endif
     const float u[4] = {act.x, act.y, act.z, act.w};
     const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
     bool done, trunc, did_reset;
-    const float reward = step_env<V, 2>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc, did_reset,   // 2: guarded (any env count)
+    const float reward = step_env<V>(P, gates, rtab, tile, mlp, lane, active, e, u, gid_lo, gid_hi, done, trunc, did_reset,
                                         [&](bool fin) { store_terminal_obs<V, GA>(P, gates, e, 0, i, fin && active); });
     if (active) {
         stream_store(rew_out + i, reward);
@@ -395,47 +365,7 @@ __device__ __forceinline__ void obs_tile_store_rows(float* __restrict__ tile, in
 // live around the loop's back edge stayed in scratch: it is only indexable by constants after the inner loops are unrolled).
 #define QR_BURST8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
-// One step's actions of a wave, HBM -> LDS without passing through registers (gfx950 LDS-DMA): lane l's 16 bytes land at
-// lds_wave_base + 16 l.  M0 carries the LDS base and is compiler-reserved: saved and restored inside the statement.  The compiler does
-// not count this load (its own s_waitcnt values only ever over-wait because of that); the consumer waits with act_ring_wait().
-__device__ __forceinline__ void act_ring_load(const float4* __restrict__ src, uint32_t lds_wave_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds_wave_base) : "memory");
-}
-// Vector-memory operations complete in issue order (vmcnt): "at most N outstanding" means everything older than the last N has
-// landed.  The slot read at step k was requested at step k - R, behind that step's dynamics; a full wave then still issues that
-// step's reward and done stores (2; the observation block of the step before only from step 1 on) and in each of the R - 1 steps in
-// between kFlush observation stores, reward, done and the ring load: N = 2 + (R - 1)(kFlush + 3) operations are certainly younger.
-// The first R steps and ragged waves (which may issue none of these) wait for everything.
-// NOTE -- the counted wait is a MARGIN, not an architectural guarantee: operations of different kinds do not retire strictly in issue
-// order under load.  The no-MLP lean form, whose four steps take ~3 us, read slots the ring load had not reached yet (from step ~30 of
-// a 262 144-env rollout on; tools/lean_stress.py e2e_nores) -- so that form does NOT use the ring (it has the registers for the
-// prefetch).  The MLP form's four steps take ~13 us, 4-5 x the worst load-to-landing time seen anywhere in these kernels, and the
-// full-chip-load test checks it; a poisoned-slot handshake that turns the margin into a guarantee was built and measured (reader
-// re-reads behind vmcnt(0) when it still finds the poison: correct on every form, - 10 % on this one) and is not in.
-template <int N>
-__device__ __forceinline__ void act_ring_wait(bool counted) {
-    static_assert(N >= 1 && N <= 63, "vmcnt is a 6-bit counter");
-    if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// A/B switches of the action path (defaults = what ships).  The one-wave form with the ring (-DQR_FAST_RING=1): 4 078 instead of 3 881
-// cycles per step in the clock-probe build, + 1 % / +- 2 % (K = 1000 / K = 20) on the wall clock in the production build
-// (profiles/r04_ring_ab.txt) -- never enabled.  The lean MLP form: ring (QR_LEAN_RING=1); QR_LEAN_PREFETCH selects, for builds
-// without the ring, register prefetch (1) or loads at the top of the chunk (0).
-#ifndef QR_FAST_RING
-#define QR_FAST_RING 0
-#endif
-#ifndef QR_LEAN_RING
-#define QR_LEAN_RING 1
-#endif
-#ifndef QR_LEAN_PREFETCH
-#define QR_LEAN_PREFETCH 1
-#endif
-
-template <int V, int GA>   // lean form: slots of the action ring (a power of two)
+template <int V, int GA>   // lean form: steps of actions per burst
 constexpr int lean_act_chunk() { return obs_len<V, GA>() > 32 ? 2 : 4; }
 template <int V, int GA, bool kMlp>   // floats of (dynamic) LDS of the lean form: tables, observation tiles, action slots, layer-1 operands, reset pool
 constexpr int lean_lds_floats() {
@@ -452,10 +382,12 @@ constexpr int lean_lds_floats() {
 //     step (as the other form does, to take the LDS latency off a lone wave's chain) its 24 registers were live through the residual
 //     MLPs and the allocator spilled two address pairs -- and the reload of a spilled value is a vector-memory wait (vmcnt(0)) that
 //     drains the wave's whole queue of outstanding stores once per step;
-//   * with the residual MLPs: the actions come through a RING of LDS slots filled by LDS-DMA R steps ahead (act_ring_load: no
-//     registers -- the guard of the matrix block, quadrace_device.hpp residual_mlp, needs them -- and no chunk boundary);
-//     without the MLPs: the next 4-step chunk is requested into registers a chunk ahead (that form has them, and its steps are too
-//     fast for the ring's counted wait, see act_ring_wait).
+//   * actions: the next 4-step chunk is requested into registers a chunk ahead, like the one-wave form.  (Round 4 fed the MLP form
+//     through a RING of LDS slots filled by LDS-DMA with a COUNTED s_waitcnt vmcnt(N) on the consumer side: 1-3 % faster, and unsound --
+//     loads and stores share vmcnt on gfx9-family hardware and do not retire in issue order against each other, so "N younger
+//     operations" guarantees nothing; the no-MLP form was caught reading slots the load had not reached.  The compiler's own waits
+//     for the register prefetch are conservative for exactly that reason (vmcnt(0) at the top of a chunk).  The ring is gone:
+//     round 5 A/B on one box, 1 Mi envs 37.6 -> 37.1 G env-steps/s, profiles/r05_unguarded_ab.txt.)
 // 1 Mi envs: 36.9 -> 39.6 G env-steps/s A/B'd on one box (profiles/r04_lean_ab.txt), every build checked against K x step_kernel under
 // full-chip load (tools/lean_stress.py, profiles/r04_lean_stress.txt, tests/test_gpu_round4.py::test_lean_forms_agree...).
 template <int V, int GA, bool kMlp, bool kLean>
@@ -468,8 +400,6 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     constexpr int kVec = 16 * L;                 // float4 elements of a wave's [64][L] observation block
     constexpr int kFlush = (kVec + 63) / 64;     // store instructions per block
     constexpr bool kALds = kLean && kMlp;
-    constexpr bool kRing = kLean ? (kMlp && QR_LEAN_RING != 0) : (QR_FAST_RING != 0);   // actions through the LDS-DMA ring: the MLP lean form only
-    constexpr bool kPrefetch = !kRing && (!kLean || (QR_LEAN_PREFETCH != 0));       // next chunk requested into registers a chunk ahead
     constexpr int kOffA = kResetTableFloats + kMaxGates * kGateStride + kBlock * L + 4 * kBlock * kActChunk;
     constexpr int kOffWho = kOffA + (kALds ? 4 * kMlpQuads * 64 : 0);   // lean: [4 waves][16] dwords, then the reset pool [4][64][NB] float4
     constexpr int kOffPool = kOffWho + 4 * 16;
@@ -515,11 +445,9 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     if (kMlp && !kMlpViaLds) mlp_load_regs(P.tables, lane, mlp, !kALds);
     float4 b0, b1, b2, b3, b4, b5, b6, b7;
     b0 = b1 = b2 = b3 = b4 = b5 = b6 = b7 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if constexpr (kPrefetch) {
 #define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)(J < K ? J : K - 1) * n + ii];
-        QR_BURST8(QR_X)
+    QR_BURST8(QR_X)   // first chunk of actions
 #undef QR_X
-    }
     Env<V> e;
     load_env<V>(P, ii, e);
     if ((int)threadIdx.x < tab_vec) reinterpret_cast<float4*>(lds)[threadIdx.x] = tv;
@@ -537,22 +465,8 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
         mlp_load_regs(lds + kResetTableFloats + kMaxGates * kGateStride + kBlock * L, lane, mlp);
         __syncthreads();   // every wave has its weight registers: the area is free for the action slots
     }
-    // kRing: the actions come through a RING of kActChunk LDS slots filled by LDS-DMA kActChunk steps ahead:
-    // no registers, no chunk boundary, and the consumer's counted wait never waits behind the wave's own recent stores.  (With the
-    // register prefetch of whole chunks the compiler waits vmcnt(7..0) for the loads at the top of every chunk -- it cannot count the
-    // stores of the inner loop -- i.e. the store queue drains once per chunk.)  First turn requested here (the one-wave form's slot
-    // area held the MLP table until the barrier above).
+    // lane-private action slots (consecutive lanes = consecutive 16 B, conflict-free); each lane only reads back what it wrote itself
     float4* const act_slot = reinterpret_cast<float4*>(lds + kResetTableFloats + kMaxGates * kGateStride + kBlock * L) + threadIdx.x;
-    const float4* act_src = actions + ii;       // this lane's action of the step the next ring load asks for
-    [[maybe_unused]] const uint32_t ring_base =
-        __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(act_slot - lane));   // LDS byte address of the wave's slot 0
-    if constexpr (kRing) {
-#pragma unroll
-        for (int j = 0; j < kActChunk; ++j) {
-            act_ring_load(act_src, ring_base + (uint32_t)j * kBlock * 16u);
-            if (j + 1 < K) act_src += n;        // clamped: past the last step the ring re-reads step K - 1 (never consumed)
-        }
-    }
     const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
     float stash[kLean ? 1 : reset_value_count<V>()];
@@ -583,34 +497,21 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     bool any_reset = false;
     bool pending = false;                      // a tile written by the previous step waits to be streamed out (full waves)
     QR_CLOCK_STAMP(P, 1);
-    for (int k0 = 0; k0 < K; k0 += kActChunk) {   // (ring: a "chunk" is one turn of the ring)
+    for (int k0 = 0; k0 < K; k0 += kActChunk) {
         const int c = (K - k0 < kActChunk) ? K - k0 : kActChunk;
-        if constexpr (!kRing && !kPrefetch) {   // this chunk's actions, loaded here (clamped step index keeps the loads unconditional)
-#define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)((k0 + J < K) ? k0 + J : K - 1) * n + ii];
-            QR_BURST8(QR_X)
-#undef QR_X
-        }
-        if constexpr (!kRing) {
 #define QR_X(J) if constexpr (J < kActChunk) act_slot[J * kBlock] = b##J;
+        QR_BURST8(QR_X)
+#undef QR_X
+        if (k0 + kActChunk < K) {   // request the next chunk now; it lands while this chunk is simulated
+#define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)((k0 + kActChunk + J < K) ? k0 + kActChunk + J : K - 1) * n + ii];
             QR_BURST8(QR_X)
 #undef QR_X
-            if (kPrefetch && k0 + kActChunk < K) {   // request the next chunk now; it lands while this chunk is simulated
-#define QR_X(J) if constexpr (J < kActChunk) b##J = actions[(size_t)((k0 + kActChunk + J < K) ? k0 + kActChunk + J : K - 1) * n + ii];
-                QR_BURST8(QR_X)
-#undef QR_X
-            }
         }
         for (int j = 0; j < c; ++j) {
 #ifdef QR_PHASE_TIMING
             P.tick_on = (k0 + j == K / 2);
 #endif
             QR_TICK(P, 2);
-            if constexpr (kRing) {
-                constexpr int kYounger = 2 + (kActChunk - 1) * (kFlush + 3);
-                // first turn: wait for everything (exact counts per step of the first turn were built and measured: 38.5 instead of
-                // 39.1 G env-steps/s at 1 Mi envs, a tie at K = 32 -- the extra branches cost more than the four early drains)
-                act_ring_wait<(kYounger < 63 ? kYounger : 63)>(full_wave && k0 > 0);
-            }
             const float4 act = act_slot[j * kBlock];
             // stream the previous step's observation block out: LDS reads here, global stores after the rotation matrix
             // (lean: the reads happen next to the stores, behind the dynamics -- 24 registers that would otherwise be live through the
@@ -632,10 +533,6 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
             bool done, trunc;
             const float reward = step_dynamics<V, kALds ? 1 : 0>(P, gate, mlp, kMlp, lane, e, u, nw, new_target, done, trunc);
             QR_TICK(P, 5);
-            if constexpr (kRing) {              // the slot just consumed (its read has returned: the dynamics used it) gets step j + R
-                act_ring_load(act_src, ring_base + (uint32_t)j * kBlock * 16u);
-                if (k0 + j + kActChunk + 1 < K) act_src += n;
-            }
             if (pending) {
                 if constexpr (kLean) read_block();
                 float4* g4 = reinterpret_cast<float4*>(obs_step - n * L + (size_t)wave_first * L);
@@ -666,14 +563,10 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
             float o[L];
             observe_with<V, GA>(P, gate, rel, e, o);
             if (full_wave) {
-#ifdef QR_FAST_IMMEDIATE_FLUSH   /* A/B: stream the block out right away, as the general kernel does */
-                store_obs_coalesced<V, GA>(tile, obs_step, (size_t)wave_first, lane, o);
-#else
-                obs_tile_store_rows<V, GA>(tile, lane, o);
+                obs_tile_store_rows<V, GA>(tile, lane, o);   // streamed out in the middle of the NEXT step (worth ~600 cycles per step, r04)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 pending = true;
-#endif
             } else if (active) {
                 store_obs<V, GA>(obs_step, i, o);
             }
@@ -1033,8 +926,6 @@ hipError_t launch_step(int variant, const Params& P, const float* actions, float
     return hipGetLastError();
 }
 
-// the reset stash costs 24 registers for the whole loop: worth it while every workgroup has a CU to itself (then the wave's budget is
-// 512 registers anyway); beyond that the plain form keeps two workgroups per CU.  QR_ROLLOUT_STASH=0 / 1 forces the choice.
 static int n_wgs(int n) { return (n + kBlock - 1) / kBlock; }
 static int device_cus() {
     static int cus = 0;
@@ -1045,26 +936,6 @@ static int device_cus() {
     }
     return cus;
 }
-static bool use_rollout_stash(int n) {
-    static int forced = -2;
-    if (forced == -2) {
-        const char* v = getenv("QR_ROLLOUT_STASH");
-        forced = v ? (v[0] == '0' ? 0 : 1) : -1;
-    }
-    if (forced >= 0) return forced == 1;
-    return (n + kBlock - 1) / kBlock <= device_cus();
-}
-
-// QR_ROLLOUT_FAST=0 keeps the round-3 kernels for every launch (A/B switch; the results are bit-identical either way)
-static bool rollout_fast_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* v = getenv("QR_ROLLOUT_FAST");
-        on = (v && v[0] == '0') ? 0 : 1;
-    }
-    return on == 1;
-}
-
 // Which kernel runs a K-step call -- ONE selection, used by the launcher and by qr_rollout_kernel_name() (bench.py prints the symbol
 // rocprofv3 will show, and looks its counter evidence up under that name):
 //   at most one workgroup per CU, default mode (no pause flags, no terminal-observation rows):
@@ -1074,11 +945,14 @@ static bool rollout_fast_enabled() {
 //   more workgroups, default mode: E2E + residual MLPs -> rollout_lean_mlp_kernel, INDI / E2E without -> rollout_lean_kernel up to four
 //       workgroups per CU;
 //   more workgroups, anything else -> rollout_kernel
+// `form` = qr_set_rollout_form(), two flags: QR_ROLLOUT_MULTI_WAVE (bit 0: the forms built for more than one workgroup per CU at any
+// env count), QR_ROLLOUT_GENERAL (bit 1: rollout_stash_kernel / rollout_kernel for every launch); 0 = QR_ROLLOUT_AUTO (the table above).  All forms are
+// bit-identical (tests/test_gpu_round4.py); the setter exists for tests and A/B runs -- there is no environment variable.
 enum RolloutKernel { kRkFastMlp, kRkFast, kRkStash, kRkLeanMlp, kRkLean, kRkPlain };
-static RolloutKernel select_rollout(int variant, const Params& P) {
-    const bool plain_mode = !(P.flags & (kFlagPause | kFlagPauseIfCollision)) && P.term_obs == nullptr && rollout_fast_enabled();
+static RolloutKernel select_rollout(int variant, const Params& P, int form) {
+    const bool plain_mode = !(P.flags & (kFlagPause | kFlagPauseIfCollision)) && P.term_obs == nullptr && !(form & 2);
     const bool mlp = variant == kE2E && (P.flags & kFlagResidual);
-    if (use_rollout_stash(P.n)) {
+    if (n_wgs(P.n) <= device_cus() && !(form & 1)) {   // one wave per SIMD: the register file of a whole SIMD per wave (reset stash, operands in registers)
         if (plain_mode && mlp) return kRkFastMlp;
         if (plain_mode && variant == kE2E) return kRkFast;
         return kRkStash;
@@ -1090,8 +964,8 @@ static RolloutKernel select_rollout(int variant, const Params& P) {
     return kRkPlain;
 }
 
-const char* rollout_kernel_name(int variant, const Params& P) {
-    switch (select_rollout(variant, P)) {
+const char* rollout_kernel_name(int variant, const Params& P, int form) {
+    switch (select_rollout(variant, P, form)) {
         case kRkFastMlp: return "rollout_fast_mlp_kernel";
         case kRkFast: return "rollout_fast_kernel";
         case kRkStash: return "rollout_stash_kernel";
@@ -1136,10 +1010,10 @@ static hipError_t launch_rollout_lean(const Params& P, int K, const float4* a4, 
 #endif
 }
 
-hipError_t launch_rollout(int variant, const Params& P, int K, const float* actions, float* obs, float* rew,
+hipError_t launch_rollout(int variant, const Params& P, int form, int K, const float* actions, float* obs, float* rew,
                           uint8_t* done, uint8_t* trunc, hipStream_t st) {
     const float4* a4 = reinterpret_cast<const float4*>(actions);
-    switch (select_rollout(variant, P)) {
+    switch (select_rollout(variant, P, form)) {
         case kRkFastMlp: { QR_DISPATCH_GA(kE2E, rollout_fast_mlp_kernel, P, K, a4, obs, rew, done, trunc) } break;
         case kRkFast: { QR_DISPATCH_GA(kE2E, rollout_fast_kernel, P, K, a4, obs, rew, done, trunc) } break;
         case kRkLeanMlp: return launch_rollout_lean<kE2E, true>(P, K, a4, obs, rew, done, trunc, st);

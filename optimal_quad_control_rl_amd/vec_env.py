@@ -566,6 +566,14 @@ class Quadcopter3DGates(_Base):
             self._last_obs = obs
         return obs, rew, done, trunc
 
+    ROLLOUT_FORMS = {"auto": 0, "multi_wave": 1, "general": 2, "general_multi_wave": 3}
+
+    def set_rollout_form(self, form):
+        """Which family of fused kernels `rollout_device` may use: "auto" (by env count and mode), "multi_wave" (the forms built for more
+        than one workgroup per CU, at any env count), "general" (the general kernels for every launch), "general_multi_wave" (both).  All bit-identical: a test / A-B hook."""
+        _lib.check(self._L.qr_set_rollout_form(self._h, self.ROLLOUT_FORMS[form]))
+        return self
+
     def rollout_kernel_name(self):
         """Symbol of the device kernel rollout_device() launches on this env right now, as rocprofv3 prints it."""
         name = self._L.qr_rollout_kernel_name(self._h).decode()

@@ -73,8 +73,7 @@ def test_split_mlp_is_as_close_to_float64_as_the_float32_chain(residual_blob):
 def test_rollout_kernel_selection_is_reported_and_every_kernel_agrees(residual_blob):
     """qr_rollout_kernel_name reports the kernel a K-step call launches (bench.py prints it and looks its PMC evidence up under it):
     specialised kernels in the default mode, the general ones with a pause flag or a terminal-observation buffer -- and the choice never
-    changes the results: the same env, seed and actions give bit-identical rollouts through QR_ROLLOUT_FAST=0's kernels (a subprocess:
-    the switch is read once per process)."""
+    changes the results: the same env, seed and actions give bit-identical rollouts through every other kernel family (qr_set_rollout_form)."""
     import torch
     from optimal_quad_control_rl_amd import Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES, square_track, zigzag_track
 
@@ -99,78 +98,57 @@ def test_rollout_kernel_selection_is_reported_and_every_kernel_agrees(residual_b
     assert big_indi.rollout_kernel_name() == "qr::rollout_lean_kernel<1, 1>"
     big_indi.pause_if_collision = True
     assert big_indi.rollout_kernel_name() == "qr::rollout_kernel<1, 1>"
-    # the same rollouts through the other kernels of other processes (the switches are read once per process): for every number of
-    # gates ahead, specialised (fast / lean: more than one workgroup per CU, forced here with QR_ROLLOUT_STASH=0) and general forms
-    code = (
-        "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
-        "from optimal_quad_control_rl_amd import Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES, zigzag_track\n"
-        "rows = []\n"
-        "for ga in (0, 1, 2, 3, 4, 11, 21):\n"   # 11: INDI; 21: a ragged env count (part-filled last wave, workgroup with empty waves)
-        "    n = 4096 if ga != 21 else 4096 + 64 + 37\n"
-        "    env = (Quadcopter3DGatesINDI if ga == 11 else Quadcopter3DGates)(n, *zigzag_track(), gates_ahead=ga %% 10, seed=3, infos_mode='none')\n"
-        "    if ga != 11: env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES\n"
-        "    print(env.rollout_kernel_name()); env.reset_device()\n"
-        "    a = torch.rand((43, n, 4), device='cuda', generator=torch.Generator(device='cuda').manual_seed(1)) * 2 - 1\n"
-        "    o, r, d, t = env.rollout_device(a)\n"
-        "    rows.append(np.concatenate([o.cpu().numpy().reshape(43, -1), r.cpu().numpy(), d.cpu().numpy().astype(np.float32), t.cpu().numpy().astype(np.float32)], axis=1).ravel())\n"
-        "np.save(sys.argv[1], np.concatenate(rows))\n"
-    ) % ROOT
-    import tempfile
+    # the same rollouts through every other family (qr_set_rollout_form): for every number of gates ahead, INDI, and a ragged env count
     outs = []
-    expected = {("1", None): "rollout_fast_mlp_kernel", ("0", None): "rollout_stash_kernel", ("1", "0"): "rollout_lean_mlp_kernel",
-                ("0", "0"): "rollout_kernel"}
-    for (fast, stash), kernel in expected.items():
-        f = tempfile.mktemp(suffix=".npy")
-        env_vars = dict(os.environ, QR_ROLLOUT_FAST=fast)
-        env_vars.pop("QR_ROLLOUT_STASH", None)
-        if stash is not None:
-            env_vars["QR_ROLLOUT_STASH"] = stash
-        r = subprocess.run([sys.executable, "-c", code, f], env=env_vars, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        names = r.stdout.strip().splitlines()
-        assert len(names) == 7 and all(("qr::%s<0, %d>" % (kernel, ga)) in r.stdout for ga in range(5)), r.stdout
-        assert names[6] == "qr::%s<0, 1>" % kernel, r.stdout
-        indi = "qr::rollout_stash_kernel<1, 1>" if stash is None else ("qr::rollout_lean_kernel<1, 1>" if fast == "1" else "qr::rollout_kernel<1, 1>")
-        assert names[5] == indi, r.stdout
-        outs.append(np.load(f))
+    expected = {"auto": "rollout_fast_mlp_kernel", "general": "rollout_stash_kernel", "multi_wave": "rollout_lean_mlp_kernel",
+                "general_multi_wave": "rollout_kernel"}
+    for form, kernel in expected.items():
+        rows, names = [], []
+        for ga in (0, 1, 2, 3, 4, 11, 21):   # 11: INDI; 21: a ragged env count (part-filled last wave, workgroup with empty waves)
+            n = 4096 if ga != 21 else 4096 + 64 + 37
+            env = (Quadcopter3DGatesINDI if ga == 11 else Quadcopter3DGates)(n, *zigzag_track(), gates_ahead=ga % 10, seed=3, infos_mode="none")
+            if ga != 11:
+                env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+            env.set_rollout_form(form)
+            names.append(env.rollout_kernel_name())
+            env.reset_device()
+            a = torch.rand((43, n, 4), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 2 - 1
+            o, r, d, t = env.rollout_device(a)
+            rows.append(np.concatenate([o.cpu().numpy().reshape(43, -1), r.cpu().numpy(), d.cpu().numpy().astype(np.float32),
+                                        t.cpu().numpy().astype(np.float32)], axis=1).ravel())
+            env.close()
+        assert names[:5] == ["qr::%s<0, %d>" % (kernel, ga) for ga in range(5)] and names[6] == "qr::%s<0, 1>" % kernel, names
+        indi = {"auto": "rollout_stash_kernel", "general": "rollout_stash_kernel", "multi_wave": "rollout_lean_kernel", "general_multi_wave": "rollout_kernel"}[form]
+        assert names[5] == "qr::%s<1, 1>" % indi, names
+        outs.append(np.concatenate(rows))
     for other in outs[1:]:
         assert np.array_equal(outs[0], other, equal_nan=True)
 
 
 @pytest.mark.gpu
 def test_lean_forms_agree_with_the_general_kernels_under_full_chip_load():
-    """Every test above runs at most one workgroup per CU.  The lean fused forms exist for MORE, and this test -- written for that gap --
-    found unguarded builds of the MLP kernels returning wrong values in a wave's last lane quarter (lanes 48-63: a reward, an observation
-    element, the MLP output) in rare steps, only with two workgroups per CU, nondeterministically, while passing everything else
-    (DESIGN section 4 "A hazard with two waves per SIMD"; the guard is in csrc/quadrace_device.hpp residual_mlp; tools/lean_stress.py is
-    the elementwise version of this check).  So: 1 Mi envs E2E (16 waves per SIMD queued, the memory system saturated by the stores)
-    and 262 144 envs INDI, three 40-step rollouts each: digests of every output and a strided sample must equal those of the general
-    kernels (QR_ROLLOUT_FAST=0, another process)."""
-    code = (
-        "import sys, json, torch; sys.path.insert(0, %r)\n"
-        "from optimal_quad_control_rl_amd import Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES, square_track\n"
-        "res = {}\n"
-        "for name, cls, n in (('e2e', Quadcopter3DGates, 1 << 20), ('indi', Quadcopter3DGatesINDI, 1 << 18)):\n"
-        "    env = cls(n, *square_track(), gates_ahead=1, seed=5, infos_mode='none')\n"
-        "    if name == 'e2e': env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES\n"
-        "    env.reset_device()\n"
-        "    a = torch.rand((40, n, 4), device='cuda', generator=torch.Generator(device='cuda').manual_seed(2)) * 2 - 1\n"
-        "    digs = []\n"
-        "    for rep in range(3):\n"
-        "        o, r, d, t = env.rollout_device(a)\n"
-        "        digs.append([int(o.view(torch.int32).to(torch.int64).sum()), int(r.view(torch.int32).to(torch.int64).sum()), int(d.sum()), int(t.sum()),\n"
-        "           int((o.view(torch.int32).flatten()[::4099].to(torch.int64) * torch.arange(1, o.numel() // 4099 + 2, device='cuda')[: (o.numel() + 4098) // 4099]).sum())])\n"
-        "    res[name] = [env.rollout_kernel_name(), digs, int(torch.isfinite(o).all())]\n"
-        "print(json.dumps(res))\n"
-    ) % ROOT
-    outs = {}
-    for fast in ("1", "0"):
-        env_vars = dict(os.environ, QR_ROLLOUT_FAST=fast)
-        env_vars.pop("QR_ROLLOUT_STASH", None)
-        r = subprocess.run([sys.executable, "-c", code], env=env_vars, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs[fast] = json.loads(r.stdout.strip().splitlines()[-1])
-    assert outs["1"]["e2e"][0] == "qr::rollout_lean_mlp_kernel<0, 1>" and outs["0"]["e2e"][0] == "qr::rollout_kernel<0, 1>"
-    assert outs["1"]["indi"][0] == "qr::rollout_lean_kernel<1, 1>" and outs["0"]["indi"][0] == "qr::rollout_kernel<1, 1>"
-    for name in ("e2e", "indi"):
-        assert outs["1"][name][1] == outs["0"][name][1], (name, outs)
+    """Every test above runs at most one workgroup per CU.  The lean fused forms exist for MORE, and this test -- written in round 4 for
+    that gap -- found MLP kernels returning wrong values in a wave's last lane quarter (lanes 48-63) in rare steps, only with two
+    workgroups per CU, nondeterministically, while passing everything else.  Round 5 found the cause (a packed-f32 instruction form the
+    chip computes wrongly next to another wave's matrix instructions: isa_lint.py, DESIGN section 4, tests/test_gpu_round5.py) and the
+    build no longer emits it; this test stays as the full-chip-load check: 1 Mi envs E2E and 262 144 envs INDI, three 40-step rollouts
+    each, every output bit-identical to the general kernels' (tools/lean_stress.py is the per-step-kernel version of the check)."""
+    import torch
+    from optimal_quad_control_rl_amd import Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES, square_track
+
+    for name, cls, n, lean in (("e2e", Quadcopter3DGates, 1 << 20, "qr::rollout_lean_mlp_kernel<0, 1>"), ("indi", Quadcopter3DGatesINDI, 1 << 18, "qr::rollout_lean_kernel<1, 1>")):
+        a = torch.rand((40, n, 4), device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)) * 2 - 1
+        outs = {}
+        for form in ("auto", "general"):
+            env = cls(n, *square_track(), gates_ahead=1, seed=5, infos_mode="none")
+            if name == "e2e":
+                env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+            env.set_rollout_form(form)
+            assert env.rollout_kernel_name() == (lean if form == "auto" else "qr::rollout_kernel<%d, 1>" % (0 if name == "e2e" else 1))
+            env.reset_device()
+            outs[form] = [[t.clone() for t in env.rollout_device(a)] for _ in range(3)]
+            assert bool(torch.isfinite(outs[form][-1][0]).all())
+            env.close()
+        for ra, rg in zip(outs["auto"], outs["general"]):
+            for x, y in zip(ra, rg):
+                assert torch.equal(x, y), name

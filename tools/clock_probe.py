@@ -50,7 +50,7 @@ if os.environ.get("QR_PROBE_OLD_ABI") == "1":   # a build of the round-3 sources
     _lib.SIGNATURES.pop("qr_rollout_kernel_name", None)
 L = _lib.load()
 L.qr_debug_set_ticks.argtypes = [C.c_void_p, C.c_void_p]
-print(f"# {variant} K={K} stash={os.environ.get('QR_ROLLOUT_STASH', 'auto')} flags={extra}")
+print(f"# {variant} K={K} form={os.environ.get('QR_ROLLOUT_FORM', 'auto')} flags={extra}")
 print("#     envs  waves | kernel_us us/step | loop cyc/step (med, p90) | eff MHz | prologue cyc(us) | tail cyc | waves/SIMD max | first->last wave entry us")
 for n in sizes:
     env = bench.make_env(variant, n, 1, 0, residual=None if os.environ.get("QR_PROBE_NORES") == "1" else "default")

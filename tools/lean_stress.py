@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Full-chip-load agreement of a fused rollout kernel with K x the per-step kernel, elementwise on the device (the check that found the
 lean form's lost reward stores at two workgroups per CU; tests/test_gpu_round4.py runs the cross-process version of it):
-    [QR_PROBE_LIB=<build>] [QR_ROLLOUT_FAST=0] [QR_ROLLOUT_STASH=0] python tools/lean_stress.py [envs] [e2e|indi] [gates_ahead]"""
+    [QR_PROBE_LIB=<build>] [QR_ROLLOUT_FORM=multi_wave|general] python tools/lean_stress.py [envs] [e2e|indi] [gates_ahead]"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from optimal_quad_control_rl_amd import build as B
@@ -20,6 +20,7 @@ def mk():
     else:
         kw = dict(residual=None) if variant == "e2e_nores" else {}
         e = Quadcopter3DGates(n, *square_track(), gates_ahead=ga, seed=5, infos_mode='none', **kw); e.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+    if os.environ.get("QR_ROLLOUT_FORM"): e.set_rollout_form(os.environ["QR_ROLLOUT_FORM"])   # auto | multi_wave | general
     e.reset_device(); return e
 a = torch.rand((K, n, 4), device='cuda', generator=torch.Generator(device='cuda').manual_seed(2)) * 2 - 1
 A = mk(); print(A.rollout_kernel_name())

@@ -58,7 +58,7 @@ for _ in range(8):
 t = np.stack(reps)[2:]
 names = {2: "loop top", 3: "sincos/rot", 4: "mlp", 5: "eom+euler+reward", 6: "reset + small stores", 7: "observe + obs stores"}
 slots = [s for s in range(2, 8) if (t[:, :, s] != 0).any()]
-print(f"{variant} n={n} tag='{tag}' stash={os.environ.get('QR_ROLLOUT_STASH','auto')} fast={os.environ.get('QR_ROLLOUT_FAST','1')}: one step (k = {K // 2}) of the fused loop, cycles (median over waves and launches; un-drained stamps cost ~100-200 cycles each)")
+print(f"{variant} n={n} tag='{tag}' form={os.environ.get('QR_ROLLOUT_FORM','auto')}: one step (k = {K // 2}) of the fused loop, cycles (median over waves and launches; un-drained stamps cost ~100-200 cycles each)")
 for a, b in zip(slots[:-1], slots[1:]):
     d = t[:, :, b] - t[:, :, a]
     print(f"  {a}->{b} {names[b]:24s} {np.median(d):8.0f}   (p10 {np.percentile(d, 10):6.0f}  p90 {np.percentile(d, 90):6.0f})")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What the auto-reset costs the fused rollout kernel (GPU box): us per step at 65 536 envs x 1000 steps for termination rates forced
-through max_steps, and with resets switched off (pause_if_collision).  QR_ROLLOUT_STASH=0 selects the kernel without the per-lane reset
+through max_steps, and with resets switched off (pause_if_collision).  QR_ROLLOUT_FORM=multi_wave selects the kernel without the per-lane reset
 stash.  Usage: python tools/reset_cost_probe.py [envs] [steps]"""
 import sys, time, torch
 sys.path.insert(0, "/root/repo")
@@ -8,6 +8,8 @@ from optimal_quad_control_rl_amd import Quadcopter3DGates, TRAIN_DISTURBANCE_RAN
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 env = Quadcopter3DGates(n, *zigzag_track(), gates_ahead=1, seed=0, infos_mode="none")
+import os
+if os.environ.get("QR_ROLLOUT_FORM"): env.set_rollout_form(os.environ["QR_ROLLOUT_FORM"])
 env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
 g = torch.Generator(device="cuda").manual_seed(0)
 for name, scale, bias, ms, pic in (("uniform(-1,1)", 1.0, 0.0, 1200, False), ("max_steps 20", 1.0, 0.0, 20, False), ("max_steps 5", 1.0, 0.0, 5, False), ("max_steps 2", 1.0, 0.0, 2, False), ("pause_if_collision (no resets)", 1.0, 0.0, 1200, True)):

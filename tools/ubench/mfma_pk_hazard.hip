@@ -173,8 +173,14 @@ static void row(const char* an) {
     fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
     (void)hipMalloc(&g_out, 256 * 256 * 4); (void)hipMalloc(&g_sink, 4);
+    if (argc > 1 && !strcmp(argv[1], "--quick")) {   // tests/test_gpu_round5.py
+        row<0, 1, 7>("f16 32x32x16, s_nop 7 between");
+        row<1, 1, 7>("f16 32x32x16, s_nop 7 between");
+        row<19, 1, 7>("f16 32x32x16, s_nop 7 between");
+        return 0;
+    }
     printf("## victim instruction forms against f16 32x32x16 matrix instructions issued with 8 wait states between them by the SIMD's other wave\n");
 #define X(ID, TXT, NAME) row<ID, 1, 7>("f16 32x32x16, s_nop 7 between");
     VICTIMS(X)
