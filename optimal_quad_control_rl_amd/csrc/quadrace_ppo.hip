@@ -2625,7 +2625,7 @@ int qr_ppo_epoch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_d
                  float max_grad_norm, float lr, float beta1, float beta2, float eps, float* stats_dev, void* stream) {
     if (!p || !theta_dev || !adam_m_dev || !adam_v_dev || !obs_dev || !act_dev || !old_logp_dev || !adv_dev || !ret_dev || !perm_dev)
         return ppofail(QR_E_INVALID, "qr_ppo_epoch: null argument");
-    if (B < 64 || (B % 64 != 0 && !(p->fused && !p->grad4)) || B > p->max_B || num_minibatches < 1 || num_minibatches > qr_ppo::kMaxEpochMinibatches || lr < 0.0f)
+    if (B < 64 || (B % 64 != 0 && !(p->fused && !p->grad4)) || B > p->max_B || num_minibatches < 1 || num_minibatches > qr_ppo::kMaxEpochMinibatches || !(lr >= 0.0f))
         return ppofail(QR_E_INVALID, "qr_ppo_epoch: bad minibatch size / count / learning rate");
     if (num_epochs < 1 || num_epochs > 64 || (num_epochs > 1 && !device_shuffle))
         return ppofail(QR_E_INVALID, "qr_ppo_epoch: num_epochs > 1 needs device_shuffle (the caller cannot rewrite the permutation in between)");

@@ -155,6 +155,8 @@ def test_bench_gpus2_without_a_launcher_spawns_two_ranks():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["rccl"]["rccl_world_size"] == 2 and line["rccl"]["backend"] == "gloo"
     assert len(line["rccl"]["per_rank_ms_per_step"]) == 2
+    # every rank's own diagnosis row (kernel symbol, kernel time per step): a straggler must be visible in the line itself
+    assert len(line["rccl"]["per_rank_kernel"]) == 2 and len(line["rccl"]["per_rank_kernel_us_per_step"]) == 2
     assert line["data"].startswith("cpu-standin")          # a stand-in run can never pass for a measurement
     assert abs(line["value"] - 64 * 2 * 6 / (line["ms_per_step"] * 1e-3 * 6)) < 1e-6 * line["value"]
 
