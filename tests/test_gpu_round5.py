@@ -37,9 +37,9 @@ def OA():
     return OracleAdapter
 
 
-def _pair(PA, OA, variant, n, residual_blob, seed):
-    trk = P.tracks()["square"]
-    kw = dict(gates_ahead=1, residual=residual_blob if variant == E2E else None,
+def _pair(PA, OA, variant, n, residual_blob, seed, track="square", ga=1):
+    trk = P.tracks()[track]
+    kw = dict(gates_ahead=ga, residual=residual_blob if variant == E2E else None,
               dist_ranges=P.TRAIN_DIST_RANGES if variant == E2E else None, seed=seed)
     g, o = PA(variant, n, trk, **kw), OA(variant, n, trk, **kw)
     o.env.set_threads(min(32, os.cpu_count() or 1))
@@ -58,11 +58,12 @@ def _actions(rng, variant, n, k):
     return a
 
 
-@pytest.mark.parametrize("variant,n", [(E2E, 262144), (E2E, 1 << 20), (INDI, 262144), (INDI, 1 << 20)])
-def test_per_step_kernel_against_the_oracle_above_65536_envs(PA, OA, variant, n, residual_blob):
+@pytest.mark.parametrize("variant,n,track,ga", [(E2E, 262144, "square", 1), (E2E, 1 << 20, "square", 1), (INDI, 262144, "square", 1),
+                                                (INDI, 1 << 20, "square", 1), (E2E, 262144, "zigzag", 2), (INDI, 262144, "zigzag", 0)])
+def test_per_step_kernel_against_the_oracle_above_65536_envs(PA, OA, variant, n, track, ga, residual_blob):
     """Teacher-forced lock-step, 8 steps through resets: dones / targets / step counts exact (a differing `done` must sit on a
     termination threshold), freshly reset envs bit-exact, live envs within the one-step tolerance."""
-    g, o, trk = _pair(PA, OA, variant, n, residual_blob, seed=70 + variant)
+    g, o, trk = _pair(PA, OA, variant, n, residual_blob, seed=70 + variant, track=track, ga=ga)
     gate_pos, gate_yaw = np.asarray(trk[0], np.float32), np.asarray(trk[1], np.float32)
     rng = np.random.default_rng(500 + variant)
     tot_done, mismatches, worst_state, worst_obs = 0, 0, 0.0, 0.0
@@ -99,13 +100,15 @@ def test_per_step_kernel_against_the_oracle_above_65536_envs(PA, OA, variant, n,
     assert tot_done >= n and mismatches <= 16, (tot_done, mismatches)
 
 
-@pytest.mark.parametrize("variant,n", [(E2E, 262144), (E2E, 1 << 20), (INDI, 262144), (INDI, 1 << 20)])
-def test_fused_rollout_against_the_oracle_above_65536_envs(PA, OA, variant, n, residual_blob):
+@pytest.mark.parametrize("variant,n,track,ga", [(E2E, 262144, "square", 1), (E2E, 1 << 20, "square", 1), (INDI, 262144, "square", 1),
+                                                (INDI, 1 << 20, "square", 1), (E2E, 524288, "zigzag", 0), (E2E, 262144, "zigzag", 3),
+                                                (INDI, 524288, "zigzag", 2)])
+def test_fused_rollout_against_the_oracle_above_65536_envs(PA, OA, variant, n, track, ga, residual_blob):
     """qr_step_many (the large-N fused forms: two and more workgroups per CU) FREE-RUNNING 8 steps from the oracle's state, through the
     resets the step limit forces in every wave, against the oracle running the same 8 steps: every step's done flags exact except on
     knife edges (such an env is dropped from then on), rewards and observations of all other envs within the free-run tolerance."""
     K = 8
-    g, o, trk = _pair(PA, OA, variant, n, residual_blob, seed=90 + variant)
+    g, o, trk = _pair(PA, OA, variant, n, residual_blob, seed=90 + variant, track=track, ga=ga)
     rng = np.random.default_rng(700 + variant)
     wo, do, to, so = o.get_state()
     g.set_state(wo, do if variant == E2E else None, to, so)
