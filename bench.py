@@ -667,6 +667,7 @@ def headline(result):
                               "per_step_frac": (ops.get("roofline") or {}).get("frac"),
                               "cpu_baseline_value": (o.get("cpu_baseline") or {}).get("value")}
     pu, c5, c5b = result.get("ppo_update") or {}, result.get("config5") or {}, result.get("config5_mb65536") or {}
+    c5r = result.get("config5_ref_ratio") or {}
     if pu or c5:
         h["ppo"] = {"dtype": "f16 matrix-core operands, f32 accumulation / parameters / Adam (precision='f32' = float32 via torch: A/B mode, not timed here)",
                     "update_us_per_16384_rows": pu.get("epoch_us"), "update_useful_TFLOPs": pu.get("epoch_useful_TFLOPs"),
@@ -675,7 +676,8 @@ def headline(result):
                     "stream_launch_us_per_update": pu.get("native_us"), "torch_us": pu.get("torch_us"),
                     "config5_value": c5.get("value"), "config5_us_per_update": c5.get("us_per_update"),
                     "config5_what": _short(c5.get("what"), 150),
-                    "config5_mb65536_value": c5b.get("value"), "config5_mb65536_us_per_update": c5b.get("us_per_update")}
+                    "config5_mb65536_value": c5b.get("value"), "config5_mb65536_us_per_update": c5b.get("us_per_update"),
+                    "config5_16_minibatches_per_epoch_value": c5r.get("value"), "config5_16_minibatches_per_epoch_rows": c5r.get("minibatch")}
     if "parity" in result:
         h["parity"] = {k: result["parity"].get(k) for k in ("max_rel_dstate_100_steps", "tolerance", "error") if k in result["parity"]}
     if result.get("rccl"):
@@ -801,6 +803,9 @@ def run(args, rt, env_factory=make_env, closed_loop=True):
             try:
                 result["config5"] = config5_probe(n)
                 result["config5_mb65536"] = config5_probe(n, mb=65536)
+                # the reference splits a rollout into 20 minibatches per epoch (100 envs x 1000 steps / batch_size 5000, R:785-792);
+                # this build's rollout (a power of two rows) divides into 32 (above) or 16 per epoch: the reference's ratio is bracketed
+                result["config5_ref_ratio"] = config5_probe(n, mb=(n * 32) // 16)
             except Exception as ex:  # pragma: no cover
                 result["config5"] = {"error": repr(ex)}
             try:
