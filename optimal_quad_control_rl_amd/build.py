@@ -89,18 +89,19 @@ def needs_build():
     return any(os.path.getmtime(d) > t for s in SOURCES for d in _deps(s))
 
 
-def build_native(force=False, verbose=False, extra_flags=(), out=None):
-    """out: link an experiment variant (tools/exp_build.sh) somewhere else than LIB -- same pipeline, same rewrite, same lint."""
+def build_native(force=False, verbose=False, extra_flags=(), out=None, drop_flags=()):
+    """out: link an experiment / profiling variant (tools/exp_build.sh, tools/*_probe.py) somewhere else than LIB -- same pipeline, same
+    rewrite, same lint; drop_flags: entries of FLAGS to leave out for that variant."""
     if out is None and not force and not needs_build():
         return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
     from concurrent.futures import ThreadPoolExecutor
     from . import isa_lint
-    compile_flags = [f for f in FLAGS if f != "-shared"]
+    compile_flags = [f for f in FLAGS if f != "-shared" and f not in drop_flags]
     objs, jobs = [], []
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:   # sources compile concurrently
         for src in SOURCES:
-            obj = _obj(src, extra_flags)
+            obj = _obj(src, tuple(extra_flags) + tuple("no" + f for f in drop_flags))
             objs.append(obj)
             if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src)):
                 flags = [f for f in compile_flags if not (src in NO_VGPR_FORM and f in ("-mllvm", "-amdgpu-mfma-vgpr-form"))]

@@ -139,33 +139,36 @@ def test_fused_rollout_against_the_oracle_above_65536_envs(PA, OA, variant, n, t
     assert worst_obs < P.TOL_FREE_RUN and worst_state < P.TOL_FREE_RUN and worst_rew < 5 * P.TOL_STEP_REWARD, (worst_obs, worst_state, worst_rew)
 
 
-def _mk(variant, n, seed, residual_blob):
+def _mk(variant, n, seed, residual_blob, form="auto"):
     from optimal_quad_control_rl_amd import Quadcopter3DGates, Quadcopter3DGatesINDI, TRAIN_DISTURBANCE_RANGES, square_track
     if variant == E2E:
         e = Quadcopter3DGates(n, *square_track(), gates_ahead=1, seed=seed, infos_mode="none")
         e.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
     else:
         e = Quadcopter3DGatesINDI(n, *square_track(), gates_ahead=1, seed=seed, infos_mode="none")
+    e.set_rollout_form(form)
     e.reset_device()
     return e
 
 
-@pytest.mark.parametrize("va,vb", [(E2E, E2E), (E2E, INDI)])
-def test_two_handles_on_two_streams_match_their_serial_runs(va, vb, residual_blob):
-    """Two 65 536-env handles driven from two streams share every SIMD of the chip (each launch alone is one workgroup per CU).  The
-    reference keeps a training and a test env alive together (R:765-766); results must not depend on what else is resident."""
+@pytest.mark.parametrize("va,vb,form", [(E2E, E2E, "auto"), (E2E, INDI, "auto"), (E2E, E2E, "multi_wave"), (E2E, INDI, "multi_wave")])
+def test_two_handles_on_two_streams_match_their_serial_runs(va, vb, form, residual_blob):
+    """Two 65 536-env handles driven from two streams share the chip (each launch alone is one workgroup per CU).  The reference keeps a
+    training and a test env alive together (R:765-766); results must not depend on what else is resident.  "multi_wave" forces the
+    255-register kernel forms, of which TWO waves fit a SIMD: waves of different launches then really share SIMDs -- the configuration
+    in which the unfixed round-4 build corrupts a handle's results (profiles/r05_cross_kernel.txt)."""
     n, K, reps = 65536, 300, 4
     dev = torch.device("cuda")
     acts = torch.rand((K, n, 4), device=dev, generator=torch.Generator(device=dev).manual_seed(3)) * 2 - 1
     ref = []
     for v, seed in ((va, 11), (vb, 12)):
-        e = _mk(v, n, seed, residual_blob)
+        e = _mk(v, n, seed, residual_blob, form)
         ref.append([t.clone() for t in e.rollout_device(acts)])
         e.close()
     torch.cuda.synchronize()
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     for rep in range(reps):
-        ea, eb = _mk(va, n, 11, residual_blob), _mk(vb, n, 12, residual_blob)
+        ea, eb = _mk(va, n, 11, residual_blob, form), _mk(vb, n, 12, residual_blob, form)
         torch.cuda.synchronize()
         with torch.cuda.stream(s1):
             ra = ea.rollout_device(acts)

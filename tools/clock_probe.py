@@ -25,18 +25,9 @@ os.makedirs(os.path.dirname(dbg), exist_ok=True)
 CSRC = os.environ.get("QR_PROBE_CSRC", B.CSRC)   # A/B against another checkout of the sources (same box, same call)
 deps = [os.path.join(CSRC, h) for h in B.HEADERS]
 flags = ["-DQR_CLOCK_PROBE", *extra]
-os.makedirs(B.OBJ_DIR, exist_ok=True)
-objs, procs = [], []
-for src in ([] if (os.environ.get("QR_PROBE_NOBUILD") == "1" and os.path.exists(dbg)) else B.SOURCES):   # per-source objects, compiled concurrently, only the stale ones (an edit of one .hip costs one compile)
-    obj = B._obj(src, ["-DQR_CLOCK_PROBE" + tag, *extra])
-    objs.append(obj)
-    path = os.path.join(CSRC, src)
-    if not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in [path] + deps):
-        procs.append(subprocess.Popen([B._hipcc(), *[f for f in B.FLAGS if f != "-shared"], *flags, "-c", path, "-o", obj]))
-for pr in procs:
-    assert pr.wait() == 0
-if procs or (objs and not os.path.exists(dbg)):
-    subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", dbg, *objs])
+if not (os.environ.get("QR_PROBE_NOBUILD") == "1" and os.path.exists(dbg)):   # the product's own pipeline (assembly rewrite + lint), stale objects only
+    B.CSRC = CSRC
+    B.build_native(extra_flags=tuple(flags), out=dbg)
 if "--build" in sys.argv:
     sys.exit(0)
 B.LIB = dbg

@@ -21,14 +21,8 @@ dbg = os.path.join(B.PKG, "_dbg", "libquadrace_ph%s.so" % tag)
 os.makedirs(os.path.dirname(dbg), exist_ok=True)
 if not (os.environ.get("QR_PROBE_NOBUILD") == "1" and os.path.exists(dbg)):
     flags = ["-DQR_PHASE_TIMING", "-DQR_PHASE_TIMING_NODRAIN", "-DQR_GA_ONLY=1"]
-    objs, procs = [], []
-    for src in B.SOURCES:
-        obj = B._obj(src, ["-DQR_PH" + tag])
-        objs.append(obj)
-        procs.append(subprocess.Popen([B._hipcc(), *[f for f in B.FLAGS if f != "-shared"], *flags, "-c", os.path.join(CSRC, src), "-o", obj]))
-    for pr in procs:
-        assert pr.wait() == 0
-    subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", dbg, *objs])
+    B.CSRC = CSRC
+    B.build_native(extra_flags=tuple(flags), out=dbg)   # the product's own pipeline (assembly rewrite + lint)
 if "--build" in sys.argv:
     sys.exit(0)
 B.LIB = dbg

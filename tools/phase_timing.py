@@ -19,7 +19,7 @@ variant = sys.argv[1] if len(sys.argv) > 1 else "e2e"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 dbg = os.path.join(ROOT, "gpurun_out", "libquadrace_dbg.so")
 os.makedirs(os.path.dirname(dbg), exist_ok=True)
-subprocess.check_call([B._hipcc(), *B.FLAGS, "-DQR_PHASE_TIMING", "-o", dbg] + [os.path.join(B.CSRC, s) for s in B.SOURCES])
+B.build_native(extra_flags=("-DQR_PHASE_TIMING",), out=dbg)   # the product's own pipeline (assembly rewrite + lint)
 B.LIB = dbg  # make the adapter load the instrumented build
 B.needs_build = lambda: False
 from optimal_quad_control_rl_amd import _lib  # noqa: E402

@@ -12,8 +12,7 @@ dbg = os.path.join(ROOT, "optimal_quad_control_rl_amd", "_dbg", "libquadrace_dbg
 os.makedirs(os.path.dirname(dbg), exist_ok=True)
 srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES]
 if "--build-only" in sys.argv or not os.path.exists(dbg) or os.path.getmtime(dbg) < max(os.path.getmtime(f) for f in srcs):
-    flags = [f for f in B.FLAGS if f not in ("-mllvm", "-amdgpu-mfma-vgpr-form")]
-    subprocess.check_call([B._hipcc(), *flags, "-DQR_PHASE_TIMING", *(["-DQR_PHASE_TIMING_NODRAIN"] if nodrain else []), *extra, "-o", dbg] + srcs)
+    B.build_native(extra_flags=("-DQR_PHASE_TIMING", *(["-DQR_PHASE_TIMING_NODRAIN"] if nodrain else []), *extra), out=dbg, drop_flags=("-mllvm", "-amdgpu-mfma-vgpr-form"))
 if "--build-only" in sys.argv:
     sys.exit(0)
 B.LIB = dbg
