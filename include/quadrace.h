@@ -172,8 +172,9 @@ int qr_set_timing(qr_env* env, int32_t on);
 const char* qr_rollout_kernel_name(const qr_env* env);
 /* Which family of fused kernels qr_step_many may pick from (all produce bit-identical results; this is a testing / A-B hook, there is
  * no environment variable): AUTO = by env count and mode; flags MULTI_WAVE = the forms built for more than
- * one workgroup per CU, at any env count; GENERAL = the general kernels (every mode) for every launch; the two may be or-ed. */
-enum { QR_ROLLOUT_AUTO = 0, QR_ROLLOUT_MULTI_WAVE = 1, QR_ROLLOUT_GENERAL = 2 };
+ * one workgroup per CU, at any env count; GENERAL = the general kernels (every mode) for every launch (the two may be or-ed); ONE_WAVE = the forms built for one
+ * workgroup per CU at any env count (slower there: profiles/r05_one_wave_ab.txt). */
+enum { QR_ROLLOUT_AUTO = 0, QR_ROLLOUT_MULTI_WAVE = 1, QR_ROLLOUT_GENERAL = 2, QR_ROLLOUT_ONE_WAVE = 4 /* the one-wave-per-SIMD forms at any env count */ };
 int qr_set_rollout_form(qr_env* env, int32_t form);
 int qr_profile_steps(qr_env* env, int32_t num_steps, const float* actions_dev, float* obs_out_dev,
                      float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream,

@@ -585,7 +585,7 @@ const char* qr_rollout_kernel_name(const qr_env* e) {
 
 int qr_set_rollout_form(qr_env* e, int32_t form) {
     if (!e) return fail(QR_E_INVALID, "qr_set_rollout_form: null env");
-    if (form < 0 || form > (QR_ROLLOUT_MULTI_WAVE | QR_ROLLOUT_GENERAL)) return fail(QR_E_INVALID, "qr_set_rollout_form: unknown form");
+    if (form < 0 || form > (QR_ROLLOUT_MULTI_WAVE | QR_ROLLOUT_GENERAL | QR_ROLLOUT_ONE_WAVE)) return fail(QR_E_INVALID, "qr_set_rollout_form: unknown form");
     e->rollout_form = form;
     return QR_OK;
 }

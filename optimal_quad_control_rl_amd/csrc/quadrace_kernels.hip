@@ -952,7 +952,7 @@ enum RolloutKernel { kRkFastMlp, kRkFast, kRkStash, kRkLeanMlp, kRkLean, kRkPlai
 static RolloutKernel select_rollout(int variant, const Params& P, int form) {
     const bool plain_mode = !(P.flags & (kFlagPause | kFlagPauseIfCollision)) && P.term_obs == nullptr && !(form & 2);
     const bool mlp = variant == kE2E && (P.flags & kFlagResidual);
-    if (n_wgs(P.n) <= device_cus() && !(form & 1)) {   // one wave per SIMD: the register file of a whole SIMD per wave (reset stash, operands in registers)
+    if ((form & 4) || (n_wgs(P.n) <= device_cus() && !(form & 1))) {   // one wave per SIMD: the register file of a whole SIMD per wave (reset stash, operands in registers)
         if (plain_mode && mlp) return kRkFastMlp;
         if (plain_mode && variant == kE2E) return kRkFast;
         return kRkStash;

@@ -566,11 +566,11 @@ class Quadcopter3DGates(_Base):
             self._last_obs = obs
         return obs, rew, done, trunc
 
-    ROLLOUT_FORMS = {"auto": 0, "multi_wave": 1, "general": 2, "general_multi_wave": 3}
+    ROLLOUT_FORMS = {"auto": 0, "multi_wave": 1, "general": 2, "general_multi_wave": 3, "one_wave": 4}
 
     def set_rollout_form(self, form):
         """Which family of fused kernels `rollout_device` may use: "auto" (by env count and mode), "multi_wave" (the forms built for more
-        than one workgroup per CU, at any env count), "general" (the general kernels for every launch), "general_multi_wave" (both).  All bit-identical: a test / A-B hook."""
+        than one workgroup per CU, at any env count), "general" (the general kernels for every launch), "general_multi_wave" (both), "one_wave" (the one-wave forms at any env count).  All bit-identical: a test / A-B hook."""
         _lib.check(self._L.qr_set_rollout_form(self._h, self.ROLLOUT_FORMS[form]))
         return self
 
