@@ -221,6 +221,14 @@ int qr_rollout_policy(qr_env* env, qr_policy* policy, int32_t num_steps, const f
  * the reference's batch_size is 5000, R:792; the QR_PPO_SPLIT / QR_PPO_GRAD4 forms need B % 64 == 0). */
 typedef struct qr_ppo qr_ppo;
 int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo** out);
+/* The same with explicit choices of the kernel forms (verification / A-B; qr_ppo_create = flags 0 = the measured-fastest forms; the
+ * library reads no environment variable): PARTIAL_F32 keeps the per-workgroup gradient partials in f32 instead of bf16 (twice the
+ * bytes through the fabric; the form the kernels are verified in to f32 summation noise); FORM_SPLIT / FORM_GRAD4 select the earlier
+ * forms of the gradient kernel (three launches through an HBM scratch buffer / the 4-wave fused kernel; minibatches must then be
+ * multiples of 64 rows) -- independent implementations the default kernel is tested against; NO_EPOCH_GRAPH makes qr_ppo_epoch
+ * enqueue plain launches instead of replaying a captured graph. */
+enum { QR_PPO_PARTIAL_F32 = 1, QR_PPO_FORM_SPLIT = 2, QR_PPO_FORM_GRAD4 = 4, QR_PPO_NO_EPOCH_GRAPH = 8 };
+int qr_ppo_create_ex(int32_t obs_len, int32_t device, int32_t max_minibatch, int32_t flags, qr_ppo** out);
 int qr_ppo_destroy(qr_ppo* ppo);
 int qr_ppo_num_params(const qr_ppo* ppo);
 /* builds the f16 operand images from the parameters: call once before the first qr_ppo_minibatch and after any
@@ -240,11 +248,8 @@ int qr_ppo_grad(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const
  * Two launches:
  * ONE gradient kernel (forward, loss, backward and the weight gradients of 128 samples per workgroup and pass; per-workgroup
  * partial sums, rounded to bf16 when they leave the workgroup) and ONE kernel that sums the partials in f32 in a fixed order, takes
- * the global norm across a grid-wide barrier, clips, applies Adam and re-packs the f16 operand images.  Environment, read at
- * qr_ppo_create: QR_PPO_PARTIAL=f32 keeps the partials in f32 (twice the bytes through the fabric; the form the kernels are
- * verified in to f32 summation noise); QR_PPO_SPLIT=1 / QR_PPO_GRAD4=1 select the earlier forms of the gradient kernel (three
- * launches with the operands passed through an HBM scratch buffer / the 4-wave fused kernel); QR_PPO_EPOCH_GRAPH=0 makes
- * qr_ppo_epoch enqueue plain launches instead of replaying a captured graph.  A non-finite gradient norm makes
+ * the global norm across a grid-wide barrier, clips, applies Adam and re-packs the f16 operand images.  (Other forms of the kernels: qr_ppo_create_ex.)
+ *  A non-finite gradient norm makes
  * the whole update a no-op (counted, see qr_ppo_status).  stats_dev (may be NULL) float[4] is accumulated into. */
 int qr_ppo_minibatch(qr_ppo* ppo, float* theta_dev, float* adam_m_dev, float* adam_v_dev, const float* obs_dev,
                      const float* act_dev, const float* old_logp_dev, const float* adv_dev, const float* ret_dev,

@@ -61,6 +61,7 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp]),
     "qr_profile_steps": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _f32p, _f32p]),
     "qr_ppo_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "qr_ppo_create_ex": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "qr_ppo_destroy": (C.c_int, [_vp]),
     "qr_ppo_num_params": (C.c_int, [_vp]),
     "qr_ppo_pack": (C.c_int, [_vp, _vp, _vp]),
@@ -92,7 +93,7 @@ SIGNATURES = {
 }
 
 
-ADDED_IN_ROUND_5 = ("qr_set_rollout_form",)
+ADDED_IN_ROUND_5 = ("qr_set_rollout_form", "qr_ppo_create_ex")
 
 
 class QuadraceError(RuntimeError):

@@ -2160,10 +2160,10 @@ struct qr_ppo {
     int L = 0, device = 0, max_B = 0, num_params = 0;
     int image_half8 = 0, slots = 0, raw_slots = 0, max_chunks = 32;  // chunks = split of the minibatch's sample groups in phase B
     static constexpr int kFusedChunks = 128;          // workgroups (= partials) per network of the fused gradient kernel
-    bool fused = true;                                // QR_PPO_SPLIT=1: the two-kernel form (phase A + phase B through scratch)
-    bool grad4 = false;                               // QR_PPO_GRAD4=1: fused gradient kernel in its 4-wave form (round 2)
-    bool partial_bf16 = true;                         // QR_PPO_PARTIAL=f32: the role-split kernel's partials as f32 (twice the bytes)
-    bool epoch_graph = true;                          // QR_PPO_EPOCH_GRAPH=0: qr_ppo_epoch enqueues its launches on the stream
+    bool fused = true;                                // QR_PPO_FORM_SPLIT: the two-kernel form (phase A + phase B through scratch)
+    bool grad4 = false;                               // QR_PPO_FORM_GRAD4: fused gradient kernel in its 4-wave form (round 2)
+    bool partial_bf16 = true;                         // QR_PPO_PARTIAL_F32: the role-split kernel's partials as f32 (twice the bytes)
+    bool epoch_graph = true;                          // QR_PPO_NO_EPOCH_GRAPH: qr_ppo_epoch enqueues its launches on the stream
     qr::half8* d_images = nullptr;
     qr::half8* d_tbuf = nullptr;
     float* d_partial = nullptr;  // [max_chunks][num_params] phase-B outputs
@@ -2374,7 +2374,13 @@ void adam_constants(qr::ApplyArgs& a, float max_grad_norm, float lr, bool device
 extern "C" {
 
 int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo** out) {
+    return qr_ppo_create_ex(obs_len, device, max_minibatch, 0, out);
+}
+
+int qr_ppo_create_ex(int32_t obs_len, int32_t device, int32_t max_minibatch, int32_t flags, qr_ppo** out) {
     if (!out) return ppofail(QR_E_INVALID, "qr_ppo_create: null output");
+    if (flags < 0 || flags > (QR_PPO_PARTIAL_F32 | QR_PPO_FORM_SPLIT | QR_PPO_FORM_GRAD4 | QR_PPO_NO_EPOCH_GRAPH))
+        return ppofail(QR_E_INVALID, "qr_ppo_create_ex: unknown flag");
     *out = nullptr;
     if (max_minibatch < 64 || max_minibatch % 64 != 0) return ppofail(QR_E_INVALID, "qr_ppo_create: max_minibatch must be a multiple of 64");
     int ndev = 0;
@@ -2394,16 +2400,11 @@ int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo
     });
     if (rc != QR_OK) { delete p; return rc; }
     p->num_params = qr::ppo_num_params(obs_len);
-    {
-        const char* split = getenv("QR_PPO_SPLIT");
-        p->fused = !(split && split[0] == '1');
-        const char* g4 = getenv("QR_PPO_GRAD4");
-        p->grad4 = g4 && g4[0] == '1';
-        const char* pf = getenv("QR_PPO_PARTIAL");
-        p->partial_bf16 = !(pf && pf[0] == 'f');
-        const char* eg = getenv("QR_PPO_EPOCH_GRAPH");
-        p->epoch_graph = !(eg && eg[0] == '0');
-    }
+    // which forms of the kernels this handle uses: explicit flags (the library reads no environment variable)
+    p->fused = !(flags & QR_PPO_FORM_SPLIT);
+    p->grad4 = (flags & QR_PPO_FORM_GRAD4) != 0;
+    p->partial_bf16 = !(flags & QR_PPO_PARTIAL_F32);
+    p->epoch_graph = !(flags & QR_PPO_NO_EPOCH_GRAPH);
     PPO_HIP(hipSetDevice(device));
     const size_t tbytes = (size_t)2 * p->slots * (max_minibatch / 64) * 256 * 16;
     const size_t mbbytes = (size_t)(qr_ppo::kMaxEpochMinibatches + 1) * 2 * sizeof(double);

@@ -84,8 +84,9 @@ class MfmaPpoUpdater:
     net_arch (120, 120, 120).  The module's parameters are re-pointed at views of ONE flat float32 vector (the layout
     the C ABI defines), so torch code that evaluates the networks keeps seeing the current weights."""
 
-    def __init__(self, policy, obs_len, device, max_minibatch, betas=(0.9, 0.999), eps=1e-5):
+    def __init__(self, policy, obs_len, device, max_minibatch, betas=(0.9, 0.999), eps=1e-5, flags=None):
         import ctypes as C
+        import os
 
         from . import _lib
 
@@ -95,7 +96,13 @@ class MfmaPpoUpdater:
         self.device = device
         h = C.c_void_p()
         # (capacity in whole groups of 64 rows; a minibatch itself may be any size >= 64: the kernel masks a partial last group)
-        _lib.check(self._L.qr_ppo_create(int(obs_len), int(device.index or 0), (int(max_minibatch) + 63) // 64 * 64, C.byref(h)))
+        # kernel forms: `flags` (QR_PPO_* of include/quadrace.h), or -- for the test suite and A/B tools only -- the environment
+        # variables of rounds 2-4, translated HERE (the library itself reads none)
+        if flags is None:
+            env = os.environ
+            flags = ((1 if env.get("QR_PPO_PARTIAL", "")[:1] == "f" else 0) | (2 if env.get("QR_PPO_SPLIT") == "1" else 0) |
+                     (4 if env.get("QR_PPO_GRAD4") == "1" else 0) | (8 if env.get("QR_PPO_EPOCH_GRAPH") == "0" else 0))
+        _lib.check(self._L.qr_ppo_create_ex(int(obs_len), int(device.index or 0), (int(max_minibatch) + 63) // 64 * 64, int(flags), C.byref(h)))
         self._h = h
         n = self._L.qr_ppo_num_params(self._h)
         self.theta = torch.zeros(n, dtype=torch.float32, device=device)

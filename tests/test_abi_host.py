@@ -136,3 +136,16 @@ def test_kernel_sincos_algorithm_accuracy():
     for const in ("0.6366197723675814f", "1.5707963705062866f", "-4.371139000186241e-8f", "-1.7151245100059e-15f",
                   "2.7183114939898219e-6f", "-0.49999999725103100f"):
         assert const in src
+
+
+def test_library_reads_no_environment_variable():
+    """Kernel forms are chosen through the ABI (qr_set_rollout_form, qr_ppo_create_ex), never through getenv: the library does not
+    even import the symbol."""
+    import subprocess
+
+    from optimal_quad_control_rl_amd import build
+
+    lib = build.build_native_locked()
+    und = subprocess.run(["nm", "-D", "--undefined-only", lib], check=True, capture_output=True, text=True).stdout
+    assert "getenv" not in und
+
