@@ -118,7 +118,7 @@ def build_native(force=False, verbose=False, extra_flags=(), out=None, drop_flag
     bad = isa_lint.lint_library(tmp)   # the final code objects, by disassembly: whatever the compiler and the rewrite did
     if bad:
         os.unlink(tmp)
-        raise RuntimeError("libquadrace.so would contain %d packed-f32 instruction(s) of the hazardous form (isa_lint.py): %s ..." % (len(bad), bad[:3]))
+        raise RuntimeError("libquadrace.so would contain %d hazardous instruction(s) (isa_lint.py: packed-f32 form / store-data overwrite): %s ..." % (len(bad), bad[:3]))
     os.replace(tmp, target)
     return target
 

@@ -310,6 +310,7 @@ struct PpoBatch {
 };
 
 #ifdef QR_PHASE_TIMING
+#define QR_TICK_GATE true   /* ppo_grad_kernel: -DQR_TICK_PASS=p stamps pass p only (a later pass overwrites an earlier one's stamps) */
 #ifdef QR_PHASE_TIMING_NODRAIN   /* stamps without draining the queues: where the waves ARE, not what a stage costs in isolation */
 #define PPO_TICK_DRAIN() asm volatile("" ::: "memory")
 #else
@@ -318,7 +319,7 @@ struct PpoBatch {
 #define PPO_TICK(a, slot)                                                                                       \
     do {                                                                                                        \
         PPO_TICK_DRAIN();                                                                                       \
-        if ((a).ticks && (threadIdx.x & 63) == 0)                                                               \
+        if ((a).ticks && (threadIdx.x & 63) == 0 && QR_TICK_GATE)                                               \
             (a).ticks[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6)) * 16 + (slot)] = clock64(); \
     } while (0)
 // constant-rate (100 MHz) device-wide clock: workgroup start / end skew across the grid, and the apply kernel's stages
@@ -358,7 +359,7 @@ __device__ __forceinline__ half8 mask_pack(const f32x16p& acc, uint32_t word, in
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         const uint32_t on = (word >> (8 * (t & 1) + 4 * s + d)) & 0x00010001u;
-        p[d] &= on * 0xFFFFu;  // 0x0001 -> 0xFFFF in each half (no carry between the halves)
+        asm("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(p[d]) : "v"(on));   // bits x {0, 1} per half (see epilogue_dword)
     }
     return __builtin_bit_cast(half8, p);
 }
@@ -374,10 +375,13 @@ __device__ __forceinline__ uint32_t epilogue_dword(const f32x16p (&acc)[2], int 
     const int shift = 8 * ti + 4 * sh + dd;
     if (!BWD) {
         const uint32_t r = relu_pack2(acc[ti][8 * sh + 2 * dd], acc[ti][8 * sh + 2 * dd + 1]);
-        const ushort2p one = {1, 1};
-        // relu output >= 0: its f16 bit pattern is non-zero iff the unit is active; min(bits, 1) per half -> 0 / 1
-        const uint32_t on = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2p, r), one));
-        word |= on << shift;
+        // relu output >= 0: its f16 bit pattern is non-zero iff the unit is active; min(bits, 1) per half -> 0 / 1.  ONE packed
+        // instruction, written out: the compiler expanded the vector min into two 16-bit compares, two selects and a v_perm per dword
+        // (6 issue slots where the forward pass of a lone wave is issue-bound: 9 VALU per dword against 2 MFMAs per 2 dwords)
+        // (the OR into `word` sits in the same asm: left to the compiler the 32 ORs of a layer were re-associated into a tree at the
+        // END of the layer and the 32 intermediate values spilled)
+        uint32_t on;
+        asm("v_pk_min_u16 %1, %2, %3\n\tv_lshl_or_b32 %0, %1, %4, %0" : "+v"(word), "=&v"(on) : "v"(r), "s"(0x00010001u), "n"(shift));
         return r;
     }
     typedef _Float16 half2p __attribute__((ext_vector_type(2)));
@@ -385,7 +389,34 @@ __device__ __forceinline__ uint32_t epilogue_dword(const f32x16p (&acc)[2], int 
     uint32_t r = __builtin_bit_cast(uint32_t, c);
     asm("v_pk_max_f16 %0, %0, %1\n\tv_pk_min_f16 %0, %0, %2" : "+v"(r) : "v"(0xFBFFFBFFu), "v"(0x7BFF7BFFu));  // +-65504
     const uint32_t on = (word >> shift) & 0x00010001u;
-    return r & (on * 0xFFFFu);  // 0x0001 -> 0xFFFF in each half (no carry between the halves)
+    uint32_t out;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(out) : "v"(r), "v"(on));   // bits x {0, 1} per half: the value or zero, one instruction
+    return out;
+}
+
+// Backward epilogue dword with the ReLU derivative taken from the FORWARD ACTIVATION itself (`hdw` = the same dword of h, two f16 >= 0:
+// active iff its bits are non-zero -- the criterion the mask bits record): saturation + pack, zero where the unit was inactive.
+__device__ __forceinline__ uint32_t epilogue_dword_h(const f32x16p (&acc)[2], int d, uint32_t hdw) {
+    const int ti = d >> 3, sh = (d >> 2) & 1, dd = d & 3;
+    typedef _Float16 half2p __attribute__((ext_vector_type(2)));
+    const half2p c = {(_Float16)acc[ti][8 * sh + 2 * dd], (_Float16)acc[ti][8 * sh + 2 * dd + 1]};
+    uint32_t r = __builtin_bit_cast(uint32_t, c);
+    asm("v_pk_max_f16 %0, %0, %1\n\tv_pk_min_f16 %0, %0, %2" : "+v"(r) : "v"(0xFBFFFBFFu), "v"(0x7BFF7BFFu));  // +-65504
+    uint32_t on, out;
+    asm("v_pk_min_u16 %1, %2, %3\n\tv_pk_mul_lo_u16 %0, %4, %1" : "=v"(out), "=&v"(on) : "v"(hdw), "s"(0x00010001u), "v"(r));
+    return out;
+}
+__device__ __forceinline__ half8 mask_pack_h(const f32x16p& acc, int s, const u32x4p& hpack) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = acc[8 * s + j];
+    u32x4p p = __builtin_bit_cast(u32x4p, sat_pack(v));
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t on;
+        asm("v_pk_min_u16 %1, %2, %3\n\tv_pk_mul_lo_u16 %0, %0, %1" : "+v"(p[d]), "=&v"(on) : "v"(hpack[d]), "s"(0x00010001u));
+    }
+    return __builtin_bit_cast(half8, p);
 }
 
 // ---- W^T operands out of the forward image: ds_read_b64_tr_b16 (gfx950) ------------------------------------------------------
@@ -446,9 +477,13 @@ __device__ __forceinline__ void lds_tr_wait(half8& a0, half8& a1) {
 // side by side, epilogue of the previous pair in the shadow of the MFMAs), operand ring 3 deep = 12 reads in flight.
 // Two lane-address registers (first / second read of an operand pair): for the plain image they differ by 128 bytes, for the
 // swizzled one (ppo_grad_kernel) by the swizzle too -- see tr_lane_hidden().
-template <int kFwdOff>
+// kHMask (ppo_grad_kernel, round 5): the ReLU derivative comes from the layer's forward activations, which the wave has just published
+// to the exchange area as its own natural packs (hm_e / hm_o = this wave's and lane's pack 0, for even / odd pack index: the
+// chunk swizzle of packs_to_lds) -- read back two pairs of output tiles ahead; `mask` is then unused and the forward pass builds no
+// mask words (2 issue slots per dword less where a lone wave is issue-bound, 1 less here).
+template <int kFwdOff, bool kHMask = false>
 __device__ __forceinline__ void mlp_layer_bwd(unsigned tr_lane_addr0, unsigned tr_lane_addr1, const half8 (&in)[8], half8 (&out)[8],
-                                              const uint32_t (&mask)[2]) {
+                                              const uint32_t (&mask)[2], const u32x4p* hm_e = nullptr, const u32x4p* hm_o = nullptr) {
     const unsigned tr_addr0 = tr_lane_addr0 + 16u * (unsigned)kFwdOff;   // start of this layer's image (the immediates are 16-bit)
     const unsigned tr_addr1 = tr_lane_addr1 + 16u * (unsigned)kFwdOff;
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -464,6 +499,11 @@ __device__ __forceinline__ void mlp_layer_bwd(unsigned tr_lane_addr0, unsigned t
         a0[SLOT] = lds_tr_pair2<c0_>(tr_addr0, tr_addr1);                                                                  \
         a1[SLOT] = lds_tr_pair2<c0_ + 16 * 128>(tr_addr0, tr_addr1);                                                       \
     } while (0)
+    u32x4p hmv[4];   // pack j of the pair whose epilogue runs (steps 2 j, 2 j + 1); re-loaded in place for the second pair
+    if constexpr (kHMask) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hmv[j] = ((j & 1) ? hm_o : hm_e)[j * 64];          // packs 0..3: output tiles 0, 1
+    }
     QR_TR_FETCH(0, 0); QR_TR_FETCH(1, 1); QR_TR_FETCH(2, 2);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -489,8 +529,13 @@ __device__ __forceinline__ void mlp_layer_bwd(unsigned tr_lane_addr0, unsigned t
             if (tp > 0) {
                 const int p = tp - 1;
 #pragma unroll
-                for (int d = (16 * s) / KS; d < (16 * (s + 1)) / KS; ++d)
-                    o32[4 * p + (d >> 2)][d & 3] = epilogue_dword<true>(acc[p], d, word[p]);   // out[2 (2p + ti) + sh]
+                for (int d = (16 * s) / KS; d < (16 * (s + 1)) / KS; ++d) {
+                    if constexpr (kHMask) o32[4 * p + (d >> 2)][d & 3] = epilogue_dword_h(acc[p], d, hmv[d >> 2][d & 3]);
+                    else o32[4 * p + (d >> 2)][d & 3] = epilogue_dword<true>(acc[p], d, word[p]);   // out[2 (2p + ti) + sh]
+                }
+                if constexpr (kHMask) {   // pack s / 2 of the first pair is used up: the second pair's takes its registers (8 steps ahead)
+                    if (tp == 1 && (s & 1)) hmv[s >> 1] = (((s >> 1) & 1) ? hm_o : hm_e)[(4 + (s >> 1)) * 64];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -511,7 +556,7 @@ __device__ __forceinline__ void mlp_layer_bwd(unsigned tr_lane_addr0, unsigned t
 //     1/KS of the epilogue of the PREVIOUS pair (its accumulators finished a pair ago: no hazard wait)
 // kSwz: the image in LDS is chunk-swizzled (ppo_grad_kernel: bits 2-3 of the 16-byte chunk index XORed with bits 5-6, so that the
 // backward pass's transposed reads are bank-conflict free); chunk row r = tile * KS + s then sits at lane ^ ((h | (r & 1) << 1) << 2).
-template <int KS, bool BWD, bool kSwz = false>
+template <int KS, bool BWD, bool kSwz = false, bool kNoMask = false>
 __device__ __forceinline__ void mlp_layer(const half8* __restrict__ W, int lane, const half8 (&in)[KS], half8 (&out)[8],
                                           uint32_t (&mask)[2]) {
     const int lane_e = kSwz ? lane ^ ((lane >> 5) << 2) : lane;           // chunk rows (tile * KS + s) of even / odd parity
@@ -544,8 +589,14 @@ __device__ __forceinline__ void mlp_layer(const half8* __restrict__ W, int lane,
             if (tp > 0) {
                 const int p = tp - 1;
 #pragma unroll
-                for (int d = (16 * s) / KS; d < (16 * (s + 1)) / KS; ++d)
-                    o32[4 * p + (d >> 2)][d & 3] = epilogue_dword<BWD>(acc[p], d, word[p]);   // out[2 (2p + ti) + sh]
+                for (int d = (16 * s) / KS; d < (16 * (s + 1)) / KS; ++d) {
+                    if constexpr (!BWD && kNoMask) {   // relu + saturation + pack only (the backward pass reads the activation back)
+                        const int ti = d >> 3, sh = (d >> 2) & 1, dd = d & 3;
+                        o32[4 * p + (d >> 2)][d & 3] = relu_pack2(acc[p][ti][8 * sh + 2 * dd], acc[p][ti][8 * sh + 2 * dd + 1]);
+                    } else {
+                        o32[4 * p + (d >> 2)][d & 3] = epilogue_dword<BWD>(acc[p], d, word[p]);   // out[2 (2p + ti) + sh]
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -884,10 +935,10 @@ __device__ __forceinline__ void dw_block_tr(unsigned base_d0, unsigned base_d1, 
         b0[SLOT] = lds_tr_pair2<QR_EX_OFF(1, (KQ) >> 1, 0, (KQ) & 1)>(base_h0, base_h1);            \
         b1[SLOT] = lds_tr_pair2<QR_EX_OFF(1, (KQ) >> 1, 1, (KQ) & 1)>(base_h0, base_h1);            \
     } while (0)
-#define QR_EX_STEP(KQ)                                                                                            \
+#define QR_EX_STEP(KQ, LATER)                                                                                     \
     do {                                                                                                          \
-        if ((KQ) < 7) { lds_tr_wait<4>(a0[(KQ) & 1], a1[(KQ) & 1]); lds_tr_wait<4>(b0[(KQ) & 1], b1[(KQ) & 1]); } \
-        else { lds_tr_wait<0>(a0[(KQ) & 1], a1[(KQ) & 1]); lds_tr_wait<0>(b0[(KQ) & 1], b1[(KQ) & 1]); }          \
+        lds_tr_wait<LATER>(a0[(KQ) & 1], a1[(KQ) & 1]);                                                           \
+        lds_tr_wait<LATER>(b0[(KQ) & 1], b1[(KQ) & 1]);                                                           \
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[(KQ) & 1], b0[(KQ) & 1], acc[0][0], 0, 0, 0);       \
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[(KQ) & 1], b1[(KQ) & 1], acc[0][1], 0, 0, 0);       \
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[(KQ) & 1], b0[(KQ) & 1], acc[1][0], 0, 0, 0);       \
@@ -895,14 +946,14 @@ __device__ __forceinline__ void dw_block_tr(unsigned base_d0, unsigned base_d1, 
     } while (0)
     QR_EX_A(0, 0); QR_EX_B(0, 0); QR_EX_A(1, 1);
     __builtin_amdgcn_sched_barrier(0);
-    QR_EX_STEP(0); QR_EX_B(1, 1); QR_EX_A(2, 0); __builtin_amdgcn_sched_barrier(0);
-    QR_EX_STEP(1); QR_EX_B(2, 0); QR_EX_A(3, 1); __builtin_amdgcn_sched_barrier(0);
-    QR_EX_STEP(2); QR_EX_B(3, 1); QR_EX_A(4, 0); __builtin_amdgcn_sched_barrier(0);
-    QR_EX_STEP(3); QR_EX_B(4, 0); QR_EX_A(5, 1); __builtin_amdgcn_sched_barrier(0);
-    QR_EX_STEP(4); QR_EX_B(5, 1); QR_EX_A(6, 0); __builtin_amdgcn_sched_barrier(0);
-    QR_EX_STEP(5); QR_EX_B(6, 0); QR_EX_A(7, 1); __builtin_amdgcn_sched_barrier(0);
-    QR_EX_STEP(6); QR_EX_B(7, 1); __builtin_amdgcn_sched_barrier(0);
-    QR_EX_STEP(7);
+    QR_EX_STEP(0, 4); QR_EX_B(1, 1); QR_EX_A(2, 0); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(1, 4); QR_EX_B(2, 0); QR_EX_A(3, 1); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(2, 4); QR_EX_B(3, 1); QR_EX_A(4, 0); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(3, 4); QR_EX_B(4, 0); QR_EX_A(5, 1); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(4, 4); QR_EX_B(5, 1); QR_EX_A(6, 0); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(5, 4); QR_EX_B(6, 0); QR_EX_A(7, 1); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(6, 4); QR_EX_B(7, 1); __builtin_amdgcn_sched_barrier(0);
+    QR_EX_STEP(7, 0);
 #undef QR_EX_STEP
 #undef QR_EX_B
 #undef QR_EX_A
@@ -1002,7 +1053,9 @@ __device__ __forceinline__ void store_dw_tile(const f32x16p& acc, PT* __restrict
 // fabric while the workgroup still computes the next one -- as plain stores the lines sat dirty in L2 until the end-of-kernel
 // write-back (measured with tools/ppo_launch_timing.py: 6.6 us between the last workgroup's exit and the apply kernel's first
 // instruction; 1.4 us with write-through stores issued per layer).
-template <typename PT>
+// kRows8: `rows` is a multiple of 8 (hidden layers: 32, or 24 in the last row block), so a quad is stored by both lane halves or by
+// none -- a wave-uniform (scalar) branch per store instead of an EXEC-mask sequence
+template <typename PT, bool kRows8 = false>
 __device__ __forceinline__ void store_dw_tile_raw(const f32x16p& acc, PT* __restrict__ tile, int rows, int lane, float scale) {
     typedef PT pt4 __attribute__((ext_vector_type(4)));
     int ln = lane;
@@ -1011,7 +1064,7 @@ __device__ __forceinline__ void store_dw_tile_raw(const f32x16p& acc, PT* __rest
     pt4* out = reinterpret_cast<pt4*>(tile) + ln;
 #pragma unroll
     for (int a4 = 0; a4 < 4; ++a4)
-        if (8 * a4 + h4 < rows) {
+        if (kRows8 ? 8 * a4 < rows : 8 * a4 + h4 < rows) {
             pt4 v;
             v.x = (PT)(acc[4 * a4] * scale); v.y = (PT)(acc[4 * a4 + 1] * scale);
             v.z = (PT)(acc[4 * a4 + 2] * scale); v.w = (PT)(acc[4 * a4 + 3] * scale);
@@ -1019,7 +1072,12 @@ __device__ __forceinline__ void store_dw_tile_raw(const f32x16p& acc, PT* __rest
                 __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + 64 * a4), __builtin_bit_cast(unsigned long long, v),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store_dwordx2 ... sc1
             else
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(out + 64 * a4), "v"(v) : "memory");
+                // s_nop 1: a store of more than 8 bytes reads its data registers AFTER issue -- two wait states before a VALU
+                // instruction may overwrite them (gfx940 family).  The compiler's hazard recogniser pads its own stores and does not look
+                // inside inline asm: as long as every store sat behind an EXEC-mask sequence the scalar instructions in between
+                // covered it by accident; with wave-uniform branches (kRows8) the next tile's v_pk_mul_f32 followed at once and the
+                // f32 partials of the hidden layers were corrupted (tests/test_gpu_ppo_kernel.py, f32 cases).
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(out + 64 * a4), "v"(v) : "memory");
         }
 }
 
@@ -1306,6 +1364,25 @@ __global__ void __launch_bounds__(256, 1) ppo_grad4_kernel(PpoBatch a, float* __
 // next delta -> barrier -> chain writes ...  Same barrier count per pass as before (8), same arithmetic, same partial layout, same
 // results bit for bit (tests/test_gpu_ppo_kernel.py compares the two kernels); 512 threads, 256 VGPRs per wave.  In a later pass of
 // a large minibatch the chain waves' gather flies while the dW waves finish the previous pass.
+// statistics of one chain wave: wave sums of the per-lane terms (policy: d log_std[4] (x 1/B), surrogate loss, approx kl, clipped
+// count; value: squared error) -> wave_out; same order of additions whenever it is called
+__device__ __forceinline__ void chain_stats_out(const PpoBatch& a, float (&wsum)[8], int net, bool live, int lane, int g, int et, float scale) {
+    if (net == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wsum[k] = wave_sum(wsum[k]) * scale;
+        wsum[4] = wave_sum(wsum[4]);
+        wsum[5] = wave_sum(wsum[5]);
+        wsum[6] = wave_sum(wsum[6]);
+    } else {
+        wsum[4] = wave_sum(wsum[4]);
+    }
+    if (live && lane == 0) {
+        float4* wo = reinterpret_cast<float4*>(a.wave_out + (((size_t)net * a.G + g) * 2 + et) * 8);
+        wo[0] = make_float4(wsum[0], wsum[1], wsum[2], wsum[3]);
+        wo[1] = make_float4(wsum[4], wsum[5], wsum[6], wsum[7]);
+    }
+}
+
 template <int L, typename PT>
 __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __restrict__ partial, int num_params) {
     using D = PpoDims<L>;
@@ -1317,6 +1394,11 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
     const unsigned lds_base = (unsigned)(size_t)smem;
     const int net = blockIdx.y;
     const int stop_flag = *a.stop;
+#if defined(QR_PHASE_TIMING) && defined(QR_TICK_PASS)
+    const int pass = QR_TICK_PASS;   // (shadowed by the pass loops' own counter)
+#undef QR_TICK_GATE
+#define QR_TICK_GATE (pass == QR_TICK_PASS)
+#endif
     PPO_TICK(a, 0);
 #ifdef QR_PHASE_TIMING
     PPO_WALL(a.ticks, (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 16 + 14);
@@ -1405,15 +1487,23 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
             }
             const bool valid = h == 0 && live && row_ok;
             // ---- forward: the activations stay in registers until they have been published for their layer's weight gradient
-            uint32_t m1[2], m2[2], m3[2];
+#ifdef QR_PPO_MASK_WORDS
+            constexpr bool kHM = false;   // A/B: ReLU-derivative bits built in the forward pass (the grad4 / split kernels' way)
+#else
+            constexpr bool kHM = true;    // ... or taken from the published activations in the backward pass (see mlp_layer_bwd)
+#endif
+            uint32_t m1[2] = {0u, 0u}, m2[2] = {0u, 0u}, m3[2] = {0u, 0u};
             half8 h1[8], h2[8], h3[8];
-            mlp_layer<KS1, false, true>(W, lane, in, h1, m1);
+            // this wave's own packs in the h region of the exchange area, as this lane wrote them (packs_to_lds): even / odd pack index
+            const u32x4p* hm_e = reinterpret_cast<const u32x4p*>(E + 4 * 8 * 64 + wave * 8 * 64) + (lane ^ (h << 2));
+            const u32x4p* hm_o = reinterpret_cast<const u32x4p*>(E + 4 * 8 * 64 + wave * 8 * 64) + (lane ^ ((h | 2) << 2));
+            mlp_layer<KS1, false, true, kHM>(W, lane, in, h1, m1);
             PPO_TICK(a, 2);
             if (pass == 0) __syncthreads();   // [B] W2 staged
-            mlp_layer<8, false, true>(W + P::kOff2, lane, h1, h2, m2);
+            mlp_layer<8, false, true, kHM>(W + P::kOff2, lane, h1, h2, m2);
             PPO_TICK(a, 3);
             if (pass == 0) __syncthreads();   // [C] W3 staged
-            mlp_layer<8, false, true>(W + P::kOff3, lane, h2, h3, m3);
+            mlp_layer<8, false, true, kHM>(W + P::kOff3, lane, h2, h3, m3);
             PPO_TICK(a, 4);
             if (pass == 0) __syncthreads();   // [S0] W4 staged
             half8 w4[8], w4t[4];
@@ -1464,20 +1554,17 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
                     dls[k] = gl * (z[k] * z[k] - 1.0f);
                 }
                 const float clipped_ratio = fminf(fmaxf(ratio, 1.0f - a.clip), 1.0f + a.clip);
+                // per-lane terms of the minibatch statistics; their wave sums are formed AFTER d3 (below), where this wave would
+                // otherwise wait for the dW waves at [S2]: nothing downstream in the chain needs them
 #pragma unroll
-                for (int k = 0; k < 4; ++k) wsum[k] = wave_sum(dls[k]) * scale;
-                wsum[4] = wave_sum(valid ? -fminf(A * ratio, A * clipped_ratio) : 0.0f);
-                wsum[5] = wave_sum(valid ? (ratio - 1.0f) - log_ratio : 0.0f);
-                wsum[6] = wave_sum(valid && fabsf(ratio - 1.0f) > a.clip ? 1.0f : 0.0f);
+                for (int k = 0; k < 4; ++k) wsum[k] = dls[k];
+                wsum[4] = valid ? -fminf(A * ratio, A * clipped_ratio) : 0.0f;
+                wsum[5] = valid ? (ratio - 1.0f) - log_ratio : 0.0f;
+                wsum[6] = valid && fabsf(ratio - 1.0f) > a.clip ? 1.0f : 0.0f;
             } else {
                 const float err = valid ? out4[0] - st_[6 * kStashRows] : 0.0f;
                 dout[0] = a.vf_coef * 2.0f * err;
-                wsum[4] = wave_sum(err * err);
-            }
-            if (live && lane == 0) {
-                float4* wo = reinterpret_cast<float4*>(a.wave_out + (((size_t)net * a.G + g) * 2 + et) * 8);
-                wo[0] = make_float4(wsum[0], wsum[1], wsum[2], wsum[3]);
-                wo[1] = make_float4(wsum[4], wsum[5], wsum[6], wsum[7]);
+                wsum[4] = err * err;
             }
             PPO_TICK(a, 5);
             // ---- layer 4 operands: d4 (k-slot (h, j) = output unit 8 h + j) transposed by the identity MFMA, h3 as natural packs
@@ -1501,26 +1588,41 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
             half8 dA[8], dB[8];
             lds_tr_wait<0>(w4t[0], w4t[1]);
             lds_tr_wait<0>(w4t[2], w4t[3]);
+            u32x4p hm3[2][4];   // h3 (published before [S1]) read back half a layer at a time: 16 registers, not 32
+            if constexpr (kHM) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hm3[0][k] = ((k & 1) ? hm_o : hm_e)[k * 64];
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4t[t], d4, zero, 0, 0, 0);
-                dA[2 * t] = mask_pack(acc, m3[t >> 1], t, 0);
-                dA[2 * t + 1] = mask_pack(acc, m3[t >> 1], t, 1);
+                if constexpr (kHM) {
+                    if (t == 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) hm3[1][k] = ((k & 1) ? hm_o : hm_e)[(4 + k) * 64];
+                    }
+                    dA[2 * t] = mask_pack_h(acc, 0, hm3[t >> 1][2 * (t & 1)]);
+                    dA[2 * t + 1] = mask_pack_h(acc, 1, hm3[t >> 1][2 * (t & 1) + 1]);
+                } else {
+                    dA[2 * t] = mask_pack(acc, m3[t >> 1], t, 0);
+                    dA[2 * t + 1] = mask_pack(acc, m3[t >> 1], t, 1);
+                }
             }
+            chain_stats_out(a, wsum, net, live, lane, g, et, scale);
             PPO_TICK(a, 7);
             __syncthreads();   // [S2] the dW waves are done reading the layer-4 operands
             packs_to_lds(dA, E, wave, lane);
             packs_to_lds(h2, E + 4 * 8 * 64, wave, lane);
             __syncthreads();   // [S3] layer-3 operands published
             PPO_TICK(a, 8);
-            mlp_layer_bwd<P::kOff3>(lds_base + tr_lane_hidden(lane, 0, true), lds_base + tr_lane_hidden(lane, 1, true), dA, dB, m2);   // d2
+            mlp_layer_bwd<P::kOff3, kHM>(lds_base + tr_lane_hidden(lane, 0, true), lds_base + tr_lane_hidden(lane, 1, true), dA, dB, m2, hm_e, hm_o);   // d2
             PPO_TICK(a, 9);
             __syncthreads();   // [S4]
             packs_to_lds(dB, E, wave, lane);
             packs_to_lds(h1, E + 4 * 8 * 64, wave, lane);
             __syncthreads();   // [S5] layer-2 operands published
             PPO_TICK(a, 10);
-            mlp_layer_bwd<P::kOff2>(lds_base + tr_lane_hidden(lane, 0, true), lds_base + tr_lane_hidden(lane, 1, true), dB, dA, m1);   // d1
+            mlp_layer_bwd<P::kOff2, kHM>(lds_base + tr_lane_hidden(lane, 0, true), lds_base + tr_lane_hidden(lane, 1, true), dB, dA, m1, hm_e, hm_o);   // d1
             PPO_TICK(a, 11);
             __syncthreads();   // [S6]
             // ---- layer 1 operands: d1 as natural packs, x0 transposed by the identity MFMA (column unit = input index)
@@ -1618,7 +1720,7 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
 #pragma unroll
                 for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
-                    for (int bi = 0; bi < 2; ++bi) store_dw_tile_raw<PT>(dw3[bt][bi], gn + (D::kRawT3 + 4 * (to0 + bt) + ti0 + bi) * 1024, kH - 32 * (to0 + bt), lane, scale);
+                    for (int bi = 0; bi < 2; ++bi) store_dw_tile_raw<PT, true>(dw3[bt][bi], gn + (D::kRawT3 + 4 * (to0 + bt) + ti0 + bi) * 1024, kH - 32 * (to0 + bt), lane, scale);
             }
             PPO_TICK(a, 9);
             __syncthreads();   // [S5]
@@ -1633,14 +1735,14 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
 #pragma unroll
                 for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
-                    for (int bi = 0; bi < 2; ++bi) store_dw_tile_raw<PT>(dw2[bt][bi], gn + (D::kRawT2 + 4 * (to0 + bt) + ti0 + bi) * 1024, kH - 32 * (to0 + bt), lane, scale);
+                    for (int bi = 0; bi < 2; ++bi) store_dw_tile_raw<PT, true>(dw2[bt][bi], gn + (D::kRawT2 + 4 * (to0 + bt) + ti0 + bi) * 1024, kH - 32 * (to0 + bt), lane, scale);
             }
             dw_tiles_tr_old_half<D::kIT, 0>(ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw1);   // tiles (wave, 0..kIT-1)
             dw_tiles_tr_old_half<D::kIT, 4>(ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw1);
             __builtin_amdgcn_sched_barrier(0);
             if (last) {
 #pragma unroll
-                for (int bi = 0; bi < D::kIT; ++bi) store_dw_tile_raw<PT>(dw1[0][bi], gn + (D::kIT * wave + bi) * 1024, kH - 32 * wave, lane, scale);
+                for (int bi = 0; bi < D::kIT; ++bi) store_dw_tile_raw<PT, true>(dw1[0][bi], gn + (D::kIT * wave + bi) * 1024, kH - 32 * wave, lane, scale);
             }
             PPO_TICK(a, 13);
 #ifdef QR_PHASE_TIMING
@@ -1652,6 +1754,10 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
     }
 }
 
+#if defined(QR_PHASE_TIMING) && defined(QR_TICK_PASS)
+#undef QR_TICK_GATE
+#define QR_TICK_GATE true
+#endif
 // ---- phase B: weight gradients -------------------------------------------------------------------------------------------
 // One wave = a 2x2 block of 32x32 weight tiles of one layer (operands shared: 4 loads feed 4 MFMAs) over a chunk of the
 // minibatch's sample groups.  Results go, NOT atomically, to partial[chunk][param]; the norm kernel sums the chunks.

@@ -89,6 +89,26 @@ def test_rule_agrees_with_the_measured_matrix():
     assert sum(1 for f in rows.values() if f > 0) >= 6
 
 
+def test_store_data_rule():
+    """Rule 2: a VALU write of the data registers of a > 8-byte vector-memory store needs two wait states (round 5: an inline-asm
+    global_store_dwordx4 followed at once by the next tile's v_pk_mul_f32 corrupted the f32 partial gradients)."""
+    S = "\tglobal_store_dwordx4 v[164:165], v[172:175], off sc1"
+    hz = lambda body: isa_lint.store_data_hazards((S + "\n" + body).split("\n"))
+    assert len(hz("\tv_pk_mul_f32 v[172:173], v[176:177], v[54:55]")) == 1              # the bug as it was compiled
+    assert len(hz("\ts_nop 0\n\tv_mov_b32_e32 v175, 0")) == 1                          # one wait state is not enough
+    assert hz("\ts_nop 1\n\tv_pk_mul_f32 v[172:173], v[176:177], v[54:55]") == []      # the fix
+    assert hz("\ts_mov_b32 s0, 0\n\ts_mov_b32 s1, 0\n\tv_mov_b32_e32 v172, 0") == []  # two instructions in between
+    assert hz("\tv_mov_b32_e32 v171, 0\n\tv_mov_b32_e32 v176, 0") == []               # neighbours of the data registers
+    assert hz("\tv_mov_b32_e32 v164, 0") == []                                         # the ADDRESS registers are read at issue
+    assert hz("\tv_cmp_lt_i32_e32 vcc, 8, v172") == []                                 # reads, does not write
+    two = "\tglobal_store_dwordx2 v[164:165], v[172:173], off\n\tv_mov_b32_e32 v172, 0"
+    assert isa_lint.store_data_hazards(two.split("\n")) == []                          # 8 bytes: no hazard
+    buf = "\tbuffer_store_dwordx4 v[1:4], v5, s[0:3], 0 offen\n\tv_add_u32_e32 v5, 1, v5\n\tv_add_u32_e32 v4, 1, v5"
+    assert [w for _, w in isa_lint.store_data_hazards(buf.split("\n"))] == ["v_add_u32_e32 v4, 1, v5"]   # buffer form: data first
+    dis = "\tglobal_store_dwordx4 v[2:3], v[4:7], off   // 000000001230: DC7C0000 007F0402\n\tv_mov_b32_e32 v4, 0   // 000000001238: 7E080280"
+    assert len(isa_lint.store_data_hazards(dis.split("\n"))) == 1                      # disassembler lines
+
+
 def test_the_built_library_contains_no_hazardous_instruction():
     """Disassembles every code object of libquadrace.so (what the GPU will run, not what the compiler was asked for)."""
     lib = build.build_native_locked()

@@ -50,6 +50,8 @@ def measure(L=17, B=16384, R=65536 * 8, iters=100, with_torch=True):
                    "vs torch autograd + torch.optim.Adam on the same rows", "obs_len": L, "minibatch": B,
            "native_us": t_native * 1e6, "native_samples_per_s": B / t_native, "useful_TFLOPs": flops / t_native / 1e12,
            "epoch_us": t_epoch * 1e6, "epoch_minibatches": nb, "epoch_useful_TFLOPs": flops / t_epoch / 1e12}
+    st = up.status()   # (stopped, optimiser steps, skipped non-finite, barrier timeouts): the last two must be 0
+    out.update(status_skipped_nonfinite=st[2], status_barrier_timeouts=st[3])
     up.close()
     if with_torch:
         ref = ActorCritic(L, 4).to(dev)

@@ -20,7 +20,10 @@ B.needs_build = lambda: False
 from optimal_quad_control_rl_amd import _lib
 from optimal_quad_control_rl_amd.ppo import ActorCritic, MfmaPpoUpdater
 dev = torch.device("cuda", 0)
-L_, Bn, R = 17, 16384, 65536 * 4
+_pa = [a for a in sys.argv[1:] if not a.startswith("--")]
+L_ = int(_pa[0]) if _pa else 17
+Bn = int(_pa[1]) if len(_pa) > 1 else 16384
+R = max(65536 * 4, 16 * Bn)
 obs = torch.randn((R, L_), device=dev); act = torch.randn((R, 4), device=dev) * 0.5
 old_lp = torch.randn(R, device=dev) * 0.1 - 3.0; adv = torch.randn(R, device=dev); ret = torch.randn(R, device=dev)
 perm = torch.randperm(R, device=dev).to(torch.int32)
@@ -29,7 +32,7 @@ up = MfmaPpoUpdater(pol, L_, dev, Bn)
 lib = _lib.load()
 lib.qr_ppo_debug_set_ticks.argtypes = [C.c_void_p, C.c_void_p]
 grad4 = os.environ.get("QR_PPO_GRAD4") == "1" or os.environ.get("QR_PPO_SPLIT") == "1"
-waves = 2 * (Bn // 64) * 2 * (1 if grad4 else 2)    # two nets x groups x two 32-sample tiles (one chain wave each) [+ as many dW waves]
+waves = 2 * min(Bn // 64, 256) * 2 * (1 if grad4 else 2)    # two nets x groups x two 32-sample tiles (one chain wave each) [+ as many dW waves]
 ticks = torch.zeros((waves, 16), dtype=torch.int64, device=dev)
 for k in range(5):
     up.minibatch(obs, act, old_lp, adv, ret, perm[k * Bn:(k + 1) * Bn], 3e-4)
