@@ -483,20 +483,20 @@ def host_path_probe(variant, n, ga):
             "ms_per_step": dt * 1e3, "value": n / dt, "unit": "env-steps/s"}
 
 
-def config5_probe(n, iters=3, mb=16384):
+def config5_probe(n, iters=3, mb=16384, n_steps=32):
     """BASELINE config 5 as a whole loop, short: PPO on the 4-gate square track with the E2E model (residual MLPs +
     disturbances), reference hyper-parameters where they are the reference's (gamma 0.999, 10 epochs, constant lr 3e-4, target_kl
     None, 3 x 120 ReLU nets, R:784-795; SB3's time-limit bootstrap) and this build's rollout shape (n envs x 32 steps).  Collect =
     qr_rollout_policy, GAE = qr_ppo_gae, update = qr_ppo_epoch (all epochs of a train() as one replayed graph, permutations drawn on
     the device); every one of the epochs x minibatches updates runs.  `mb` rows per minibatch: 16 384 (128 minibatches per epoch,
-    the round-2 recipe) or 65 536 (32 per epoch -- closer to the reference's 20 per epoch, R:792).  Reports end-to-end env-steps/s."""
+    the round-2 recipe) or 65 536 (32 per epoch); n_steps = 40 with mb = n x 40 / 20 is the REFERENCE'S OWN SPLIT -- 20 minibatches
+    per epoch (100 envs x 1000 steps / batch_size 5000, R:785-792).  Reports end-to-end env-steps/s."""
     import torch
     from optimal_quad_control_rl_amd import Quadcopter3DGates, TRAIN_DISTURBANCE_RANGES, square_track
     from optimal_quad_control_rl_amd.ppo import PPO
 
     env = Quadcopter3DGates(n, *square_track(), gates_ahead=1, infos_mode="none", seed=1)
     env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
-    n_steps = 32
     mb = min(mb, n * n_steps)
     model = PPO(env, seed=0, gamma=0.999, n_steps=n_steps, n_epochs=10, batch_size=mb, learning_rate=3e-4,
                 target_kl=None, fused_collect=True, native_update=True)
@@ -677,7 +677,8 @@ def headline(result):
                     "config5_value": c5.get("value"), "config5_us_per_update": c5.get("us_per_update"),
                     "config5_what": _short(c5.get("what"), 150),
                     "config5_mb65536_value": c5b.get("value"), "config5_mb65536_us_per_update": c5b.get("us_per_update"),
-                    "config5_16_minibatches_per_epoch_value": c5r.get("value"), "config5_16_minibatches_per_epoch_rows": c5r.get("minibatch")}
+                    "config5_20_minibatches_per_epoch_value": c5r.get("value"), "config5_20_minibatches_per_epoch_rows": c5r.get("minibatch"),
+                    "config5_20_minibatches_per_epoch_us_per_update": c5r.get("us_per_update")}
     if "parity" in result:
         h["parity"] = {k: result["parity"].get(k) for k in ("max_rel_dstate_100_steps", "tolerance", "error") if k in result["parity"]}
     if result.get("rccl"):
@@ -803,9 +804,9 @@ def run(args, rt, env_factory=make_env, closed_loop=True):
             try:
                 result["config5"] = config5_probe(n)
                 result["config5_mb65536"] = config5_probe(n, mb=65536)
-                # the reference splits a rollout into 20 minibatches per epoch (100 envs x 1000 steps / batch_size 5000, R:785-792);
-                # this build's rollout (a power of two rows) divides into 32 (above) or 16 per epoch: the reference's ratio is bracketed
-                result["config5_ref_ratio"] = config5_probe(n, mb=(n * 32) // 16)
+                # the reference splits a rollout into 20 minibatches per epoch (100 envs x 1000 steps / batch_size 5000, R:785-792):
+                # 40 steps per rollout give exactly that split with whole 64-row groups (n x 40 / 20 = 2 n rows per minibatch)
+                result["config5_ref_ratio"] = config5_probe(n, mb=(n * 40) // 20, n_steps=40)
             except Exception as ex:  # pragma: no cover
                 result["config5"] = {"error": repr(ex)}
             try:

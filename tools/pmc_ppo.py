@@ -18,7 +18,7 @@ if sys.argv[1] == "probe":
     src = torch.empty(CAL // 4, device=dev); dst = torch.empty_like(src)
     for _ in range(3):
         dst.copy_(src)                      # calibration copies (256 MiB read + 256 MiB written each)
-    L, B, R = 17, 16384, 65536 * 8
+    L, B, R = int(os.environ.get("QR_PMC_OBS_LEN", "24")), 16384, 65536 * 8
     obs = torch.randn((R, L), device=dev); act = torch.randn((R, 4), device=dev) * 0.5
     old_lp = torch.randn(R, device=dev) * 0.1 - 3.0; adv = torch.randn(R, device=dev); ret = torch.randn(R, device=dev)
     perm = torch.randperm(R, device=dev).to(torch.int32)
@@ -48,7 +48,8 @@ else:
     f = per_kernel(load(sys.argv[2], "FETCH_SIZE")); w = per_kernel(load(sys.argv[3], "WRITE_SIZE"))
     fs, ws = CAL / (f["cal"] * 1024), CAL / (w["cal"] * 1024)
     res = {"counters": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB; scales from a 256 MiB copy in the same run",
-           "fetch_scale": fs, "write_scale": ws, "minibatch": 16384, "obs_len": 17, "per_launch_MB": {}}
+           "fetch_scale": fs, "write_scale": ws, "minibatch": 16384, "obs_len": int(os.environ.get("QR_PMC_OBS_LEN", "24")), "commit": os.environ.get("QR_COMMIT"),
+           "per_launch_MB": {}}
     for name in f:
         if name != "cal":
             res["per_launch_MB"][name] = {"read": f[name] * 1024 * fs / 1e6, "write": w[name] * 1024 * ws / 1e6}
