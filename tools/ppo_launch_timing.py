@@ -68,3 +68,16 @@ for rep in range(K):
 print(f"one minibatch update, obs_len {L_}, {Bn} rows; wall-clock us since the FIRST workgroup of the gradient kernel started (median of {K - 4} updates)")
 for k in rows[0]:
     print(f"  {k:24s} {np.median([r[k] for r in rows[4:]]):8.2f}")
+# distribution of the gradient workgroups' start / exit over the grid (last repetition): percentiles per network and by workgroup id % 8
+g8 = g.reshape(-1, 8, 16)
+start = (g8[:, :, 14].min(1) - g0) / 100.0
+exit_ = (g8[:, 4:, 15].max(1) - g0) / 100.0
+half = len(g8) // 2
+for name, sl in (("policy", slice(0, half)), ("value", slice(half, None))):
+    s_, e_ = start[sl], exit_[sl]
+    pct = lambda x: " ".join(f"{np.percentile(x, p):6.2f}" for p in (0, 10, 50, 90, 100))   # noqa: E731
+    print(f"  {name:6s} workgroups: start p0/10/50/90/100 {pct(s_)} | exit {pct(e_)} | duration {pct(e_ - s_)}")
+    by8 = [np.median((e_ - s_)[i::8]) for i in range(8)]
+    print(f"         median duration by workgroup id % 8: " + " ".join(f"{x:6.2f}" for x in by8))
+    order = np.argsort(e_)
+    print(f"         earliest exits: ids {order[:6].tolist()}  latest: ids {order[-6:].tolist()}")
