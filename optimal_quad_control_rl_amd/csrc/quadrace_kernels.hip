@@ -141,20 +141,21 @@ __device__ __forceinline__ void store_terminal_obs(const Params& P, const float*
 // ---------------------------------------------------------------------------------------------------
 // Fused step: residual MLP -> EoM -> Euler -> reward/termination -> auto-reset -> gate-frame observation
 // ---------------------------------------------------------------------------------------------------
-template <int V, int GA>
-__global__ void __launch_bounds__(kBlock)
-step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ obs_out,
-            float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+// kFull: every workgroup of the launch is full (n a multiple of the workgroup size) -- `active` is compile-time true and the EXEC-mask
+// sequences of the ragged tail leave the code; step_kernel holds both copies behind a launch-uniform branch (see rollout_fast_body).
+template <int V, int GA, bool kFull>
+__device__ __forceinline__ void step_body(Params P, const float4* __restrict__ actions, float* __restrict__ obs_out,
+                                          float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out,
+                                          float* __restrict__ lds) {
     // The MLP table is staged through LDS with the reset / gate rows (two 16-byte loads per thread), then 22 LDS reads per lane fill the
     // weight registers behind the barrier.  (Round 4 A/B, same box: loading the registers straight from global memory instead -- 22
     // loads per lane through the texture path -- costs 0.84 us per launch, 6.60 vs 5.77 us; that form is gone.)
     constexpr int kTab = (V == kE2E) ? kMlpTableFloats : 0;
-    __shared__ __attribute__((aligned(16))) float lds[kTab + kResetTableFloats + kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     // Lanes past the end of a ragged batch stay ACTIVE (they shadow env 0) because the residual MLP uses
     // wave-wide operations (MFMA, permlane swap); only their stores are suppressed.
-    const bool active = i < P.n;
+    const bool active = kFull || i < P.n;
     const int ii = active ? i : 0;
     QR_TICK(P, 0);
     // Prologue ordering (one wave per SIMD at N = 65 536: every exposed latency is paid in full).  Loads return in
@@ -226,6 +227,15 @@ template <int V, int GA>
 constexpr int act_chunk() {  // steps of actions staged per burst, sized so the static LDS stays <= 64 KiB
     return (65536 - 4 * (kResetTableFloats + kMaxGates * kGateStride) - 4 * kBlock * obs_len<V, GA>() - 16 * kMlpQuads * 64) / (16 * kBlock) >= 8 ? 8 : 4;
 }
+template <int V, int GA>
+__global__ void __launch_bounds__(kBlock)
+step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ obs_out,
+            float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
+    constexpr int kTab = (V == kE2E) ? kMlpTableFloats : 0;
+    __shared__ __attribute__((aligned(16))) float lds[kTab + kResetTableFloats + kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
+    if (P.n % kBlock == 0) step_body<V, GA, true>(P, actions, obs_out, rew_out, done_out, trunc_out, lds);
+    else step_body<V, GA, false>(P, actions, obs_out, rew_out, done_out, trunc_out, lds);
+}
 
 // kStash (round 3; launches with at most one workgroup per CU, where the register budget is free): every lane keeps the draws of
 // ITS OWN next reset -- 24 (16) floats: Philox blocks 0..5 (0..3) of (seed, global env id, current episode) -- and an auto-reset
@@ -233,20 +243,18 @@ constexpr int act_chunk() {  // steps of actions staged per burst, sized so the 
 // terminates again (about every 14 steps at a 1.2 % termination rate), instead of the wave walking its done lanes one by one
 // through reset_done_lanes() in 56 % of the steps: measured 0.31 us of a 2.80 us step (tools probe: 2.49 us with resets off,
 // +0.21 us per per cent of terminating lanes).  Same stream, same arithmetic as reset_env(): bit-identical.
-template <int V, int GA, bool kStash>
-__device__ __forceinline__ void rollout_body(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
-                                             float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
-                                             uint8_t* __restrict__ trunc_out) {
+template <int V, int GA, bool kStash, bool kFull>
+__device__ __forceinline__ void rollout_body_impl(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
+                                                  float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
+                                                  uint8_t* __restrict__ trunc_out, float* __restrict__ lds) {
     constexpr int kActChunk = act_chunk<V, GA>();
     constexpr int L = obs_len<V, GA>();
     // the plain form runs two workgroups per CU, where 256 registers is the limit: the layer-1 weight operands (20 registers) live in
     // LDS there and are re-read every step (MlpRegs::a_lds); the stash form has the register file of a whole SIMD per wave
     constexpr bool kALds = (V == kE2E) && !kStash;
-    __shared__ __attribute__((aligned(16))) float lds[kResetTableFloats + kMaxGates * kGateStride + kBlock * L +
-                                                       4 * kBlock * kActChunk + (kALds ? 4 * kMlpQuads * 64 : 0)];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool active = i < P.n;  // ragged tail lanes stay active (wave-wide MLP ops) and shadow env 0
+    const bool active = kFull || i < P.n;  // ragged tail lanes stay active (wave-wide MLP ops) and shadow env 0
     const int ii = active ? i : 0;
     QR_CLOCK_STAMP(P, 0);
     QR_CLOCK_HWID(P);
@@ -268,7 +276,7 @@ __device__ __forceinline__ void rollout_body(Params P, int K, const float4* __re
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
     const size_t n = (size_t)P.n;
     const int wave_first = i - lane;
-    const bool full_wave = wave_first + 64 <= P.n;
+    const bool full_wave = kFull || wave_first + 64 <= P.n;
     float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
     // lane-private action slots: element (j, thread) at [j * kBlock + threadIdx.x] (consecutive lanes = consecutive
     // 16 B, conflict-free); each lane only reads back what it wrote itself
@@ -331,6 +339,17 @@ __device__ __forceinline__ void rollout_body(Params P, int K, const float4* __re
     QR_CLOCK_STAMP(P, 3);
 }
 
+template <int V, int GA, bool kStash>
+__device__ __forceinline__ void rollout_body(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
+                                             float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
+                                             uint8_t* __restrict__ trunc_out) {
+    constexpr bool kALds = (V == kE2E) && !kStash;
+    __shared__ __attribute__((aligned(16))) float lds[kResetTableFloats + kMaxGates * kGateStride + kBlock * obs_len<V, GA>() +
+                                                       4 * kBlock * act_chunk<V, GA>() + (kALds ? 4 * kMlpQuads * 64 : 0)];
+    if (P.n % kBlock == 0) rollout_body_impl<V, GA, kStash, true>(P, K, actions, obs_out, rew_out, done_out, trunc_out, lds);
+    else rollout_body_impl<V, GA, kStash, false>(P, K, actions, obs_out, rew_out, done_out, trunc_out, lds);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Round 4: the fused rollout for the DEFAULT mode (no pause flags, no terminal-observation buffer; residual on / off is a
 // template parameter), launches with at most one workgroup per CU.  Same step_dynamics() / observe_with() / reset_from_stash()
@@ -390,10 +409,14 @@ constexpr int lean_lds_floats() {
 //     round 5 A/B on one box, 1 Mi envs 37.6 -> 37.1 G env-steps/s, profiles/r05_unguarded_ab.txt.)
 // 1 Mi envs: 36.9 -> 39.6 G env-steps/s A/B'd on one box (profiles/r04_lean_ab.txt), every build checked against K x step_kernel under
 // full-chip load (tools/lean_stress.py, profiles/r04_lean_stress.txt, tests/test_gpu_round4.py::test_lean_forms_agree...).
-template <int V, int GA, bool kMlp, bool kLean>
-__device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
-                                                  float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
-                                                  uint8_t* __restrict__ trunc_out) {
+// kFull = every workgroup of the launch is full (n is a multiple of the workgroup size: the common case, and every benchmark
+// size): `active` and `full_wave` are compile-time true and the EXEC-mask sequences around the ragged tail's stores leave the loop
+// (46 of the loop's ~715 instructions; a lone wave pays ~5 cycles for every instruction it issues, scalar or vector).  Both copies
+// live in ONE kernel behind a launch-uniform branch (rollout_fast_body): same symbols, same registers, same arithmetic.
+template <int V, int GA, bool kMlp, bool kLean, bool kFull>
+__device__ __forceinline__ void rollout_fast_body_impl(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
+                                                       float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
+                                                       uint8_t* __restrict__ trunc_out, float* __restrict__ lds) {
     constexpr int kActChunk = kLean ? lean_act_chunk<V, GA>() : act_chunk<V, GA>();
     constexpr int L = obs_len<V, GA>();
     constexpr int S = Env<V>::S;
@@ -404,18 +427,9 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     constexpr int kOffWho = kOffA + (kALds ? 4 * kMlpQuads * 64 : 0);   // lean: [4 waves][16] dwords, then the reset pool [4][64][NB] float4
     constexpr int kOffPool = kOffWho + 4 * 16;
     static_assert(!kLean || kOffPool + 4 * 64 * reset_value_count<V>() == lean_lds_floats<V, GA, kMlp>(), "lean LDS layout");
-    float* lds;
-    if constexpr (kLean) {   // 73-81 KB per workgroup, two workgroups per CU: dynamic LDS (launch_rollout_lean sets the limit)
-        extern __shared__ __attribute__((aligned(16))) float lds_lean[];
-        lds = lds_lean;
-    } else {
-        __shared__ __attribute__((aligned(16))) float lds_fast[kOffWho];
-        static_assert(sizeof(float) * kOffWho <= 65536, "static LDS");
-        lds = lds_fast;
-    }
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool active = i < P.n;  // ragged tail lanes stay active (wave-wide MLP ops) and shadow env 0
+    const bool active = kFull || i < P.n;  // ragged tail lanes stay active (wave-wide MLP ops) and shadow env 0
     const int ii = active ? i : 0;
     const size_t n = (size_t)P.n;
     QR_CLOCK_STAMP(P, 0);
@@ -483,7 +497,7 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     }
     bool pool_ok = false;                     // lean: this lane's pool row holds the draws of its current episode
     const int wave_first = i - lane;
-    const bool full_wave = wave_first + 64 <= P.n;
+    const bool full_wave = kFull || wave_first + 64 <= P.n;
     float* tile = gates + kMaxGates * kGateStride + (threadIdx.x >> 6) * 64 * L;
     // per-step output rows: scalar bases (advanced by scalar adds) + constant per-lane offsets
     const float4* tile4 = reinterpret_cast<const float4*>(tile);
@@ -584,6 +598,25 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
     store_world<V>(P, i, e);
     if (any_reset) store_dist<V>(P, i, e);
     QR_CLOCK_STAMP(P, 3);
+}
+template <int V, int GA, bool kMlp, bool kLean>
+__device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4* __restrict__ actions, float* __restrict__ obs_out,
+                                                  float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
+                                                  uint8_t* __restrict__ trunc_out) {
+    constexpr int kActChunk = kLean ? lean_act_chunk<V, GA>() : act_chunk<V, GA>();
+    constexpr int kOffWho = kResetTableFloats + kMaxGates * kGateStride + kBlock * obs_len<V, GA>() + 4 * kBlock * kActChunk +
+                            ((kLean && kMlp) ? 4 * kMlpQuads * 64 : 0);
+    float* lds;
+    if constexpr (kLean) {   // 73-81 KB per workgroup, two workgroups per CU: dynamic LDS (launch_rollout_lean sets the limit)
+        extern __shared__ __attribute__((aligned(16))) float lds_lean[];
+        lds = lds_lean;
+    } else {
+        __shared__ __attribute__((aligned(16))) float lds_fast[kOffWho];
+        static_assert(sizeof(float) * kOffWho <= 65536, "static LDS");
+        lds = lds_fast;
+    }
+    if (P.n % kBlock == 0) rollout_fast_body_impl<V, GA, kMlp, kLean, true>(P, K, actions, obs_out, rew_out, done_out, trunc_out, lds);
+    else rollout_fast_body_impl<V, GA, kMlp, kLean, false>(P, K, actions, obs_out, rew_out, done_out, trunc_out, lds);
 }
 template <int V, int GA>
 __global__ void __launch_bounds__(kBlock)
