@@ -138,6 +138,9 @@ __device__ __forceinline__ void store_terminal_obs(const Params& P, const float*
     store_obs<V, GA>(P.term_obs + row_base * obs_len<V, GA>(), i, to);
 }
 
+#ifndef QR_FULL_OK
+#define QR_FULL_OK true   /* -DQR_FULL_OK=false: A/B build without the full-grid copies */
+#endif
 // ---------------------------------------------------------------------------------------------------
 // Fused step: residual MLP -> EoM -> Euler -> reward/termination -> auto-reset -> gate-frame observation
 // ---------------------------------------------------------------------------------------------------
@@ -233,7 +236,7 @@ step_kernel(Params P, const float4* __restrict__ actions, float* __restrict__ ob
             float* __restrict__ rew_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ trunc_out) {
     constexpr int kTab = (V == kE2E) ? kMlpTableFloats : 0;
     __shared__ __attribute__((aligned(16))) float lds[kTab + kResetTableFloats + kMaxGates * kGateStride + kBlock * obs_len<V, GA>()];
-    if (P.n % kBlock == 0) step_body<V, GA, true>(P, actions, obs_out, rew_out, done_out, trunc_out, lds);
+    if (QR_FULL_OK && P.n % kBlock == 0) step_body<V, GA, true>(P, actions, obs_out, rew_out, done_out, trunc_out, lds);
     else step_body<V, GA, false>(P, actions, obs_out, rew_out, done_out, trunc_out, lds);
 }
 
@@ -346,7 +349,7 @@ __device__ __forceinline__ void rollout_body(Params P, int K, const float4* __re
     constexpr bool kALds = (V == kE2E) && !kStash;
     __shared__ __attribute__((aligned(16))) float lds[kResetTableFloats + kMaxGates * kGateStride + kBlock * obs_len<V, GA>() +
                                                        4 * kBlock * act_chunk<V, GA>() + (kALds ? 4 * kMlpQuads * 64 : 0)];
-    if (P.n % kBlock == 0) rollout_body_impl<V, GA, kStash, true>(P, K, actions, obs_out, rew_out, done_out, trunc_out, lds);
+    if (QR_FULL_OK && P.n % kBlock == 0) rollout_body_impl<V, GA, kStash, true>(P, K, actions, obs_out, rew_out, done_out, trunc_out, lds);
     else rollout_body_impl<V, GA, kStash, false>(P, K, actions, obs_out, rew_out, done_out, trunc_out, lds);
 }
 
@@ -615,7 +618,7 @@ __device__ __forceinline__ void rollout_fast_body(Params P, int K, const float4*
         static_assert(sizeof(float) * kOffWho <= 65536, "static LDS");
         lds = lds_fast;
     }
-    if (P.n % kBlock == 0) rollout_fast_body_impl<V, GA, kMlp, kLean, true>(P, K, actions, obs_out, rew_out, done_out, trunc_out, lds);
+    if (QR_FULL_OK && P.n % kBlock == 0) rollout_fast_body_impl<V, GA, kMlp, kLean, true>(P, K, actions, obs_out, rew_out, done_out, trunc_out, lds);
     else rollout_fast_body_impl<V, GA, kMlp, kLean, false>(P, K, actions, obs_out, rew_out, done_out, trunc_out, lds);
 }
 template <int V, int GA>
