@@ -13,9 +13,13 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libquadrace.so")
-SOURCES = ["quadrace_kernels.hip", "quadrace_abi.hip", "quadrace_policy.hip", "quadrace_ppo.hip", "quad3d.hip"]
+SOURCES = ["quadrace_kernels.hip", "quadrace_kernels_mlp.hip", "quadrace_abi.hip", "quadrace_policy.hip", "quadrace_ppo.hip", "quad3d.hip"]
 HEADERS = ["quadrace_device.hpp", "quadrace_policy.hpp", os.path.join("..", "..", "include", "quadrace.h"),
-           os.path.join("..", "..", "include", "quad3d.h")]
+           os.path.join("..", "..", "include", "quad3d.h"), "quadrace_kernels.hip"]   # (quadrace_kernels_mlp.hip includes quadrace_kernels.hip)
+# quadrace_kernels_mlp.hip = the two fused E2E + residual-MLP rollout kernels, without the SLP vectoriser: at two waves per SIMD a
+# packed-f32 instruction costs 1.3 x a scalar one and the register moves that feed it come on top (1 Mi envs: 40.5 -> 42.3 G
+# env-steps/s, profiles/r05_slp_ab.txt); every other kernel keeps the vectoriser (INDI at 65 536 envs loses 8 % without it)
+PER_SOURCE_FLAGS = {"quadrace_kernels_mlp.hip": ["-fno-slp-vectorize"]}
 # -ffp-contract=off: FMAs are written explicitly (fmaf) in the kernels, so the arithmetic is fixed by the source and
 # the per-step kernel and the fused rollout kernel produce bit-identical trajectories.
 # -amdgpu-mfma-vgpr-form: keep the MFMA accumulators of the residual MLP in VGPRs (gfx950 has a unified register file),
@@ -105,7 +109,7 @@ def build_native(force=False, verbose=False, extra_flags=(), out=None, drop_flag
             objs.append(obj)
             if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src)):
                 flags = [f for f in compile_flags if not (src in NO_VGPR_FORM and f in ("-mllvm", "-amdgpu-mfma-vgpr-form"))]
-                jobs.append(pool.submit(_compile_one, src, obj, [*flags, *extra_flags], verbose))
+                jobs.append(pool.submit(_compile_one, src, obj, [*flags, *PER_SOURCE_FLAGS.get(src, []), *extra_flags], verbose))
         for j in jobs:
             j.result()
     target = out or LIB

@@ -899,6 +899,7 @@ set_state_kernel(Params P, const float* __restrict__ world, const float* __restr
     P.ts[i] = pack_ts<V>(e);
 }
 
+#ifndef QR_TU_MLP_ROLLOUT   // (everything from here on belongs to the main translation unit, except launch_rollout_mlp at the end)
 // qr_probe_residual: body velocity (R:103) and the residual thrust / moment MLP outputs (R:254-262) of the CURRENT state
 // of every env, row [vbx vby vbz thrust Mx My Mz] -- the same device functions the step kernels inline, exposed so that
 // parity tests can pin them directly against the reference's fixture rows instead of through finite differences.
@@ -932,10 +933,22 @@ __global__ void __launch_bounds__(kBlock) clear_episode_kernel(Params P) {
     P.ts[i] = ts;
 }
 
+#endif  // !QR_TU_MLP_ROLLOUT
+
 // ---------------------------------------------------------------------------------------------------
 // host-callable launchers (used by quadrace_abi.hip)
 // ---------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(int n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+// The two fused E2E + residual-MLP kernels (rollout_fast_mlp_kernel, rollout_lean_mlp_kernel) are instantiated in a translation unit
+// of their own, quadrace_kernels_mlp.hip = this file with QR_TU_MLP_ROLLOUT defined, compiled WITHOUT the SLP vectoriser
+// (build.py PER_SOURCE_FLAGS): next to their matrix instructions, and above all at two waves per SIMD where a packed-f32
+// instruction costs 1.3 x a scalar one (profiles/r04_valu_rate.txt), the vectoriser's packed operations and the ~80 register moves
+// that feed them are a net loss there: 1 Mi envs 40.5 -> 42.3 G env-steps/s, 65 536 envs + 1.5 % (profiles/r05_slp_ab.txt).  The INDI
+// and per-step kernels keep it (INDI at 65 536 envs loses 8 % without).  Same arithmetic either way: the vectoriser packs, it does not
+// re-associate (-ffp-contract=off, explicit fmaf) -- the forms stay bit-identical (tests/test_gpu_round4.py).
+hipError_t launch_rollout_mlp(bool lean, const Params& P, int K, const float4* a4, float* obs, float* rew, uint8_t* done,
+                              uint8_t* trunc, hipStream_t st);
 
 // compile-time (variant, gates_ahead) dispatch: keeps every observation index static (registers, no scratch)
 #ifdef QR_GA_ONLY  // developer builds (ISA inspection, tools/phase_timing.py): instantiate one gates_ahead value only
@@ -954,6 +967,7 @@ static inline dim3 grid_for(int n) { return dim3((unsigned)((n + kBlock - 1) / k
     }
 #endif
 
+#ifndef QR_TU_MLP_ROLLOUT
 hipError_t launch_step(int variant, const Params& P, const float* actions, float* obs, float* rew, uint8_t* done,
                        uint8_t* trunc, hipStream_t st) {
     const float4* a4 = reinterpret_cast<const float4*>(actions);
@@ -1011,6 +1025,8 @@ const char* rollout_kernel_name(int variant, const Params& P, int form) {
     }
 }
 
+#endif  // !QR_TU_MLP_ROLLOUT
+
 // the lean forms' LDS is dynamic (more than the 64 KB a static array may have): limit set once per device and instantiation
 template <int V, int GA, bool kMlp>
 static hipError_t launch_rollout_lean_vg(const Params& P, int K, const float4* a4, float* obs, float* rew, uint8_t* done,
@@ -1020,11 +1036,17 @@ static hipError_t launch_rollout_lean_vg(const Params& P, int K, const float4* a
     constexpr size_t lds = lds_need;
     static unsigned long long configured = 0;   // per device ordinal
     if constexpr (kMlp) {
+#ifdef QR_TU_MLP_ROLLOUT
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(rollout_lean_mlp_kernel<V, GA>), lds, configured)) return e;
         hipLaunchKernelGGL((rollout_lean_mlp_kernel<V, GA>), grid_for(P.n), dim3(kBlock), lds, st, P, K, a4, obs, rew, done, trunc);
+#else
+        return hipErrorInvalidValue;   // (instantiated in quadrace_kernels_mlp.hip only)
+#endif
     } else {
+#ifndef QR_TU_MLP_ROLLOUT
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(rollout_lean_kernel<V, GA>), lds, configured)) return e;
         hipLaunchKernelGGL((rollout_lean_kernel<V, GA>), grid_for(P.n), dim3(kBlock), lds, st, P, K, a4, obs, rew, done, trunc);
+#endif
     }
     return hipGetLastError();
 }
@@ -1046,13 +1068,21 @@ static hipError_t launch_rollout_lean(const Params& P, int K, const float4* a4, 
 #endif
 }
 
+#ifdef QR_TU_MLP_ROLLOUT
+hipError_t launch_rollout_mlp(bool lean, const Params& P, int K, const float4* a4, float* obs, float* rew, uint8_t* done,
+                              uint8_t* trunc, hipStream_t st) {
+    if (lean) return launch_rollout_lean<kE2E, true>(P, K, a4, obs, rew, done, trunc, st);
+    QR_DISPATCH_GA(kE2E, rollout_fast_mlp_kernel, P, K, a4, obs, rew, done, trunc)
+    return hipGetLastError();
+}
+#else
 hipError_t launch_rollout(int variant, const Params& P, int form, int K, const float* actions, float* obs, float* rew,
                           uint8_t* done, uint8_t* trunc, hipStream_t st) {
     const float4* a4 = reinterpret_cast<const float4*>(actions);
     switch (select_rollout(variant, P, form)) {
-        case kRkFastMlp: { QR_DISPATCH_GA(kE2E, rollout_fast_mlp_kernel, P, K, a4, obs, rew, done, trunc) } break;
+        case kRkFastMlp: return launch_rollout_mlp(false, P, K, a4, obs, rew, done, trunc, st);
         case kRkFast: { QR_DISPATCH_GA(kE2E, rollout_fast_kernel, P, K, a4, obs, rew, done, trunc) } break;
-        case kRkLeanMlp: return launch_rollout_lean<kE2E, true>(P, K, a4, obs, rew, done, trunc, st);
+        case kRkLeanMlp: return launch_rollout_mlp(true, P, K, a4, obs, rew, done, trunc, st);
         case kRkLean:
             if (variant == kE2E) return launch_rollout_lean<kE2E, false>(P, K, a4, obs, rew, done, trunc, st);
             return launch_rollout_lean<kINDI, false>(P, K, a4, obs, rew, done, trunc, st);
@@ -1144,5 +1174,7 @@ hipError_t launch_set_state(int variant, const Params& P, const float* world, co
                            episode);
     return hipGetLastError();
 }
+
+#endif  // QR_TU_MLP_ROLLOUT
 
 }  // namespace qr
