@@ -270,3 +270,36 @@ def test_split_layer_error_bound_at_large_body_rates(residual_blob):
     print("max moment error %.3e, max bound %.3e, worst error / bound %.3f" % (err.max(), bound.max(), (err / bound).max()))
     assert (err <= bound).all()
     env.close()
+
+
+@pytest.mark.parametrize("variant,form", [(E2E, "auto"), (INDI, "auto"), (E2E, "multi_wave"), (INDI, "multi_wave"), (E2E, "general")])
+def test_full_grid_copy_equals_the_general_copy(variant, form, residual_blob):
+    """Every env kernel holds two copies of its body behind a launch-uniform branch: one for launches whose env count is a multiple of
+    the workgroup size (no EXEC-mask sequences for a ragged tail) and the general one (round 5).  Env i of a handle depends on
+    (seed, global env id) only, so a 1 024-env handle (full-grid copy) and a 1 000-env handle (general copy, part-filled last
+    workgroup and wave) with the same seed must agree bit for bit on their first 1 000 envs -- fused rollout and per-step kernel,
+    through auto-resets."""
+    K, dev = 48, torch.device("cuda")
+    acts = torch.rand((K, 1024, 4), device=dev, generator=torch.Generator(device=dev).manual_seed(5)) * 2 - 1
+    out = {}
+    for n in (1024, 1000):
+        a = acts[:, :n].contiguous()
+        e = _mk(variant, n, 21, residual_blob, form)
+        e.max_steps = 7                      # resets in every wave inside the window
+        fused = [t.clone() for t in e.rollout_device(a)]
+        e.close()
+        e = _mk(variant, n, 21, residual_blob, form)
+        e.max_steps = 7
+        buf = e.rollout_device(a)            # (allocates the buffers; the state is rewound by the fresh handle below)
+        e.close()
+        e = _mk(variant, n, 21, residual_blob, form)
+        e.max_steps = 7
+        stepped = [t.clone() for t in e.step_sequence_device(a, buf)]
+        e.close()
+        out[n] = (fused, stepped)
+    for which in (0, 1):
+        for x, y in zip(out[1024][which], out[1000][which]):
+            assert torch.equal(x[:, :1000], y), "full-grid copy and general copy differ"
+        assert any(bool(t.any()) for t in (out[1000][which][2],)), "no env finished: the test would not see the reset path"
+    for x, y in zip(out[1000][0], out[1000][1]):
+        assert torch.equal(x, y), "fused rollout and per-step kernel differ"
