@@ -218,16 +218,15 @@ int qr_rollout_policy(qr_env* env, qr_policy* policy, int32_t num_steps, const f
  * accumulation; parameters, gradient accumulation and Adam are f32.
  * Rollout rows (obs [rows][obs_len], act [rows][4], old_logp / adv / ret [rows]) are device arrays; idx_dev[B] selects
  * the rows of this minibatch (64 <= B <= max_minibatch; a last, partial group of 64 rows is masked inside the gradient kernel --
- * the reference's batch_size is 5000, R:792; the QR_PPO_SPLIT / QR_PPO_GRAD4 forms need B % 64 == 0). */
+ * the reference's batch_size is 5000, R:792). */
 typedef struct qr_ppo qr_ppo;
 int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo** out);
-/* The same with explicit choices of the kernel forms (verification / A-B; qr_ppo_create = flags 0 = the measured-fastest forms; the
- * library reads no environment variable): PARTIAL_F32 keeps the per-workgroup gradient partials in f32 instead of bf16 (twice the
- * bytes through the fabric; the form the kernels are verified in to f32 summation noise); FORM_SPLIT / FORM_GRAD4 select the earlier
- * forms of the gradient kernel (three launches through an HBM scratch buffer / the 4-wave fused kernel; minibatches must then be
- * multiples of 64 rows) -- independent implementations the default kernel is tested against; NO_EPOCH_GRAPH makes qr_ppo_epoch
- * enqueue plain launches instead of replaying a captured graph. */
-enum { QR_PPO_PARTIAL_F32 = 1, QR_PPO_FORM_SPLIT = 2, QR_PPO_FORM_GRAD4 = 4, QR_PPO_NO_EPOCH_GRAPH = 8 };
+/* The same with explicit choices (verification / A-B; qr_ppo_create = flags 0 = the measured-fastest form; the library reads no
+ * environment variable): PARTIAL_F32 keeps the per-workgroup gradient partials in f32 instead of bf16 (twice the bytes through the
+ * fabric; the form the kernel is verified in to f32 summation noise); NO_EPOCH_GRAPH makes qr_ppo_epoch enqueue plain launches
+ * instead of replaying a captured graph.  Any other bit is QR_E_INVALID (bits 2 and 4 selected the round 1-2 forms of the gradient
+ * kernel, removed in round 6). */
+enum { QR_PPO_PARTIAL_F32 = 1, QR_PPO_NO_EPOCH_GRAPH = 8 };
 int qr_ppo_create_ex(int32_t obs_len, int32_t device, int32_t max_minibatch, int32_t flags, qr_ppo** out);
 int qr_ppo_destroy(qr_ppo* ppo);
 int qr_ppo_num_params(const qr_ppo* ppo);

@@ -8,24 +8,23 @@
 //
 //   adv_stats   sum / sum of squares of the advantages of EVERY minibatch of an epoch in one launch (qr_ppo_epoch_begin;
 //               SB3 normalises per minibatch; the gradient kernel finishes the maths)
-//   grad        ppo_grad_kernel: a workgroup = 4 waves = 4 tiles of 32 samples of one net per pass.  Forward (f16 MFMA chain of
-//               quadrace_policy.hpp), per-sample loss gradients, backward through W^T read out of the SAME LDS image
-//               (ds_read_b64_tr_b16) -- activations h_l and deltas d_l stay in registers in the "lane = sample" form.  Per layer
-//               both are turned into the operand form (lane = unit, k = sample) by multiplying with an identity operand on
-//               the matrix core, exchanged through 64 KB of LDS, and dW_l = d_l^T x h_(l-1) is formed at once: 2 x 2 weight
-//               tiles per wave, k = the workgroup's 128 samples, plain stores to partial[workgroup][param] -- bf16 by default
-//               (round 3: the partials' trip through the fabric is what bounds a 16 384-row update; QR_PPO_PARTIAL=f32 keeps
-//               f32), widened again and summed in f32 in a fixed order by `apply`.  Biases ride
-//               along as the constant-1 unit of every layer.  No atomics anywhere: log-std gradients and loss statistics
-//               leave as per-wave sums.
+//   grad        ppo_grad_kernel: a workgroup = 8 waves = 128 samples of one net per pass.  Chain waves 0-3: one 32-sample tile each --
+//               forward (f16 MFMA chain of quadrace_policy.hpp), per-sample loss gradients, backward through W^T read out of the SAME
+//               LDS image (ds_read_b64_tr_b16); activations h_l and deltas d_l stay in registers in the "lane = sample" form and are
+//               published per layer as natural packs to a 64 KB exchange area in LDS.  dW waves 4-7 read them back transposed
+//               (lane = unit, k = sample) and form dW_l = d_l^T x h_(l-1): 2 x 2 weight tiles per wave, k = the workgroup's 128
+//               samples, plain stores to partial[workgroup][slot] in accumulator order -- bf16 by default (the partials' trip
+//               through the fabric is what bounds a 16 384-row update; QR_PPO_PARTIAL_F32 keeps f32) -- widened again and summed in
+//               f32 in a fixed order by `apply`.  Biases ride along as the constant-1 unit of every layer.  No atomics anywhere:
+//               log-std gradients and loss statistics leave as per-wave sums.
 //   apply       ONE kernel: sums the partials and the per-wave sums into the gradient, accumulates its squared norm, crosses a
 //               grid-wide barrier (247 co-resident workgroups), then clip scale, torch.optim.Adam arithmetic, and each thread
 //               scatters its new parameter as f16 into the operand image of the next minibatch; SB3's target-KL early stop is
 //               decided here, on the device, before the step is taken
 //   (pack       the gather form of the same image layout: initial images / after external changes of theta;
-//    reduce     gradient + minibatch statistics only, for the data-parallel path: qr_ppo_grad -> all-reduce -> qr_ppo_apply;
-//    phase A + phase B   the earlier split form of `grad` -- transposed operands through an HBM scratch buffer, weight gradients
-//               by one wave per 2 x 2 tile block and sample chunk -- kept selectable with QR_PPO_SPLIT=1)
+//    reduce     gradient + minibatch statistics only, for the data-parallel path: qr_ppo_grad -> all-reduce -> qr_ppo_apply)
+// The earlier forms of `grad` (rounds 1-2: a two-kernel split through an HBM scratch buffer; a 4-wave fused kernel with one dependent
+// chain per wave) are gone since round 6; docs/history/DESIGN_rounds1-4.md describes them.
 //
 // Operand layouts are those of quadrace_policy.hpp (verified on MI355X with tools/ubench/mfma_layout.hip).
 #include <hip/hip_runtime.h>
@@ -67,12 +66,6 @@ struct PpoDims {
     // half8 per net: the forward operand image of quadrace_policy.hpp and nothing else.  The backward pass needs W^T operands
     // (lane = input unit, k = output units): it reads them out of the SAME image with ds_read_b64_tr_b16 (see lds_tr_pair).
     static constexpr int kImage = P::kTotalHalf8;
-    // transposed-operand scratch: slots of [group][kk = 2*st + s][lane] half8
-    static constexpr int kSlotX0 = 0, kSlotH1 = kIT, kSlotH2 = kIT + 4, kSlotH3 = kIT + 8;
-    static constexpr int kSlotD1 = kIT + 12, kSlotD2 = kIT + 16, kSlotD3 = kIT + 20, kSlotD4 = kIT + 24;
-    static constexpr int kSlots = kIT + 25;
-    static constexpr int kIT2 = (kIT + 1) / 2;
-    static constexpr int kBlocksPerNet = 2 * kIT2 + 10;  // 2x2 blocks of 32x32 weight tiles: layer1 2*kIT2, layers 2,3 4 each, layer4 2
     // Partials of the role-split gradient kernel in ACCUMULATOR ORDER: one 32 x 32 weight tile = 1024 slots
     // [quad a = r >> 2][lane][k = r & 3] -- what a dW wave holds, written as four 1 KB runs per tile (store_dw_tile_raw);
     // tiles per net: layer 1 [out tile][in tile], layers 2 and 3 [out tile][in tile] (4 x 4), layer 4 [in tile]
@@ -169,7 +162,7 @@ __global__ void __launch_bounds__(256) ppo_pack_kernel(const float* __restrict__
 }
 
 // ---- adv_stats: sum and sum of squares of the advantages of minibatch mb = blockIdx.y, rows idx[mb * B + 0..B), into
-// table[mb][0..1] (the table is zeroed by a memset before the launch; phase A turns the sums into mean / rstd) ----------
+// table[mb][0..1] (the table is zeroed by a memset before the launch; the gradient kernel turns the sums into mean / rstd) ----------
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -286,7 +279,7 @@ struct PpoCtrl {
 };
 constexpr unsigned int kGoStop = 0x40000000u, kGoNonFinite = 0x80000000u, kGoGenMask = 0x3FFFFFFFu;
 
-// ---- phase A ------------------------------------------------------------------------------------------------------
+// ---- one minibatch as the gradient kernel sees it ---------------------------------------------------------------------------
 struct PpoBatch {
     const float* obs;       // [rows][L]
     const float* act;       // [rows][4]
@@ -300,7 +293,6 @@ struct PpoBatch {
     const int* stop;         // PpoCtrl::stop: set by an earlier launch when the target-KL early stop hit -> nothing left to do
     const float* theta;      // flat parameters (log_std is read from here)
     const half8* images;     // [2][kImage]
-    half8* tbuf;             // [2][kSlots][G][4][64]
     float* wave_out;         // [2][2 G][8] per-wave sums: policy waves {d log_std[4] / B, surrogate loss, approx kl, clipped, -},
                              // value waves {-, -, -, -, squared error, ...}; reduced by the norm kernel (no atomics)
     float* stats;            // [0] sum surrogate loss, [1] sum squared value error, [2] sum approx kl, [3] clipped count
@@ -329,17 +321,7 @@ struct PpoBatch {
 #define PPO_WALL(ptr, index) do { } while (0)
 #endif
 
-// The transposed operands are written once and read once, by phase B: streaming ("nt") stores keep ~54 MB of dirty lines out
-// of the end-of-kernel L2 write-back (same reasoning as the env kernels' outputs, tools/ubench/launch_floor.hip).
 typedef float f32x4p __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void stream_store_h8(half8* p, const half8 v) {
-#ifdef QR_PPO_PLAIN_SCRATCH_STORES
-    *p = v;
-#else
-    __builtin_nontemporal_store(__builtin_bit_cast(f32x4p, v), reinterpret_cast<f32x4p*>(p));
-#endif
-}
-
 __device__ __forceinline__ half8 plain_pack(const f32x16p& acc, int s) {
     half8 b;
 #pragma unroll
@@ -609,291 +591,22 @@ __device__ __forceinline__ void mlp_layer(const half8* __restrict__ W, int lane,
     }
 }
 
-// Transposed operand form of a 128-unit matrix of one 32-sample tile (st) held as packs X[K-step]: multiply with the
-// identity on the matrix core.  D = X (rows = samples, k = units of tile ut) x Id (k -> column unit)  =>  lane = unit,
-// registers = samples.
-__device__ __forceinline__ void tstore_hidden(const half8 (&X)[8], half8* __restrict__ dst, size_t slot_stride, int lane, int st) {
-    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    const int c = lane & 31, h = lane >> 5;
-    half8 id[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) id[s][j] = (rho_(8 * s + j, h) == c) ? (_Float16)1.0f : (_Float16)0.0f;
-    // software pipeline: the identity MFMAs of unit tile ut + 1 are issued before unit tile ut is packed and stored, so
-    // the pack never waits for the matrix core (it used to sit behind an s_nop 7-10 right after its MFMAs)
-    f32x16p acc[2];
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[0], id[0], zero, 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[1], id[1], acc[0], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ut = 0; ut < 4; ++ut) {
-        if (ut < 3) {
-            acc[(ut + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut + 2], id[0], zero, 0, 0, 0);
-            acc[(ut + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[2 * ut + 3], id[1], acc[(ut + 1) & 1], 0, 0, 0);
-        }
-        stream_store_h8(dst + ut * slot_stride + (2 * st) * 64 + lane, plain_pack(acc[ut & 1], 0));
-        stream_store_h8(dst + ut * slot_stride + (2 * st + 1) * 64 + lane, plain_pack(acc[ut & 1], 1));
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
-// Phase A workgroup: kThreads / 64 waves = kThreads / 128 sample groups x 2 tiles of 32 samples (8 waves; 4 waves for small
-// minibatches, so that 16 k samples still occupy all 256 CUs).  Every MFMA covers 32 samples anyway, so one wave
-// takes ONE tile through both passes of its network: half the live activations / deltas / masks (no scratch memory -- a
-// scratch reload would wait for all outstanding transposed-operand stores: same in-order counter) and two waves per SIMD
-// to overlap each other's matrix-core, LDS and store latencies.  (80 KB of operand image + the stash: one workgroup per CU.)
 constexpr int kStashRows = 256;  // per-sample scalars of the workgroup's 4 x 64 samples, parked in LDS
 
-template <int L, int kPpoBlockA>
-__global__ void __launch_bounds__(kPpoBlockA, 1) ppo_phase_a_kernel(PpoBatch a) {
-    constexpr int kGroupsPerBlockA = kPpoBlockA / 128;
-    using D = PpoDims<L>;
-    using P = PolicyDims<L>;
-    constexpr int KS1 = P::kSteps1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    half8* W = reinterpret_cast<half8*>(smem);
-    const unsigned lds_base = (unsigned)(size_t)smem;   // LDS byte address of the operand image (for the transposed reads)
-    const int net = blockIdx.y;
-    const int stop_flag = *a.stop;  // loaded with everything else, TESTED only before the first store: no exposed round trip
-    PPO_TICK(a, 0);
-    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    // wave-uniform indices in scalar registers: the 25+ scratch-slot addresses become scalar bases + one lane offset
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = blockIdx.x * kGroupsPerBlockA + (wave >> 1);   // sample group of this wave
-    const int et = wave & 1;                       // its 32-sample tile: samples 32 et + c (both lane halves: k-slots by h)
-    const bool live = g < a.G;                     // whole wave
-    // Every global LOAD of this wave is issued here, BEFORE the operand images are staged: the row index, the gathered
-    // observation row and the per-sample scalars are two dependent HBM round trips that now fly under the ~7 k cycles of
-    // image staging instead of after them; and loads and stores share one in-order counter, so a load issued after the
-    // transposed-operand stores would wait for all of them to drain.
-    const int b = a.idx[(live ? g : a.G - 1) * 64 + 32 * et + c];
-    float xin[KS1][8];
-    {
-        const float* row = a.obs + (size_t)b * L;
-#pragma unroll
-        for (int s = 0; s < KS1; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 16 * s + 8 * h + j;
-                xin[s][j] = row[k < L ? k : L - 1];
-            }
-    }
-    const float4 act_v = net == 0 ? reinterpret_cast<const float4*>(a.act)[b] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const float old_logp_in = a.old_logp[b], adv_in = a.adv[b], ret_in = a.ret[b];
-    const double acc_s1 = a.acc[0], acc_s2 = a.acc[1];
-    float log_std_v[4];
-    {
-        const float* log_std = a.theta + net_off(L, 4).total + net_off(L, 1).total;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) log_std_v[k] = log_std[k];
-    }
-    {   // operand images -> LDS, 8 independent 16-byte loads in flight per thread (one load per round trip took 22 k cycles)
-        const float4* src = reinterpret_cast<const float4*>(a.images + (size_t)net * D::kImage);
-        float4* dst = reinterpret_cast<float4*>(W);
-        constexpr int kBatch = 8;
-        for (int base = 0; base < D::kImage; base += kBatch * kPpoBlockA) {
-            float4 v[kBatch];
-#pragma unroll
-            for (int q = 0; q < kBatch; ++q) {
-                const int i = base + q * kPpoBlockA + threadIdx.x;
-                v[q] = src[i < D::kImage ? i : 0];
-            }
-#pragma unroll
-            for (int q = 0; q < kBatch; ++q) {
-                const int i = base + q * kPpoBlockA + threadIdx.x;
-                if (i < D::kImage) dst[i] = v[q];
-            }
-        }
-    }
-    __syncthreads();
-    if (!live || stop_flag) return;  // whole wave / the target-KL early stop hit in an earlier launch (uniform over the grid)
-    PPO_TICK(a, 1);
-    // the per-sample scalars are parked in the LDS left over beside the operand images until the loss needs them
-    float* stash = reinterpret_cast<float*>(W + D::kImage) + wave * 32 + c;
-    if (h == 0) {
-        stash[0 * kStashRows] = act_v.x;
-        stash[1 * kStashRows] = act_v.y;
-        stash[2 * kStashRows] = act_v.z;
-        stash[3 * kStashRows] = act_v.w;
-        stash[4 * kStashRows] = old_logp_in;
-        stash[5 * kStashRows] = adv_in;
-        stash[6 * kStashRows] = ret_in;
-    }
-    float wsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // per-wave sums: d log_std[4] / B, loss statistics
-    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    const size_t slot_stride = (size_t)a.G * 256;
-    half8* tb = a.tbuf + ((size_t)net * D::kSlots * a.G + g) * 256;  // slot 0, this group, kk = 0 (scalar); + lane at each use
-
-    // ---- layer-1 operand: lane (c, h) holds inputs k = 16 s + 8 h + j of sample c; input L = constant 1
-    half8 in[KS1];
-#pragma unroll
-    for (int s = 0; s < KS1; ++s) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 16 * s + 8 * h + j;
-            v[j] = k < L ? xin[s][j] : (k == L ? 1.0f : 0.0f);
-        }
-        in[s] = sat_pack(v);  // observations can be large or NaN: keep f16 finite
-    }
-    const bool valid = h == 0;  // lanes 0..31 carry the tile's per-sample scalars (mean / value / loss gradients)
-    {
-        PPO_TICK(a, 2);
-        // transposed inputs: column unit = input index
-#pragma unroll
-        for (int ut = 0; ut < D::kIT; ++ut) {
-            f32x16p acc = zero;
-#pragma unroll
-            for (int s = 0; s < KS1; ++s) {
-                half8 id;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) id[j] = (16 * s + 8 * h + j == 32 * ut + c) ? (_Float16)1.0f : (_Float16)0.0f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(in[s], id, acc, 0, 0, 0);
-            }
-            stream_store_h8(tb + (D::kSlotX0 + ut) * slot_stride + (2 * et) * 64 + lane, plain_pack(acc, 0));
-            stream_store_h8(tb + (D::kSlotX0 + ut) * slot_stride + (2 * et + 1) * 64 + lane, plain_pack(acc, 1));
-        }
-        // ---- forward
-        uint32_t m1[2], m2[2], m3[2];
-        half8 x[8], y[8];
-        mlp_layer<KS1, false>(W, lane, in, x, m1);
-        PPO_TICK(a, 3);
-        tstore_hidden(x, tb + D::kSlotH1 * slot_stride, slot_stride, lane, et);
-        PPO_TICK(a, 4);
-        mlp_layer<8, false>(W + P::kOff2, lane, x, y, m2);
-        PPO_TICK(a, 5);
-        tstore_hidden(y, tb + D::kSlotH2 * slot_stride, slot_stride, lane, et);
-        PPO_TICK(a, 6);
-        mlp_layer<8, false>(W + P::kOff3, lane, y, x, m3);  // x = h3
-        PPO_TICK(a, 7);
-        // the output layer's 8 operands and W4^T's 4 (transposed reads of the same rows: hidden unit i = 32 t + c, k-slot (h, j) =
-        // output unit 8 h + j) are fetched from LDS now, under the h3^T store / the loss arithmetic
-        half8 w4[8], w4t[4];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) w4[s] = W[P::kOff4 + s * 64 + lane];
-        {
-            const unsigned a4 = lds_base + tr_lane_out(lane) + 16u * (unsigned)P::kOff4;
-            w4t[0] = lds_tr_pair<16 * 128 * 0, 64>(a4);
-            w4t[1] = lds_tr_pair<16 * 128 * 1, 64>(a4);
-            w4t[2] = lds_tr_pair<16 * 128 * 2, 64>(a4);
-            w4t[3] = lds_tr_pair<16 * 128 * 3, 64>(a4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        tstore_hidden(x, tb + D::kSlotH3 * slot_stride, slot_stride, lane, et);
-        PPO_TICK(a, 8);
-        float out4[4];  // rows 0..3 of the output tile: registers 0..3 of lanes 0..31 (sample 32 et + lane)
-        {
-            f32x16p acc = zero;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4[s], x[s], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out4[r] = acc[r];
-        }
-
-        // ---- per-sample loss gradients (x B; the 1/B of the batch means is applied in phase B)
-        const float* st_ = stash;  // the parked per-sample values of sample 32 et + c
-        float dout[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (net == 0) {
-            const float act[4] = {st_[0 * kStashRows], st_[1 * kStashRows], st_[2 * kStashRows], st_[3 * kStashRows]};
-            const float old_logp_v = st_[4 * kStashRows], adv_v = st_[5 * kStashRows];
-            float z[4], inv_std[4], logp = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float ls = log_std_v[k];
-                inv_std[k] = __expf(-ls);
-                z[k] = (act[k] - out4[k]) * inv_std[k];
-                logp += -0.5f * z[k] * z[k] - ls - 0.9189385332046727f;
-            }
-            const float log_ratio = valid ? logp - old_logp_v : 0.0f;
-            const float ratio = __expf(log_ratio);
-            // SB3: advantages = (adv - mean) / (std + 1e-8), unbiased std over the minibatch
-            const double amean = acc_s1 / a.B;
-            const double avar = fmax((acc_s2 - a.B * amean * amean) / (a.B > 1 ? a.B - 1 : 1), 0.0);
-            const float A = valid ? (adv_v - (float)amean) * (float)(1.0 / (sqrt(avar) + 1e-8)) : 0.0f;
-            const bool flows = A >= 0.0f ? (ratio <= 1.0f + a.clip) : (ratio >= 1.0f - a.clip);
-            const float gl = (flows && valid) ? -A * ratio : 0.0f;  // d loss / d logp
-            float dls[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                dout[k] = gl * z[k] * inv_std[k];
-                dls[k] = gl * (z[k] * z[k] - 1.0f);
-            }
-            const float scale = 1.0f / (float)a.B;
-            const float clipped_ratio = fminf(fmaxf(ratio, 1.0f - a.clip), 1.0f + a.clip);
-            float sums[8];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sums[k] = wave_sum(dls[k]) * scale;
-            sums[4] = wave_sum(valid ? -fminf(A * ratio, A * clipped_ratio) : 0.0f);
-            sums[5] = wave_sum(valid ? (ratio - 1.0f) - log_ratio : 0.0f);
-            sums[6] = wave_sum(valid && fabsf(ratio - 1.0f) > a.clip ? 1.0f : 0.0f);
-            sums[7] = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) wsum[k] += sums[k];
-        } else {
-            const float err = valid ? out4[0] - st_[6 * kStashRows] : 0.0f;
-            dout[0] = a.vf_coef * 2.0f * err;  // vf_coef * d mse / d v  (x B)
-            wsum[4] += wave_sum(err * err);
-        }
-
-        PPO_TICK(a, 9);
-        // ---- output deltas as a B operand (k-slot (h, j) = output unit 8 h + j: lanes 0..31 hold units 0..7) and transposed
-        half8 d4;
-        {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (j < 4 && valid) ? dout[j < 4 ? j : 0] : 0.0f;
-            d4 = sat_pack(v);
-            half8 id;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) id[j] = (8 * h + j == c) ? (_Float16)1.0f : (_Float16)0.0f;
-            const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(d4, id, zero, 0, 0, 0);
-            stream_store_h8(tb + D::kSlotD4 * slot_stride + (2 * et) * 64 + lane, plain_pack(acc, 0));
-            stream_store_h8(tb + D::kSlotD4 * slot_stride + (2 * et + 1) * 64 + lane, plain_pack(acc, 1));
-        }
-        // ---- backward: d3 = (W4^T d4) * relu'(z3);  d2 = (W3^T d3) * relu'(z2);  d1 = (W2^T d2) * relu'(z1)
-        lds_tr_wait<0>(w4t[0], w4t[1]);
-        lds_tr_wait<0>(w4t[2], w4t[3]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4t[t], d4, zero, 0, 0, 0);
-            x[2 * t] = mask_pack(acc, m3[t >> 1], t, 0);
-            x[2 * t + 1] = mask_pack(acc, m3[t >> 1], t, 1);
-        }
-        PPO_TICK(a, 10);
-        tstore_hidden(x, tb + D::kSlotD3 * slot_stride, slot_stride, lane, et);
-        PPO_TICK(a, 11);
-        mlp_layer_bwd<P::kOff3>(lds_base + tr_lane_hidden(lane, 0), lds_base + tr_lane_hidden(lane, 1), x, y, m2);
-        PPO_TICK(a, 12);
-        tstore_hidden(y, tb + D::kSlotD2 * slot_stride, slot_stride, lane, et);
-        PPO_TICK(a, 13);
-        mlp_layer_bwd<P::kOff2>(lds_base + tr_lane_hidden(lane, 0), lds_base + tr_lane_hidden(lane, 1), y, x, m1);
-        PPO_TICK(a, 14);
-        tstore_hidden(x, tb + D::kSlotD1 * slot_stride, slot_stride, lane, et);
-        PPO_TICK(a, 15);
-    }
-    if (lane == 0) {  // per-wave sums (reduced by the norm kernel)
-        float4* wo = reinterpret_cast<float4*>(a.wave_out + (((size_t)net * a.G + g) * 2 + et) * 8);
-        wo[0] = make_float4(wsum[0], wsum[1], wsum[2], wsum[3]);
-        wo[1] = make_float4(wsum[4], wsum[5], wsum[6], wsum[7]);
-    }
-}
-
-// ---- fused gradient kernel: phase A + phase B without the scratch round trip ------------------------------------------------
-// One workgroup = 4 waves = 4 tiles of 32 samples of ONE network per pass.  Forward and backward as in phase A, but d_l and h_(l-1)
-// go to a 64 KB exchange area in LDS instead of HBM -- as the waves' natural packs, read back in the operand form (lane = unit,
-// k = sample) with transposed LDS reads; only the narrow d4 and x0 still take the identity-MFMA route -- and the workgroup
-// multiplies them right away: dW_l (16 tiles of 32 x 32 for a hidden layer) is split 2 x 2 over the 4 waves, K = the workgroup's
-// 128 samples, accumulators live for one layer only (64 VGPRs) and leave as plain f32 stores into partial[workgroup][param]
+// ---- gradient kernel: the exchange area ---------------------------------------------------------------------------------------
+// One workgroup = 128 samples (4 tiles of 32) of ONE network per pass.  d_l and h_(l-1) go to a 64 KB exchange area in LDS as the chain
+// waves' natural packs and are read back in the operand form (lane = unit, k = sample) with transposed LDS reads; only the narrow d4
+// and x0 take the identity-MFMA route.  dW_l (16 tiles of 32 x 32 for a hidden layer) is split 2 x 2 over the four dW waves, K = the
+// workgroup's 128 samples, accumulators live for one layer only (64 VGPRs) and leave as plain stores into partial[workgroup][slot]
 // (f32 atomics were measured at ~0.3 lane-atomics per ns at any scope, tools/ubench/l2_atomics.hip; a workgroup that makes
-// several passes adds to its own partial).  Per minibatch: <= 128 partials of one network each (32 MB at most) instead of
-// 54.6 MB of f16 operands written by phase A and read 1.8 x by phase B.  LDS: 80 KB image | 64 KB exchange | 7 KB stash.
+// several passes adds to its own partial).  Per minibatch: <= 128 partials of one network each.
+// LDS: 80 KB image | 64 KB exchange | 7 KB stash.
 constexpr int kExHalf8 = 2 * 4 * 8 * 64;   // exchange area: [X = d | h][wave][k-step of the pack][lane] half8 (chunk-swizzled), or, for
                                            // d4^T / x0^T, [X][unit tile][k-step = 2 wave + s][lane] in the identity-MFMA form
 
@@ -1081,288 +794,18 @@ __device__ __forceinline__ void store_dw_tile_raw(const f32x16p& acc, PT* __rest
         }
 }
 
-template <int L>
-__global__ void __launch_bounds__(256, 1) ppo_grad4_kernel(PpoBatch a, float* __restrict__ partial, int num_params) {
-    using D = PpoDims<L>;
-    using P = PolicyDims<L>;
-    constexpr int KS1 = P::kSteps1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    half8* W = reinterpret_cast<half8*>(smem);
-    half8* E = W + D::kImage;
-    const unsigned lds_base = (unsigned)(size_t)smem;
-    const unsigned ex_lane0 = lds_base + 16u * (unsigned)D::kImage + ex_lane_const((int)(threadIdx.x & 63), 0);   // exchange area + lane
-    const unsigned ex_lane1 = lds_base + 16u * (unsigned)D::kImage + ex_lane_const((int)(threadIdx.x & 63), 1);   // constants (two reads)
-    const int net = blockIdx.y;
-    const int stop_flag = *a.stop;
-    PPO_TICK(a, 0);
-    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int et = wave & 1;
-    const int O = net == 0 ? 4 : 1;
-    const NetOff o = net_off(L, O);
-    float* gn = partial + (size_t)blockIdx.x * num_params + (net == 0 ? 0 : net_off(L, 4).total);
-    const float scale = 1.0f / (float)a.B;
-    const double acc_s1 = a.acc[0], acc_s2 = a.acc[1];
-    float log_std_v[4];
-    {
-        const float* log_std = a.theta + net_off(L, 4).total + net_off(L, 1).total;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) log_std_v[k] = log_std[k];
-    }
-    const int pairs = (a.G + 1) / 2;   // passes of 2 sample groups = 128 samples
-    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    float* stash = reinterpret_cast<float*>(E + kExHalf8) + wave * 32 + c;
-    for (int pair = blockIdx.x, pass = 0; pair < pairs; pair += gridDim.x, ++pass) {
-        const int g = 2 * pair + (wave >> 1);
-        const bool live = g < a.G;   // whole wave; a wave without samples runs on row 0 with zero deltas (it shares the barriers)
-        // All global loads of the pass up front.  Issue order = return order (one in-order counter): row index first, then -- first
-        // pass -- ALL of the thread's operand-image loads (20 x 16 bytes for 80 KB: one round trip, nothing else needs the registers
-        // yet), then the loads that depend on the row index: the gather's second round trip flies while the image lands in LDS.
-        const int b = a.idx[(live ? g : a.G - 1) * 64 + 32 * et + c];
-        constexpr int kImgLoads = (D::kImage + 255) / 256;
-        const int img_rot = (int)(blockIdx.x % kImgLoads);
-        f32x4p img[kImgLoads];
-        if (pass == 0) {
-            const f32x4p* src = reinterpret_cast<const f32x4p*>(a.images + (size_t)net * D::kImage);
-            // every workgroup walks the image in a different rotation: all 128 workgroups of a network read the SAME 80 KB, and in
-            // the same order they would all be queueing on one L2 channel at a time
-#pragma unroll
-            for (int q = 0; q < kImgLoads; ++q) {
-                const int i = ((q + img_rot) % kImgLoads) * 256 + threadIdx.x;
-                img[q] = src[i < D::kImage ? i : 0];
-            }
-        }
-        float xin[KS1][8];
-        {
-            const float* row = a.obs + (size_t)b * L;
-#pragma unroll
-            for (int s = 0; s < KS1; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = 16 * s + 8 * h + j;
-                    xin[s][j] = row[k < L ? k : L - 1];
-                }
-        }
-        const float4 act_v = net == 0 ? reinterpret_cast<const float4*>(a.act)[b] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const float old_logp_in = a.old_logp[b], adv_in = a.adv[b], ret_in = a.ret[b];
-        if (pass == 0) {
-            f32x4p* dst = reinterpret_cast<f32x4p*>(W);
-#pragma unroll
-            for (int q = 0; q < kImgLoads; ++q) {
-                const int i = ((q + img_rot) % kImgLoads) * 256 + threadIdx.x;
-                if (i < D::kImage) dst[i ^ (((i >> 5) & 3) << 2)] = img[q];   // chunk swizzle: conflict-free transposed reads
-            }
-        }
-        __syncthreads();   // image staged (first pass) / the previous pass has finished with the exchange area and the stash
-        if (stop_flag) return;   // uniform over the grid
-        PPO_TICK(a, 1);
-        if (h == 0) {
-            stash[0 * kStashRows] = act_v.x;
-            stash[1 * kStashRows] = act_v.y;
-            stash[2 * kStashRows] = act_v.z;
-            stash[3 * kStashRows] = act_v.w;
-            stash[4 * kStashRows] = old_logp_in;
-            stash[5 * kStashRows] = adv_in;
-            stash[6 * kStashRows] = ret_in;
-        }
-        half8 in[KS1];
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 16 * s + 8 * h + j;
-                v[j] = k < L ? xin[s][j] : (k == L ? 1.0f : 0.0f);
-            }
-            in[s] = sat_pack(v);
-        }
-        const bool valid = h == 0 && live;
-        // ---- forward: the activations stay in registers until their layer's weight gradient has been formed
-        uint32_t m1[2], m2[2], m3[2];
-        half8 h1[8], h2[8], h3[8];
-        mlp_layer<KS1, false, true>(W, lane, in, h1, m1);
-        PPO_TICK(a, 2);
-        mlp_layer<8, false, true>(W + P::kOff2, lane, h1, h2, m2);
-        PPO_TICK(a, 3);
-        mlp_layer<8, false, true>(W + P::kOff3, lane, h2, h3, m3);
-        PPO_TICK(a, 4);
-        half8 w4[8], w4t[4];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) w4[s] = W[P::kOff4 + s * 64 + (lane ^ ((h | ((s & 1) << 1)) << 2))];
-        {
-            const unsigned a40 = lds_base + tr_lane_out(lane, 0, true) + 16u * (unsigned)P::kOff4;
-            const unsigned a41 = lds_base + tr_lane_out(lane, 1, true) + 16u * (unsigned)P::kOff4;
-            w4t[0] = lds_tr_pair2<16 * 128 * 0>(a40, a41);
-            w4t[1] = lds_tr_pair2<16 * 128 * 1>(a40, a41);
-            w4t[2] = lds_tr_pair2<16 * 128 * 2>(a40, a41);
-            w4t[3] = lds_tr_pair2<16 * 128 * 3>(a40, a41);
-        }
-        float out4[4];
-        {
-            f32x16p acc = zero;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4[s], h3[s], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out4[r] = acc[r];
-        }
-        // ---- per-sample loss gradients (x B; the 1/B of the batch means is applied when the tiles are stored)
-        float wsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        const float* st_ = stash;
-        float dout[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (net == 0) {
-            const float act[4] = {st_[0 * kStashRows], st_[1 * kStashRows], st_[2 * kStashRows], st_[3 * kStashRows]};
-            const float old_logp_v = st_[4 * kStashRows], adv_v = st_[5 * kStashRows];
-            float z[4], inv_std[4], logp = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float ls = log_std_v[k];
-                inv_std[k] = __expf(-ls);
-                z[k] = (act[k] - out4[k]) * inv_std[k];
-                logp += -0.5f * z[k] * z[k] - ls - 0.9189385332046727f;
-            }
-            const float log_ratio = valid ? logp - old_logp_v : 0.0f;
-            const float ratio = __expf(log_ratio);
-            const double amean = acc_s1 / a.B;
-            const double avar = fmax((acc_s2 - a.B * amean * amean) / (a.B > 1 ? a.B - 1 : 1), 0.0);
-            const float A = valid ? (adv_v - (float)amean) * (float)(1.0 / (sqrt(avar) + 1e-8)) : 0.0f;
-            const bool flows = A >= 0.0f ? (ratio <= 1.0f + a.clip) : (ratio >= 1.0f - a.clip);
-            const float gl = (flows && valid) ? -A * ratio : 0.0f;
-            float dls[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                dout[k] = gl * z[k] * inv_std[k];
-                dls[k] = gl * (z[k] * z[k] - 1.0f);
-            }
-            const float clipped_ratio = fminf(fmaxf(ratio, 1.0f - a.clip), 1.0f + a.clip);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) wsum[k] = wave_sum(dls[k]) * scale;
-            wsum[4] = wave_sum(valid ? -fminf(A * ratio, A * clipped_ratio) : 0.0f);
-            wsum[5] = wave_sum(valid ? (ratio - 1.0f) - log_ratio : 0.0f);
-            wsum[6] = wave_sum(valid && fabsf(ratio - 1.0f) > a.clip ? 1.0f : 0.0f);
-        } else {
-            const float err = valid ? out4[0] - st_[6 * kStashRows] : 0.0f;
-            dout[0] = a.vf_coef * 2.0f * err;
-            wsum[4] = wave_sum(err * err);
-        }
-        if (live && lane == 0) {
-            float4* wo = reinterpret_cast<float4*>(a.wave_out + (((size_t)net * a.G + g) * 2 + et) * 8);
-            wo[0] = make_float4(wsum[0], wsum[1], wsum[2], wsum[3]);
-            wo[1] = make_float4(wsum[4], wsum[5], wsum[6], wsum[7]);
-        }
-        const bool add = pass > 0;
-        PPO_TICK(a, 5);
-        f32x16p dw[2][2];
-        // ---- layer 4: d4 (k-slot (h, j) = output unit 8 h + j) transposed, h3 transposed, dW4 tile (0, wave)
-        half8 d4;
-        {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (j < 4 && valid) ? dout[j < 4 ? j : 0] : 0.0f;
-            d4 = sat_pack(v);
-            half8 id;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) id[j] = (8 * h + j == c) ? (_Float16)1.0f : (_Float16)0.0f;
-            const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(d4, id, zero, 0, 0, 0);
-            E[(0 * 8 + 2 * wave) * 64 + lane] = plain_pack(acc, 0);
-            E[(0 * 8 + 2 * wave + 1) * 64 + lane] = plain_pack(acc, 1);
-        }
-        packs_to_lds(h3, E + 4 * 8 * 64, wave, lane);
-        __syncthreads();
-        PPO_TICK(a, 6);
-        dw[0][0] = zero;
-        dw_tile_old_tr_half<0>(E, ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, lane, dw[0][0]);   // tile (0, wave)
-        dw_tile_old_tr_half<4>(E, ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, lane, dw[0][0]);
-        store_dw_tile<kH>(dw[0][0], gn + o.w4, gn + o.b4, O, 0, wave, lane, scale, add);
-        // d3 = (W4^T d4) * relu'(z3) -- independent of the exchange area
-        half8 dA[8], dB[8];
-        lds_tr_wait<0>(w4t[0], w4t[1]);
-        lds_tr_wait<0>(w4t[2], w4t[3]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f32x16p acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4t[t], d4, zero, 0, 0, 0);
-            dA[2 * t] = mask_pack(acc, m3[t >> 1], t, 0);
-            dA[2 * t + 1] = mask_pack(acc, m3[t >> 1], t, 1);
-        }
-        PPO_TICK(a, 7);
-        __syncthreads();   // everybody is done reading the layer-4 operands
-        // ---- layer 3: dW3 = d3^T x h2
-        packs_to_lds(dA, E, wave, lane);
-        packs_to_lds(h2, E + 4 * 8 * 64, wave, lane);
-        __syncthreads();
-        PPO_TICK(a, 8);
-        {
-            const int to0 = 2 * (wave >> 1), ti0 = 2 * (wave & 1);
-            dw[0][0] = zero; dw[0][1] = zero; dw[1][0] = zero; dw[1][1] = zero;
-            dw_block_tr(ex_lane0 + 2048u * (unsigned)to0, ex_lane1 + 2048u * (unsigned)to0, ex_lane0 + 2048u * (unsigned)ti0, ex_lane1 + 2048u * (unsigned)ti0, dw);
-#pragma unroll
-            for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-                for (int bi = 0; bi < 2; ++bi) store_dw_tile<kH>(dw[bt][bi], gn + o.w3, gn + o.b3, kH, to0 + bt, ti0 + bi, lane, scale, add);
-        }
-        PPO_TICK(a, 9);
-        mlp_layer_bwd<P::kOff3>(lds_base + tr_lane_hidden(lane, 0, true), lds_base + tr_lane_hidden(lane, 1, true), dA, dB, m2);   // d2
-        PPO_TICK(a, 10);
-        __syncthreads();
-        // ---- layer 2: dW2 = d2^T x h1
-        packs_to_lds(dB, E, wave, lane);
-        packs_to_lds(h1, E + 4 * 8 * 64, wave, lane);
-        __syncthreads();
-        PPO_TICK(a, 11);
-        {
-            const int to0 = 2 * (wave >> 1), ti0 = 2 * (wave & 1);
-            dw[0][0] = zero; dw[0][1] = zero; dw[1][0] = zero; dw[1][1] = zero;
-            dw_block_tr(ex_lane0 + 2048u * (unsigned)to0, ex_lane1 + 2048u * (unsigned)to0, ex_lane0 + 2048u * (unsigned)ti0, ex_lane1 + 2048u * (unsigned)ti0, dw);
-#pragma unroll
-            for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-                for (int bi = 0; bi < 2; ++bi) store_dw_tile<kH>(dw[bt][bi], gn + o.w2, gn + o.b2, kH, to0 + bt, ti0 + bi, lane, scale, add);
-        }
-        PPO_TICK(a, 12);
-        mlp_layer_bwd<P::kOff2>(lds_base + tr_lane_hidden(lane, 0, true), lds_base + tr_lane_hidden(lane, 1, true), dB, dA, m1);   // d1
-        PPO_TICK(a, 13);
-        __syncthreads();
-        // ---- layer 1: dW1 = d1^T x x0 (input tiles: column unit = input index, input L = the constant 1 = bias)
-        packs_to_lds(dA, E, wave, lane);
-#pragma unroll
-        for (int ut = 0; ut < D::kIT; ++ut) {
-            f32x16p acc = zero;
-#pragma unroll
-            for (int s = 0; s < KS1; ++s) {
-                half8 id;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) id[j] = (16 * s + 8 * h + j == 32 * ut + c) ? (_Float16)1.0f : (_Float16)0.0f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(in[s], id, acc, 0, 0, 0);
-            }
-            E[((4 + ut) * 8 + 2 * wave) * 64 + lane] = plain_pack(acc, 0);
-            E[((4 + ut) * 8 + 2 * wave + 1) * 64 + lane] = plain_pack(acc, 1);
-        }
-        __syncthreads();
-        PPO_TICK(a, 14);
-        {
-            dw[0][0] = zero; dw[0][1] = zero;
-            dw_tiles_tr_old_half<D::kIT, 0>(ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw);   // tiles (wave, 0..kIT-1)
-            dw_tiles_tr_old_half<D::kIT, 4>(ex_lane0 + 2048u * (unsigned)wave, ex_lane1 + 2048u * (unsigned)wave, E + 4 * 8 * 64, lane, dw);
-#pragma unroll
-            for (int bi = 0; bi < D::kIT; ++bi) store_dw_tile<L>(dw[0][bi], gn + o.w1, gn + o.b1, kH, wave, bi, lane, scale, add);
-        }
-        PPO_TICK(a, 15);
-        // (the barrier at the top of the next pass separates these reads from its writes)
-    }
-}
-
-// ---- the same computation with the workgroup's two jobs on different waves (round 3) ------------------------------------------
-// ppo_grad4_kernel above walks ONE dependent chain per wave: forward, loss, then per layer [exchange d_l / h_(l-1) through LDS,
-// weight gradient dW_l (transposed reads + MFMAs + 64 f32 stores per lane), backward to d_(l-1)].  Its in-wave profile
-// (profiles/r02_ppo_phase_timing.txt) puts the weight-gradient half -- exchange, barriers, dW, stores: 22 k of 44 k cycles -- on the
-// critical path although nothing downstream needs dW.  Here a workgroup has EIGHT waves, two per SIMD:
+// ---- the gradient kernel: the workgroup's two jobs on different waves ---------------------------------------------------------
+// One dependent chain per wave -- forward, loss, then per layer [exchange d_l / h_(l-1) through LDS, weight gradient dW_l (transposed
+// reads + MFMAs + 64 stores per lane), backward to d_(l-1)] -- puts the weight-gradient half (exchange, barriers, dW, stores: 22 k of
+// 44 k cycles in round 2's 4-wave kernel) on the critical path although nothing downstream needs dW.  Here a workgroup has EIGHT
+// waves, two per SIMD:
 //   chain waves 0-3   one 32-sample tile each: gather, forward, loss, d3, d2, d1 -- and they publish (d_l, h_(l-1)) to the exchange
 //                     area as soon as d_l exists;
-//   dW waves 4-7      dW_l = d_l^T h_(l-1) over the workgroup's 128 samples (the 2 x 2 tile blocks of the 4-wave kernel) and the
+//   dW waves 4-7      dW_l = d_l^T h_(l-1) over the workgroup's 128 samples (2 x 2 tile blocks) and the
 //                     partial stores, WHILE the chain waves are already in the next backward layer; their stores drain while they
 //                     wait for the next operands.
 // One exchange area (no room for two beside the 80 KB image), so per layer: chain writes -> barrier -> dW reads || chain computes the
-// next delta -> barrier -> chain writes ...  Same barrier count per pass as before (8), same arithmetic, same partial layout, same
-// results bit for bit (tests/test_gpu_ppo_kernel.py compares the two kernels); 512 threads, 256 VGPRs per wave.  In a later pass of
+// next delta -> barrier -> chain writes ...  Eight barriers per pass; 512 threads, 256 VGPRs per wave.  In a later pass of
 // a large minibatch the chain waves' gather flies while the dW waves finish the previous pass.
 // statistics of one chain wave: wave sums of the per-lane terms (policy: d log_std[4] (x 1/B), surrogate loss, approx kl, clipped
 // count; value: squared error) -> wave_out; same order of additions whenever it is called
@@ -1429,16 +872,12 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
             // (Measured and dropped: under qr_ppo_epoch's device shuffle the row index is a computable bijection of the position, so
             // the kernel could form it instead of loading it -- one dependent round trip less, 3.4 k of the prologue's 7.7 k cycles
             // in a probe that skipped the index.  The 8-round Feistel + key derivation in front of the gather cost as much as the
-            // trip saved: epoch graph 38.4 -> 39.4 us per update at 16 384 rows, 70 -> 75 us at 65 536.  -DQR_EXP_NOIDX keeps the probe.)
+            // trip saved: epoch graph 38.4 -> 39.4 us per update at 16 384 rows, 70 -> 75 us at 65 536.  tools/exp_patches/ppo_noidx.patch keeps the probe.)
             // a minibatch need not be a multiple of 64 rows (the reference's batch_size is 5000, R:792): positions past B in the last
             // group read the minibatch's last row and carry zero loss gradients, like the rows of a wave without samples
             const int pos = (live ? g : a.G - 1) * 64 + 32 * et + c;
             const bool row_ok = pos < a.B;
-#ifdef QR_EXP_NOIDX
-            const int b = row_ok ? pos : a.B - 1;
-#else
             const int b = a.idx[row_ok ? pos : a.B - 1];
-#endif
             float xin[KS1][8];
             {
                 const float* row = a.obs + (size_t)b * L;
@@ -1487,11 +926,7 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
             }
             const bool valid = h == 0 && live && row_ok;
             // ---- forward: the activations stay in registers until they have been published for their layer's weight gradient
-#ifdef QR_PPO_MASK_WORDS
-            constexpr bool kHM = false;   // A/B: ReLU-derivative bits built in the forward pass (the grad4 / split kernels' way)
-#else
-            constexpr bool kHM = true;    // ... or taken from the published activations in the backward pass (see mlp_layer_bwd)
-#endif
+            constexpr bool kHM = true;    // ReLU-derivative bits are taken from the published activations in the backward pass (see mlp_layer_bwd)
             uint32_t m1[2] = {0u, 0u}, m2[2] = {0u, 0u}, m3[2] = {0u, 0u};
             half8 h1[8], h2[8], h3[8];
             // this wave's own packs in the h region of the exchange area, as this lane wrote them (packs_to_lds): even / odd pack index
@@ -1758,124 +1193,18 @@ __global__ void __launch_bounds__(512, 1) ppo_grad_kernel(PpoBatch a, PT* __rest
 #undef QR_TICK_GATE
 #define QR_TICK_GATE true
 #endif
-// ---- phase B: weight gradients -------------------------------------------------------------------------------------------
-// One wave = a 2x2 block of 32x32 weight tiles of one layer (operands shared: 4 loads feed 4 MFMAs) over a chunk of the
-// minibatch's sample groups.  Results go, NOT atomically, to partial[chunk][param]; the norm kernel sums the chunks.
-// (Measured: f32 atomics from ~3000 waves cost 17 us per minibatch, as much as the loads and MFMAs themselves.)
-template <int L>
-__global__ void __launch_bounds__(64) ppo_phase_b_kernel(const half8* __restrict__ tbuf, float* __restrict__ partial, int num_params,
-                                                         int G, int groups_per_chunk, int num_chunks, float scale,
-                                                         const int* __restrict__ stop) {
-    using D = PpoDims<L>;
-    const int stop_flag = *stop;  // target-KL early stop hit in an earlier launch: tested before the stores, not up front
-    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
-    // XCD-aware mapping: workgroups go round-robin to the 8 XCDs (each with its own L2), so workgroup id % 8 selects the XCD.
-    // All tile blocks of one sample chunk share their operands -> they get the same id % 8 and meet in one L2
-    // (measured: 21.9 -> 15.5 us; placing phase A's groups on the XCD that later reads them gained nothing).
-    constexpr int kJobs = 2 * D::kBlocksPerNet;
-    const int id = blockIdx.x;
-    int chunk, job;
-    if (num_chunks % 8 == 0) {
-        chunk = (id % 8) + 8 * (id / (8 * kJobs));
-        job = (id / 8) % kJobs;
-    } else {
-        chunk = id / kJobs;
-        job = id % kJobs;
-    }
-    const int net = job / D::kBlocksPerNet;
-    int j = job % D::kBlocksPerNet;
-    int layer, to0, nto, ti0, nti;
-    if (j < 2 * D::kIT2) { layer = 1; to0 = 2 * (j / D::kIT2); nto = 2; ti0 = 2 * (j % D::kIT2); nti = min(2, D::kIT - ti0); }
-    else if (j < 2 * D::kIT2 + 4) { j -= 2 * D::kIT2; layer = 2; to0 = 2 * (j >> 1); nto = 2; ti0 = 2 * (j & 1); nti = 2; }
-    else if (j < 2 * D::kIT2 + 8) { j -= 2 * D::kIT2 + 4; layer = 3; to0 = 2 * (j >> 1); nto = 2; ti0 = 2 * (j & 1); nti = 2; }
-    else { layer = 4; to0 = 0; nto = 1; ti0 = 2 * (j - (2 * D::kIT2 + 8)); nti = 2; }
-    const int slot_a = (layer == 1 ? D::kSlotD1 : (layer == 2 ? D::kSlotD2 : (layer == 3 ? D::kSlotD3 : D::kSlotD4))) + to0;
-    const int slot_b = (layer == 1 ? D::kSlotX0 : (layer == 2 ? D::kSlotH1 : (layer == 3 ? D::kSlotH2 : D::kSlotH3))) + ti0;
-    const size_t slot_stride = (size_t)G * 256;
-    const half8* A0 = tbuf + ((size_t)net * D::kSlots + slot_a) * slot_stride + lane;
-    const half8* B0 = tbuf + ((size_t)net * D::kSlots + slot_b) * slot_stride + lane;
-    const half8* A1 = A0 + (nto > 1 ? slot_stride : 0);  // a block without a second row / column re-reads the first
-    const half8* B1 = B0 + (nti > 1 ? slot_stride : 0);
-    const int g0 = chunk * groups_per_chunk;
-    const int g1 = min(G, g0 + groups_per_chunk);
-    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    f32x16p acc[2][2] = {{zero, zero}, {zero, zero}};
-    // Operands of the NEXT TWO groups are in flight while two groups are multiplied (a wave is otherwise one memory round trip
-    // per group: with 16 KB in flight per wave x 768 waves the kernel sat at 3.5 TB/s -- Little's law for ~2 us of loaded HBM
-    // latency -- so the batch in flight is doubled to 32 KB per wave).
-    constexpr int kPF = 2;                       // groups per batch
-    half8 a0[kPF][4], a1[kPF][4], b0[kPF][4], b1[kPF][4];
-    auto fetch = [&](int g, half8 (&xa0)[4], half8 (&xa1)[4], half8 (&xb0)[4], half8 (&xb1)[4]) {
-        const int gc = g < g1 ? g : (g1 - 1 > 0 ? g1 - 1 : 0);   // clamped: loads past the chunk re-read its last group (unused)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const size_t e = ((size_t)gc * 4 + kk) * 64;
-            xa0[kk] = A0[e]; xa1[kk] = A1[e]; xb0[kk] = B0[e]; xb1[kk] = B1[e];
-        }
-    };
-#pragma unroll
-    for (int j = 0; j < kPF; ++j) fetch(g0 + j, a0[j], a1[j], b0[j], b1[j]);
-    for (int g = g0; g < g1; g += kPF) {
-        half8 na0[kPF][4], na1[kPF][4], nb0[kPF][4], nb1[kPF][4];
-#pragma unroll
-        for (int j = 0; j < kPF; ++j) fetch(g + kPF + j, na0[j], na1[j], nb0[j], nb1[j]);
-#pragma unroll
-        for (int j = 0; j < kPF; ++j) {
-            if (g + j < g1) {   // wave-uniform
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[j][kk], b0[j][kk], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[j][kk], b1[j][kk], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[j][kk], b0[j][kk], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[j][kk], b1[j][kk], acc[1][1], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kPF; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                a0[j][kk] = na0[j][kk]; a1[j][kk] = na1[j][kk]; b0[j][kk] = nb0[j][kk]; b1[j][kk] = nb1[j][kk];
-            }
-    }
-    if (stop_flag) return;
-    // D: register r of lane (c, h) = dW[row = 32 to + rho(r, h)][col = 32 ti + c]
-    const int O = net == 0 ? 4 : 1;
-    const NetOff o = net_off(L, O);
-    float* gn = partial + (size_t)chunk * num_params + (net == 0 ? 0 : net_off(L, 4).total);
-    const int in_dim = layer == 1 ? L : kH, out_dim = layer == 4 ? O : kH;   // column `in_dim` is the constant-1 unit = bias
-    const int ow = layer == 1 ? o.w1 : (layer == 2 ? o.w2 : (layer == 3 ? o.w3 : o.w4));
-    const int ob = layer == 1 ? o.b1 : (layer == 2 ? o.b2 : (layer == 3 ? o.b3 : o.b4));
-#pragma unroll
-    for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-        for (int bi = 0; bi < 2; ++bi) {
-            if (bt >= nto || bi >= nti) continue;
-            const int col = 32 * (ti0 + bi) + c;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * (to0 + bt) + rho_(r, h);
-                const float v = acc[bt][bi][r] * scale;
-                if (row < out_dim) {
-                    if (col < in_dim) gn[ow + row * in_dim + col] = v;
-                    else if (col == in_dim) gn[ob + row] = v;
-                }
-            }
-        }
-}
-
 // ---- gradient reduction, global norm, clip, Adam, operand re-pack: ONE kernel ----------------------------------------------
 struct ApplyArgs {
     float *theta, *m, *v;     // parameters and Adam moments (flat, n floats)
     const float* ext_grad;    // data-parallel path: [n + 4] externally averaged gradient + minibatch statistics; else nullptr
     float* grad_out;          // optional [n + 4]: the reduced gradient + minibatch statistics (qr_ppo_grad); else nullptr
-    const float* partial;     // [chunks][n] sample-chunk partials of phase B / of the fused gradient kernel
+    const float* partial;     // [chunks][slots] the gradient kernel's per-workgroup partials (or [n] for an external gradient)
     int partial_bf16;         // 1: the partials are __bf16 (same indexing, half the bytes)
     int partial_raw;          // > 0: accumulator-order partials of ppo_grad_kernel, [chunks][partial_raw] with partial_raw = 2 x
                               // PpoDims::kRawSlots; thread -> (slot, parameter) by DenseMap
     int owner_from;           // first thread index of the log_std entries (the workgroups from there on also sum the per-wave sums)
     int chunks, n;
-    const float* wave_out;    // per-wave sums of phase A, Gw = waves per net
+    const float* wave_out;    // per-wave sums of the gradient kernel's chain waves, Gw = waves per net
     int Gw;
     float ent_coef;
     float* stats;             // optional [4], accumulated
@@ -1891,7 +1220,7 @@ struct ApplyArgs {
 #endif
 };
 
-// gradient element i and, in the block(s) that own the log_std entries, the per-wave sums of phase A:
+// gradient element i and, in the block(s) that own the log_std entries, the per-wave sums of the chain waves:
 // red[0..3] = d loss / d log_std[k] (x 1/B), red[4..7] = sum surrogate, sum squared value error, sum approx kl, clipped count
 constexpr int kApplyThreads = 256;   // 247 workgroups: the 8 MB of chunk partials are pulled by (almost) every CU
                                      // (62 x 1024 threads took 13.5 us for this kernel, bound by 62 CUs' load issue)
@@ -1905,7 +1234,7 @@ __device__ __forceinline__ float reduce_grad_element(const ApplyArgs& a, int i, 
         __syncthreads();
         return i < n ? a.ext_grad[i] : 0.0f;
     }
-    // The block(s) holding the log_std entries (the last one or two) also sum phase A's per-wave sums.  All of their loads are
+    // The block(s) holding the log_std entries (the last one or two) also sum the chain waves' per-wave sums.  All of their loads are
     // issued up front, together with the chunk partials below: one memory round trip for the whole prologue (a wave that walked
     // its 512 rows in a loop paid eight of them, and the grid barrier waits for exactly these blocks).
     //   policy waves (net 0): slots 0..3 d log_std / B, 4 surrogate, 5 approx kl, 6 clipped;  value waves (net 1): slot 4 squared error
@@ -2264,16 +1593,13 @@ __global__ void __launch_bounds__(256) ppo_gae_kernel(int T, int N, const float*
 // ------------------------------------------------------------------------------------------------------------------------
 struct qr_ppo {
     int L = 0, device = 0, max_B = 0, num_params = 0;
-    int image_half8 = 0, slots = 0, raw_slots = 0, max_chunks = 32;  // chunks = split of the minibatch's sample groups in phase B
-    static constexpr int kFusedChunks = 128;          // workgroups (= partials) per network of the fused gradient kernel
-    bool fused = true;                                // QR_PPO_FORM_SPLIT: the two-kernel form (phase A + phase B through scratch)
-    bool grad4 = false;                               // QR_PPO_FORM_GRAD4: fused gradient kernel in its 4-wave form (round 2)
+    int image_half8 = 0, raw_slots = 0;
+    static constexpr int kFusedChunks = 128;          // workgroups (= partials) per network of the gradient kernel
     bool partial_bf16 = true;                         // QR_PPO_PARTIAL_F32: the role-split kernel's partials as f32 (twice the bytes)
     bool epoch_graph = true;                          // QR_PPO_NO_EPOCH_GRAPH: qr_ppo_epoch enqueues its launches on the stream
     qr::half8* d_images = nullptr;
-    qr::half8* d_tbuf = nullptr;
-    float* d_partial = nullptr;  // [max_chunks][num_params] phase-B outputs
-    float* d_wave = nullptr;     // [2][2 x max groups][8] per-wave sums of phase A
+    float* d_partial = nullptr;  // [kFusedChunks][raw slots] partial weight gradients of the gradient kernel's workgroups
+    float* d_wave = nullptr;     // [2][2 x max groups][8] per-wave sums of the chain waves
 #ifdef QR_PHASE_TIMING
     unsigned long long* ticks = nullptr;
     unsigned long long* apply_ticks = nullptr;
@@ -2344,58 +1670,33 @@ struct PpoOps {
         b.acc = slot;
         return QR_OK;
     }
-    static constexpr size_t kLdsSplit = (size_t)D::kImage * 16 + 7 * qr::kStashRows * sizeof(float);   // operand images + per-sample stash
     static constexpr size_t kLdsFused = ((size_t)D::kImage + qr::kExHalf8) * 16 + 7 * qr::kStashRows * sizeof(float);
-    // dynamic-LDS limits of the gradient kernels on the CURRENT device (idempotent; not a stream operation, so it also runs
+    // dynamic-LDS limit of the gradient kernel on the CURRENT device (idempotent; not a stream operation, so it also runs
     // before a graph capture instead of inside it)
     static int configure(qr_ppo* p) {
-        static unsigned long long configured_a = 0, configured_a8 = 0, configured_f = 0, configured_fb = 0, configured_f4 = 0;   // per device ordinal
-        if (!p->fused) {
-            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 256>), kLdsSplit, configured_a));
-            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_phase_a_kernel<L, 512>), kLdsSplit, configured_a8));
-        } else if (p->grad4) {
-            PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad4_kernel<L>), kLdsFused, configured_f4));
-        } else if (p->partial_bf16) {
+        static unsigned long long configured_f = 0, configured_fb = 0;   // per device ordinal
+        if (p->partial_bf16) {
             PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad_kernel<L, __bf16>), kLdsFused, configured_fb));
         } else {
             PPO_HIP(qr::ensure_dynamic_lds(reinterpret_cast<const void*>(qr::ppo_grad_kernel<L, float>), kLdsFused, configured_f));
         }
         return QR_OK;
     }
-    // phase A + phase B: per-sample-chunk partial gradients in d_partial, per-wave sums in d_wave; returns the chunk count
+    // one kernel: forward, backward and the weight gradients of 128 samples per workgroup and pass; partial gradients of every workgroup
+    // in d_partial, per-wave sums in d_wave; returns the number of partials per network
     static int grad(qr_ppo* p, qr::PpoBatch b, hipStream_t st, int* chunks_out) {
-        constexpr size_t lds = kLdsSplit, lds_f = kLdsFused;
+        constexpr size_t lds_f = kLdsFused;
         if (int rc = configure(p)) return rc;
         if (int rc = adv_stats(p, b, st)) return rc;
-        if (p->fused) {   // one kernel: forward, backward and the weight gradients of 128 samples per workgroup and pass
-            const int pairs = (b.G + 1) / 2;
-            const int wgs = pairs < qr_ppo::kFusedChunks ? pairs : qr_ppo::kFusedChunks;
-            if (p->grad4)   // QR_PPO_GRAD4=1: the 4-wave form (one dependent chain per wave), kept for comparison
-                hipLaunchKernelGGL((qr::ppo_grad4_kernel<L>), dim3(wgs, 2), dim3(256), lds_f, st, b, p->d_partial, p->num_params);
-            else if (p->partial_bf16)
-                hipLaunchKernelGGL((qr::ppo_grad_kernel<L, __bf16>), dim3(wgs, 2), dim3(512), lds_f, st, b,
-                                   reinterpret_cast<__bf16*>(p->d_partial), p->num_params);
-            else
-                hipLaunchKernelGGL((qr::ppo_grad_kernel<L, float>), dim3(wgs, 2), dim3(512), lds_f, st, b, p->d_partial, p->num_params);
-            PPO_HIP(hipGetLastError());
-            *chunks_out = wgs;
-            return QR_OK;
-        }
-        // split the minibatch's sample groups into chunks: 2 * kBlocksPerNet x chunks waves in phase B
-        int chunks = p->max_chunks;
-        if (chunks > b.G) chunks = b.G;
-        if (chunks < 1) chunks = 1;
-        const int per = (b.G + chunks - 1) / chunks;
-        chunks = (b.G + per - 1) / per;
-        // one workgroup per CU (LDS): 4-wave workgroups (2 groups) while that still fits the 256 CUs in one round, else 8 waves
-        if (b.G <= 256)
-            hipLaunchKernelGGL((qr::ppo_phase_a_kernel<L, 256>), dim3((b.G + 1) / 2, 2), dim3(256), lds, st, b);
+        const int pairs = (b.G + 1) / 2;
+        const int wgs = pairs < qr_ppo::kFusedChunks ? pairs : qr_ppo::kFusedChunks;
+        if (p->partial_bf16)
+            hipLaunchKernelGGL((qr::ppo_grad_kernel<L, __bf16>), dim3(wgs, 2), dim3(512), lds_f, st, b,
+                               reinterpret_cast<__bf16*>(p->d_partial), p->num_params);
         else
-            hipLaunchKernelGGL((qr::ppo_phase_a_kernel<L, 512>), dim3((b.G + 3) / 4, 2), dim3(512), lds, st, b);
-        hipLaunchKernelGGL(qr::ppo_phase_b_kernel<L>, dim3(2 * D::kBlocksPerNet * chunks), dim3(64), 0, st, p->d_tbuf, p->d_partial,
-                           p->num_params, b.G, per, chunks, 1.0f / (float)b.B, &p->d_ctrl->stop);
+            hipLaunchKernelGGL((qr::ppo_grad_kernel<L, float>), dim3(wgs, 2), dim3(512), lds_f, st, b, p->d_partial, p->num_params);
         PPO_HIP(hipGetLastError());
-        *chunks_out = chunks;
+        *chunks_out = wgs;
         return QR_OK;
     }
     static int apply(qr_ppo* p, qr::ApplyArgs a, hipStream_t st) {
@@ -2404,7 +1705,7 @@ struct PpoOps {
         a.n = p->num_params;
         a.partial = p->d_partial;
         // the role-split gradient kernel leaves its partials in accumulator order: one thread per slot (+ one workgroup for log_std)
-        const bool raw = p->fused && !p->grad4 && !a.ext_grad;
+        const bool raw = !a.ext_grad;
         a.partial_bf16 = (raw && p->partial_bf16) ? 1 : 0;
         a.partial_raw = raw ? 2 * D::kRawSlots : 0;
         a.wave_out = p->d_wave;
@@ -2443,17 +1744,15 @@ int fill_batch(qr_ppo* p, qr::PpoBatch& b, const float* theta, const float* obs,
                const float* adv, const float* ret, const int32_t* idx, int32_t B, float clip, float vf_coef, float ent_coef,
                float* stats) {
     if (!p || !theta || !obs || !act || !old_logp || !adv || !ret || !idx) return ppofail(QR_E_INVALID, "qr_ppo: null argument");
-    // the role-split gradient kernel masks the tail of a last, partial group of 64 rows; the earlier forms need whole groups
-    const bool ragged_ok = p->fused && !p->grad4;
-    if (B < 64 || (B % 64 != 0 && !ragged_ok) || B > p->max_B)
-        return ppofail(QR_E_INVALID, "qr_ppo: minibatch size must be >= 64 (a multiple of 64 under QR_PPO_SPLIT / QR_PPO_GRAD4) and <= max_minibatch");
+    // (the gradient kernel masks the tail of a last, partial group of 64 rows)
+    if (B < 64 || B > p->max_B)
+        return ppofail(QR_E_INVALID, "qr_ppo: minibatch size must be >= 64 and <= max_minibatch");
     b.obs = obs; b.act = act; b.old_logp = old_logp; b.adv = adv; b.ret = ret; b.idx = idx;
     b.B = B; b.G = (B + 63) / 64;
     b.clip = clip; b.vf_coef = vf_coef; b.ent_coef = ent_coef;
     b.acc = nullptr;
     b.theta = theta;
     b.images = p->d_images;
-    b.tbuf = p->d_tbuf;
     b.wave_out = p->d_wave;
     b.stats = stats;
     b.stop = &p->d_ctrl->stop;
@@ -2485,7 +1784,7 @@ int qr_ppo_create(int32_t obs_len, int32_t device, int32_t max_minibatch, qr_ppo
 
 int qr_ppo_create_ex(int32_t obs_len, int32_t device, int32_t max_minibatch, int32_t flags, qr_ppo** out) {
     if (!out) return ppofail(QR_E_INVALID, "qr_ppo_create: null output");
-    if (flags < 0 || flags > (QR_PPO_PARTIAL_F32 | QR_PPO_FORM_SPLIT | QR_PPO_FORM_GRAD4 | QR_PPO_NO_EPOCH_GRAPH))
+    if (flags < 0 || (flags & ~(QR_PPO_PARTIAL_F32 | QR_PPO_NO_EPOCH_GRAPH)))
         return ppofail(QR_E_INVALID, "qr_ppo_create_ex: unknown flag");
     *out = nullptr;
     if (max_minibatch < 64 || max_minibatch % 64 != 0) return ppofail(QR_E_INVALID, "qr_ppo_create: max_minibatch must be a multiple of 64");
@@ -2500,22 +1799,17 @@ int qr_ppo_create_ex(int32_t obs_len, int32_t device, int32_t max_minibatch, int
     const int rc = dispatch_L(obs_len, [&](auto Lc) {
         using D = qr::PpoDims<decltype(Lc)::value>;
         p->image_half8 = D::kImage;
-        p->slots = D::kSlots;
         p->raw_slots = 2 * D::kRawSlots;
         return (int)QR_OK;
     });
     if (rc != QR_OK) { delete p; return rc; }
     p->num_params = qr::ppo_num_params(obs_len);
     // which forms of the kernels this handle uses: explicit flags (the library reads no environment variable)
-    p->fused = !(flags & QR_PPO_FORM_SPLIT);
-    p->grad4 = (flags & QR_PPO_FORM_GRAD4) != 0;
     p->partial_bf16 = !(flags & QR_PPO_PARTIAL_F32);
     p->epoch_graph = !(flags & QR_PPO_NO_EPOCH_GRAPH);
     PPO_HIP(hipSetDevice(device));
-    const size_t tbytes = (size_t)2 * p->slots * (max_minibatch / 64) * 256 * 16;
     const size_t mbbytes = (size_t)(qr_ppo::kMaxEpochMinibatches + 1) * 2 * sizeof(double);
     hipError_t e = hipMalloc((void**)&p->d_images, (size_t)2 * p->image_half8 * 16);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_tbuf, tbytes);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_partial, (size_t)qr_ppo::kFusedChunks * (p->raw_slots > p->num_params ? p->raw_slots : p->num_params) * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_wave, (size_t)2 * 2 * (max_minibatch / 64) * 8 * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_ctrl, sizeof(qr::PpoCtrl));
@@ -2535,7 +1829,6 @@ int qr_ppo_destroy(qr_ppo* p) {
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(p->d_images);
-    (void)hipFree(p->d_tbuf);
     (void)hipFree(p->d_partial);
     (void)hipFree(p->d_wave);
     (void)hipFree(p->d_ctrl);
@@ -2586,7 +1879,7 @@ int qr_ppo_epoch_begin(qr_ppo* p, const float* adv_dev, const int32_t* idx_dev, 
 static int epoch_begin_impl(qr_ppo* p, const float* adv_dev, const int32_t* idx_dev, int32_t B, int32_t num_minibatches, void* stream,
                             unsigned long long* bump) {
     if (!p || !adv_dev || !idx_dev) return ppofail(QR_E_INVALID, "qr_ppo_epoch_begin: null argument");
-    if (B < 64 || (B % 64 != 0 && !(p->fused && !p->grad4)) || B > p->max_B || num_minibatches < 1 || num_minibatches > qr_ppo::kMaxEpochMinibatches)
+    if (B < 64 || B > p->max_B || num_minibatches < 1 || num_minibatches > qr_ppo::kMaxEpochMinibatches)
         return ppofail(QR_E_INVALID, "qr_ppo_epoch_begin: bad minibatch size / count");
     PPO_HIP(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
@@ -2732,7 +2025,7 @@ int qr_ppo_epoch(qr_ppo* p, float* theta_dev, float* adam_m_dev, float* adam_v_d
                  float max_grad_norm, float lr, float beta1, float beta2, float eps, float* stats_dev, void* stream) {
     if (!p || !theta_dev || !adam_m_dev || !adam_v_dev || !obs_dev || !act_dev || !old_logp_dev || !adv_dev || !ret_dev || !perm_dev)
         return ppofail(QR_E_INVALID, "qr_ppo_epoch: null argument");
-    if (B < 64 || (B % 64 != 0 && !(p->fused && !p->grad4)) || B > p->max_B || num_minibatches < 1 || num_minibatches > qr_ppo::kMaxEpochMinibatches || !(lr >= 0.0f))
+    if (B < 64 || B > p->max_B || num_minibatches < 1 || num_minibatches > qr_ppo::kMaxEpochMinibatches || !(lr >= 0.0f))
         return ppofail(QR_E_INVALID, "qr_ppo_epoch: bad minibatch size / count / learning rate");
     if (num_epochs < 1 || num_epochs > 64 || (num_epochs > 1 && !device_shuffle))
         return ppofail(QR_E_INVALID, "qr_ppo_epoch: num_epochs > 1 needs device_shuffle (the caller cannot rewrite the permutation in between)");

@@ -84,9 +84,10 @@ class MfmaPpoUpdater:
     net_arch (120, 120, 120).  The module's parameters are re-pointed at views of ONE flat float32 vector (the layout
     the C ABI defines), so torch code that evaluates the networks keeps seeing the current weights."""
 
-    def __init__(self, policy, obs_len, device, max_minibatch, betas=(0.9, 0.999), eps=1e-5, flags=None):
+    force_data_parallel = False   # test hook: take the all-reduce path on a single rank
+
+    def __init__(self, policy, obs_len, device, max_minibatch, betas=(0.9, 0.999), eps=1e-5, flags=0):
         import ctypes as C
-        import os
 
         from . import _lib
 
@@ -96,12 +97,7 @@ class MfmaPpoUpdater:
         self.device = device
         h = C.c_void_p()
         # (capacity in whole groups of 64 rows; a minibatch itself may be any size >= 64: the kernel masks a partial last group)
-        # kernel forms: `flags` (QR_PPO_* of include/quadrace.h), or -- for the test suite and A/B tools only -- the environment
-        # variables of rounds 2-4, translated HERE (the library itself reads none)
-        if flags is None:
-            env = os.environ
-            flags = ((1 if env.get("QR_PPO_PARTIAL", "")[:1] == "f" else 0) | (2 if env.get("QR_PPO_SPLIT") == "1" else 0) |
-                     (4 if env.get("QR_PPO_GRAD4") == "1" else 0) | (8 if env.get("QR_PPO_EPOCH_GRAPH") == "0" else 0))
+        # kernel forms: `flags` = QR_PPO_* of include/quadrace.h (1: f32 partials, 8: no epoch graph); nothing is read from the environment
         _lib.check(self._L.qr_ppo_create_ex(int(obs_len), int(device.index or 0), (int(max_minibatch) + 63) // 64 * 64, int(flags), C.byref(h)))
         self._h = h
         n = self._L.qr_ppo_num_params(self._h)
@@ -177,12 +173,10 @@ class MfmaPpoUpdater:
     @staticmethod
     def data_parallel():
         """True when minibatch updates must be synchronised across ranks (torch.distributed initialised with more than one
-        rank; QR_PPO_FORCE_DDP=1 takes the same code path on a single rank, for testing)."""
-        import os
-
+        rank; the class attribute `force_data_parallel` takes the same code path on a single rank, for testing)."""
         if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             return False
-        return torch.distributed.get_world_size() > 1 or os.environ.get("QR_PPO_FORCE_DDP") == "1"
+        return torch.distributed.get_world_size() > 1 or MfmaPpoUpdater.force_data_parallel
 
     def broadcast_parameters(self, src=0):
         """Make every rank start from rank `src`'s parameters and optimiser state."""

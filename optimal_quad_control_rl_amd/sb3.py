@@ -184,7 +184,7 @@ class PPO:
                  observation_dim=None,          # (+) size of the observation when there is no env (a policy-only model)
                  native_update="auto",          # (+) minibatch updates in libquadrace's matrix-core kernels when the shapes allow
                  fused_collect="auto",          # (+) rollouts as one closed-loop kernel
-                 precision=None,                # (+) "f16-operands" (default) | "f32": see below; QR_PPO_PRECISION sets the default
+                 precision=None,                # (+) "f16-operands" (default) | "f32": see below
                  _init_trainer=True):
         # precision: the hand-written policy / PPO kernels compute with f16 matrix-core operands and f32 accumulation (policy mean within
         # 7e-4 of the reference's float32 nn_forward, gradient cosine >= 0.9985 against float32 autograd).  precision="f32" is the
@@ -192,7 +192,7 @@ class PPO:
         # Adam) run in float32 on the device through torch (the arithmetic SB3 itself uses, R:783-795), still on the env's device
         # tensors and still around the HIP env kernels -- ~40x slower than the matrix-core path, there for A/B runs that ask whether an
         # outcome is the recipe's or the arithmetic's.
-        precision = precision or os.environ.get("QR_PPO_PRECISION", "f16-operands")
+        precision = precision or "f16-operands"
         if precision not in ("f16-operands", "f32"):
             raise ValueError("precision must be 'f16-operands' or 'f32'")
         self.precision = precision

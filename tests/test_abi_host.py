@@ -148,4 +148,19 @@ def test_library_reads_no_environment_variable():
     lib = build.build_native_locked()
     und = subprocess.run(["nm", "-D", "--undefined-only", lib], check=True, capture_output=True, text=True).stdout
     assert "getenv" not in und
+    # ... and neither does the Python package select a kernel form, a precision or a code path from the environment:
+    # the only read left is QR_PROBE_LIB in _lib.py, which lets the forensic tools load an older build whose ABI lacks round-5 entries
+    import glob
+    import os
+    import re
+
+    pkg = os.path.dirname(build.__file__)
+    for path in sorted(glob.glob(os.path.join(pkg, "*.py"))):
+        with open(path) as f:
+            src = f.read()
+        reads = re.findall(r"(?:os\.environ|getenv\()[^\n]*", src)
+        if os.path.basename(path) == "_lib.py":
+            assert all("QR_PROBE_LIB" in r for r in reads), reads
+        else:
+            assert not reads, (path, reads)
 

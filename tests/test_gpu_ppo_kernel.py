@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(L, rows, seed=0, max_minibatch=4096):
+def _setup(L, rows, seed=0, max_minibatch=4096, flags=0):
     from optimal_quad_control_rl_amd.ppo import ActorCritic, MfmaPpoUpdater
 
     dev = torch.device("cuda", 0)
@@ -24,7 +24,7 @@ def _setup(L, rows, seed=0, max_minibatch=4096):
         pol.pi[-1].weight.mul_(30.0)
         pol.log_std.copy_(torch.tensor([-0.3, 0.1, -0.5, 0.2], device=dev))
     ref = copy.deepcopy(pol)
-    up = MfmaPpoUpdater(pol, L, dev, max_minibatch=max_minibatch)
+    up = MfmaPpoUpdater(pol, L, dev, max_minibatch=max_minibatch, flags=flags)   # flags: QR_PPO_* of include/quadrace.h (1 = f32 partials)
     g = torch.Generator(device=dev).manual_seed(seed + 1)
     obs = torch.randn((rows, L), device=dev, generator=g) * 1.5
     with torch.no_grad():
@@ -76,16 +76,14 @@ def _flat_ref_grads(ref):
                                       (17, 16384, 0.2), (24, 32768, 50.0), (17, 6400, 0.2),    # 6400: 100 groups -> 25 chunks (no XCD mapping)
                                       (24, 5000, 0.2), (24, 5000, 50.0), (13, 100, 50.0)])      # 5000 = the reference's batch_size (R:792): 78 groups + 8 rows
 @pytest.mark.parametrize("partial", ["bf16", "f32"])
-def test_gradient_matches_autograd(L, B, clip, partial, monkeypatch):
+def test_gradient_matches_autograd(L, B, clip, partial):
     """Two references: (1) autograd through the same networks with f16-rounded GEMM operands -- what the kernels compute,
     so the comparison is tight; (2) plain f32 autograd -- there the f16 forward flips the ReLU state of units whose
     pre-activation is ~0 and (with clip = 0.2) the branch of ratios on the clip edge, a few-percent unbiased difference.
     clip = 50 switches the clipping off.  Both formats of the per-workgroup partial sums: bf16 (default; every partial carries a
     relative 2^-9 rounding, which a SCALAR parameter like the value head's bias sees undiluted: bound 1e-2 instead of 6e-3) and f32."""
-    if partial == "f32":
-        monkeypatch.setenv("QR_PPO_PARTIAL", "f32")
     rows = max(3000, 4 * B)
-    pol, ref, up, obs, act, old_lp, adv, ret = _setup(L, rows, seed=L, max_minibatch=max(4096, B))
+    pol, ref, up, obs, act, old_lp, adv, ret = _setup(L, rows, seed=L, max_minibatch=max(4096, B), flags=1 if partial == "f32" else 0)
     idx = torch.randperm(rows, device=obs.device)[:B].to(torch.int32).contiguous()
     vf_coef, ent_coef = 0.5, 0.01
     up.stats.zero_()
@@ -198,7 +196,7 @@ def test_grad_then_apply_equals_minibatch():
     assert torch.allclose(up_a.m, up_b.m, rtol=1e-5, atol=1e-9)
 
 
-def test_argument_validation(monkeypatch):
+def test_argument_validation():
     from optimal_quad_control_rl_amd import _lib
     from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
 
@@ -206,13 +204,9 @@ def test_argument_validation(monkeypatch):
     idx = torch.arange(40, device=obs.device, dtype=torch.int32)
     with pytest.raises(_lib.QuadraceError):
         up.grad(obs, act, old_lp, adv, ret, idx)                # fewer than 64 rows
-    monkeypatch.setenv("QR_PPO_GRAD4", "1")
-    up4 = MfmaPpoUpdater(pol, 17, obs.device, max_minibatch=4096)
-    monkeypatch.delenv("QR_PPO_GRAD4")
-    idx = torch.arange(100, device=obs.device, dtype=torch.int32)
-    with pytest.raises(_lib.QuadraceError):
-        up4.grad(obs, act, old_lp, adv, ret, idx)               # the earlier kernel forms need whole groups of 64 rows
-    up4.close()
+    for removed in (2, 4, 16):                                  # bits 2 / 4 selected the round 1-2 kernel forms (gone); 16 never existed
+        with pytest.raises(_lib.QuadraceError):
+            MfmaPpoUpdater(pol, 17, obs.device, max_minibatch=4096, flags=removed)
     idx = torch.arange(8192, device=obs.device, dtype=torch.int32) % 256
     with pytest.raises(_lib.QuadraceError):
         up.grad(obs, act, old_lp, adv, ret, idx.contiguous())   # larger than max_minibatch
@@ -359,72 +353,42 @@ def test_epoch_table_equals_per_minibatch_statistics_and_nonfinite_guard():
     assert up_a.status()[1] == 1 and torch.isfinite(up_a.theta).all()
 
 
-@pytest.mark.parametrize("L,B", [(17, 1024), (24, 16384), (36, 40000 // 64 * 64)])
-def test_fused_gradient_kernel_equals_split_form(L, B, monkeypatch):
-    """The fused gradient kernel (default) and the two-kernel form (QR_PPO_SPLIT=1: transposed operands through HBM scratch,
-    weight gradients by sample chunk) compute the same sums in a different order: gradients and minibatch statistics agree to
-    f32 summation noise -- including a ragged last pass (B = 39 936 rows = 312 pairs of sample groups over 128 workgroups)."""
+@pytest.mark.parametrize("L,B", [(17, 1024), (24, 16384), (13, 192), (36, 40000 // 64 * 64), (17, 65536), (24, 16384 + 128), (24, 5000)])
+def test_gradient_is_invariant_under_row_order(L, B):
+    """The gradient of a minibatch is a SUM over its rows: presenting the same rows in another order puts every row into a different
+    32-sample tile, workgroup and pass (B = 39 936: 312 pairs of sample groups over 128 workgroups, a ragged last pass; B = 65 536: four
+    passes per workgroup; 5 000 / 16 512: a masked partial group) and must give the same sums to f32 summation noise -- a check of the
+    tile / workgroup / pass bookkeeping that needs no second implementation (rounds 2-5 compared against the round-1/2 kernel forms,
+    removed in round 6).  f32 partials: the arithmetic itself; bf16 partials (the default): deterministic, identical statistics and
+    log_std gradient, and a difference bounded by the 2^-9 rounding of each per-workgroup partial."""
     from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
 
-    monkeypatch.setenv("QR_PPO_PARTIAL", "f32")   # the fused kernel's partials as f32: this test checks the ARITHMETIC (bf16: below)
-    pol, ref, up_fused, obs, act, old_lp, adv, ret = _setup(L, rows=max(B, 4096) * 2, seed=3, max_minibatch=B)
-    monkeypatch.delenv("QR_PPO_PARTIAL")
-    monkeypatch.setenv("QR_PPO_SPLIT", "1")
-    up_split = MfmaPpoUpdater(pol, L, obs.device, max_minibatch=B)
-    monkeypatch.delenv("QR_PPO_SPLIT")
+    pol, ref, up8, obs, act, old_lp, adv, ret = _setup(L, rows=max(B, 4096) * 2, seed=7, max_minibatch=B + 63, flags=1)
+    up8h = MfmaPpoUpdater(pol, L, obs.device, max_minibatch=B + 63)   # the default: per-workgroup partials leave as bf16
     idx = torch.randperm(obs.shape[0], device=obs.device)[:B].to(torch.int32)
-    g_f = up_fused.grad(obs, act, old_lp, adv, ret, idx, clip=0.2, vf_coef=0.5, ent_coef=0.01, stats=True).clone()
-    g_s = up_split.grad(obs, act, old_lp, adv, ret, idx, clip=0.2, vf_coef=0.5, ent_coef=0.01, stats=True).clone()
-    torch.cuda.synchronize()
-    n = g_f.numel() - 4
-    scale = float(g_s[:n].abs().max())
-    assert float((g_f[:n] - g_s[:n]).abs().max()) <= 2e-5 * scale + 1e-7
-    assert torch.allclose(g_f[n:], g_s[n:], rtol=1e-5, atol=1e-6)     # the four minibatch statistics
-    up_fused.close(); up_split.close()
-
-
-@pytest.mark.parametrize("L,B", [(17, 1024), (24, 16384), (13, 192), (36, 1024), (36, 40000 // 64 * 64), (17, 65536), (24, 16384 + 128)])
-def test_role_split_gradient_kernel_vs_four_wave_and_split_forms(L, B, monkeypatch):
-    """Round 3: the gradient kernel runs its workgroup as four chain waves (gather, forward, loss, backward) + four dW waves
-    (weight gradients on accumulators that stay in registers across the passes of a large minibatch; partial stores once, at the
-    end).  Against the round-2 kernels on the same rows: the two-kernel split form (QR_PPO_SPLIT=1) and the 4-wave fused form
-    (QR_PPO_GRAD4=1) -- same sums in different orders, so agreement to f32 summation noise, single- and multi-pass, and identical
-    minibatch statistics (the forward / loss arithmetic is the same code)."""
-    from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
-
-    monkeypatch.setenv("QR_PPO_PARTIAL", "f32")
-    pol, ref, up8, obs, act, old_lp, adv, ret = _setup(L, rows=max(B, 4096) * 2, seed=7, max_minibatch=B)
-    monkeypatch.delenv("QR_PPO_PARTIAL")
-    up8h = MfmaPpoUpdater(pol, L, obs.device, max_minibatch=B)   # the default: per-workgroup partials leave as bf16
-    monkeypatch.setenv("QR_PPO_GRAD4", "1")
-    up4 = MfmaPpoUpdater(pol, L, obs.device, max_minibatch=B)
-    monkeypatch.delenv("QR_PPO_GRAD4")
-    monkeypatch.setenv("QR_PPO_SPLIT", "1")
-    ups = MfmaPpoUpdater(pol, L, obs.device, max_minibatch=B)
-    monkeypatch.delenv("QR_PPO_SPLIT")
-    idx = torch.randperm(obs.shape[0], device=obs.device)[:B].to(torch.int32)
-    G = lambda u: u.grad(obs, act, old_lp, adv, ret, idx, clip=0.2, vf_coef=0.5, ent_coef=0.01, stats=True).clone()   # noqa: E731
-    g8, g8b, g4, gs = G(up8), G(up8), G(up4), G(ups)
+    idx2 = idx[torch.randperm(B, device=obs.device)].contiguous()
+    idx3 = idx.flip(0).contiguous()
+    G = lambda u, i: u.grad(obs, act, old_lp, adv, ret, i, clip=0.2, vf_coef=0.5, ent_coef=0.01, stats=True).clone()   # noqa: E731
+    g8, g8b, g8p, g8r = G(up8, idx), G(up8, idx), G(up8, idx2), G(up8, idx3)
     torch.cuda.synchronize()
     n = g8.numel() - 4
     assert torch.isfinite(g8).all() and float(g8[:n].abs().max()) > 0
     assert torch.equal(g8, g8b)                                       # deterministic (no atomics)
-    scale = float(gs[:n].abs().max())
-    assert float((g8[:n] - gs[:n]).abs().max()) <= 4e-6 * scale + 1e-7, (float((g8[:n] - gs[:n]).abs().max()), scale)
-    assert float((g8[:n] - g4[:n]).abs().max()) <= 4e-6 * scale + 1e-7
-    assert torch.allclose(g8[n:], gs[n:], rtol=1e-5, atol=1e-6) and torch.allclose(g8[n:], g4[n:], rtol=1e-5, atol=1e-6)
+    scale = float(g8[:n].abs().max())
+    for other in (g8p, g8r):
+        assert float((g8[:n] - other[:n]).abs().max()) <= 4e-6 * scale + 1e-7, (float((g8[:n] - other[:n]).abs().max()), scale)
+        assert torch.allclose(g8[n:], other[n:], rtol=2e-5, atol=1e-6)   # the four minibatch statistics
     # 16-bit partials (the default): each of the <= 128 per-workgroup partial sums is rounded to bf16 (relative 2^-9) before the
     # apply kernel's fixed-order f32 sum -- deterministic, same statistics, and a gradient that differs from the f32-partial one by
     # far less than the f16 operands already cost against plain f32 (cosine >= 0.999 there)
-    g8h, g8h2 = G(up8h), G(up8h)
+    g8h, g8h2 = G(up8h, idx), G(up8h, idx)
     torch.cuda.synchronize()
     assert torch.equal(g8h, g8h2) and torch.equal(g8h[n:], g8[n:])
     assert torch.equal(g8h[n - 4:n], g8[n - 4:n])                      # log_std does not travel through the partials
     err = float((g8h[:n] - g8[:n]).abs().max())
     cos = float(torch.dot(g8h[:n].double(), g8[:n].double()) / (g8h[:n].double().norm() * g8[:n].double().norm()))
     assert 0 < err <= 8e-3 * scale and cos > 1 - 1e-5, (err, scale, cos)   # |error| <= 2^-9 sum_q |partial_q|: partials cancel
-    for u in (up8, up8h, up4, ups):
-        u.close()
+    up8.close(); up8h.close()
 
 
 def test_fused_gradient_is_deterministic_and_stateless_across_minibatch_sizes():

@@ -47,7 +47,7 @@ def smi():
         keep = {}
         for k, v in c.items():
             kl = k.lower()
-            if "sclk" in kl or "mclk" in kl or "fclk" in kl or "power" in kl or "junction" in kl or "edge" in kl or "hbm" in kl or "socclk" in kl:
+            if "sclk" in kl or "mclk" in kl or "fclk" in kl or "power" in kl or "temperature" in kl or "socclk" in kl:
                 keep[k] = v
         return keep
     except Exception as e:  # noqa: BLE001
