@@ -66,6 +66,12 @@ int q3_step(q3_env* env, const float* actions_dev, void* states_out_dev, void* r
 int q3_step_many(q3_env* env, const float* actions_dev, int num_steps, void* rew_out_dev, uint8_t* done_out_dev,
                  void* states_out_dev, void* stream);
 
+/* K steps in one launch WITH what a trainer consumes (round 6): states_steps_out [K][N][16] T = env.states after every step (the
+ * array step_wait() returns, Q3:399 / Q3:744: the first state of the next episode for an env that finished), rew_out [K][N] T,
+ * done_out / trunc_out [K][N] (the last three may be NULL).  Same results as K x q3_step, bit for bit. */
+int q3_rollout(q3_env* env, const float* actions_dev, int num_steps, void* states_steps_out_dev, void* rew_out_dev,
+               uint8_t* done_out_dev, uint8_t* trunc_out_dev, void* stream);
+
 /* states [N][16] T, target [N] i32 (gates only; ignored / zero for hover), steps [N] i32; any may be NULL */
 int q3_get_state(q3_env* env, void* states_dev, int32_t* target_dev, int32_t* steps_dev, void* stream);
 int q3_set_state(q3_env* env, const void* states_dev, const int32_t* target_dev, const int32_t* steps_dev, void* stream);

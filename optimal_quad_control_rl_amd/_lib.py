@@ -88,6 +88,7 @@ SIGNATURES = {
     "q3_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "q3_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "q3_step_many": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
+    "q3_rollout": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "q3_get_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "q3_set_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
 }

@@ -410,23 +410,68 @@ __global__ __launch_bounds__(kQ3Block) void q3_step_kernel(Q3Params P, Q3Buffers
     if (trunc_out) trunc_out[i] = trunc ? 1 : 0;
 }
 
+// a wave's 64 rows = one contiguous [64][16] block of a row-major array: transposed through a wave-private LDS tile and written with
+// 16-byte-per-lane stores that cover whole cache lines (per-lane row stores would scatter 16-byte pieces over 64 lines per instruction)
 template <typename T>
+__device__ __forceinline__ void wave_store_rows(T* __restrict__ dst, size_t wave_row0, int rows_in_wave, typename RowTile<T>::V* tile,
+                                                int lane, const T s[16]) {
+    using R = RowTile<T>;
+    using V = typename R::V;
+    V v[R::kCh];
+    memcpy(v, s, sizeof(v));
+#pragma unroll
+    for (int k = 0; k < R::kCh; ++k) tile[lane * R::kStride + k] = v[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    V* d = reinterpret_cast<V*>(dst + (size_t)16 * wave_row0);
+#pragma unroll
+    for (int q = 0; q < R::kCh; ++q) {
+        const int cidx = q * 64 + lane;
+        if (cidx < rows_in_wave * R::kCh) {   // streaming store: nothing in this launch reads the rows again
+            typedef float f32x4n __attribute__((ext_vector_type(4)));
+            static_assert(sizeof(V) == sizeof(f32x4n), "16-byte chunks");
+            const V x = tile[(cidx / R::kCh) * R::kStride + (cidx % R::kCh)];
+            __builtin_nontemporal_store(__builtin_bit_cast(f32x4n, x), reinterpret_cast<f32x4n*>(d + cidx));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the tile may be rewritten
+}
+
+// kRows: also write env.states after EVERY step to states_steps [K][N][16] and the truncation flags to trunc_out [K][N] -- the rollout
+// a trainer consumes (q3_rollout); without them (q3_step_many) a step moves its action in and reward / done out only.
+template <typename T, bool kRows>
 __global__ __launch_bounds__(kQ3Block) void q3_rollout_kernel(Q3Params P, Q3Buffers<T> B, const float4* __restrict__ actions,
                                                               int K, T* __restrict__ rew_out, uint8_t* __restrict__ done_out,
+                                                              uint8_t* __restrict__ trunc_out, T* __restrict__ states_steps,
                                                               T* __restrict__ states_out) {
+    __shared__ typename RowTile<T>::V lds[kRows ? RowTile<T>::kLdsChunks : 1];
     const int i = blockIdx.x * kQ3Block + threadIdx.x;
-    if (i >= P.n) return;
+    const int lane = threadIdx.x & 63;
+    const int wave_row0 = i - lane;
+    if (wave_row0 >= P.n) return;               // whole wave past the end
+    const bool active = i < P.n;
+    if (!kRows && !active) return;
+    const int ii = active ? i : wave_row0;      // kRows: ragged-tail lanes shadow the wave's first env (they move rows of the tile)
+    const int rows_in_wave = min(64, P.n - wave_row0);
+    typename RowTile<T>::V* tile = lds + (kRows ? (threadIdx.x >> 6) * 64 * RowTile<T>::kStride : 0);
     Q3Env<T> e;
-    q3_load(B, i, e);
-    float4 a = actions[i];
+    q3_load(B, ii, e);
+    float4 a = actions[ii];
     for (int k = 0; k < K; ++k) {
         const float u[4] = {a.x, a.y, a.z, a.w};
-        if (k + 1 < K) a = actions[(size_t)(k + 1) * P.n + i];  // next step's action is in flight during this step
+        if (k + 1 < K) a = actions[(size_t)(k + 1) * P.n + ii];  // next step's action is in flight during this step
         bool done, trunc;
-        const T reward = q3_step_env(P, i, e, u, done, trunc);
-        if (rew_out) rew_out[(size_t)k * P.n + i] = reward;
-        if (done_out) done_out[(size_t)k * P.n + i] = done ? 1 : 0;
+        const T reward = q3_step_env(P, ii, e, u, done, trunc);
+        if (active) {
+            if (rew_out) rew_out[(size_t)k * P.n + i] = reward;
+            if (done_out) done_out[(size_t)k * P.n + i] = done ? 1 : 0;
+            if (kRows && trunc_out) trunc_out[(size_t)k * P.n + i] = trunc ? 1 : 0;
+        }
+        if constexpr (kRows) wave_store_rows<T>(states_steps + (size_t)k * P.n * 16, (size_t)wave_row0, rows_in_wave, tile, lane, e.s);
     }
+    if (!active) return;
     q3_store(B, i, e);
     if (states_out) store_row<T>(states_out, i, e.s);
 }
@@ -633,21 +678,41 @@ int q3_step(q3_env* e, const float* actions, void* states_out, void* rew_out, ui
     return QR_OK;
 }
 
-int q3_step_many(q3_env* e, const float* actions, int K, void* rew_out, uint8_t* done_out, void* states_out, void* stream) {
+static int q3_launch_rollout(q3_env* e, const float* actions, int K, void* states_steps, void* rew_out, uint8_t* done_out,
+                             uint8_t* trunc_out, void* states_out, void* stream) {
     if (int rc = q3_ready(e)) return rc;
     if (!actions) return q3fail(QR_E_INVALID, "actions_dev is null");
     if (K < 1) return q3fail(QR_E_INVALID, "num_steps must be >= 1");
     Q3_HIP(hipSetDevice(e->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float4* a = reinterpret_cast<const float4*>(actions);
-    if (e->kind == Q3_KIND_HOVER)
-        q3_rollout_kernel<double><<<e->grid(), kQ3Block, 0, st>>>(e->P, e->buffers<double>(), a, K, static_cast<double*>(rew_out),
-                                                                 done_out, static_cast<double*>(states_out));
-    else
-        q3_rollout_kernel<float><<<e->grid(), kQ3Block, 0, st>>>(e->P, e->buffers<float>(), a, K, static_cast<float*>(rew_out),
-                                                                done_out, static_cast<float*>(states_out));
+    if (e->kind == Q3_KIND_HOVER) {
+        if (states_steps)
+            q3_rollout_kernel<double, true><<<e->grid(), kQ3Block, 0, st>>>(e->P, e->buffers<double>(), a, K, static_cast<double*>(rew_out), done_out,
+                                                                           trunc_out, static_cast<double*>(states_steps), static_cast<double*>(states_out));
+        else
+            q3_rollout_kernel<double, false><<<e->grid(), kQ3Block, 0, st>>>(e->P, e->buffers<double>(), a, K, static_cast<double*>(rew_out), done_out,
+                                                                            nullptr, nullptr, static_cast<double*>(states_out));
+    } else {
+        if (states_steps)
+            q3_rollout_kernel<float, true><<<e->grid(), kQ3Block, 0, st>>>(e->P, e->buffers<float>(), a, K, static_cast<float*>(rew_out), done_out,
+                                                                          trunc_out, static_cast<float*>(states_steps), static_cast<float*>(states_out));
+        else
+            q3_rollout_kernel<float, false><<<e->grid(), kQ3Block, 0, st>>>(e->P, e->buffers<float>(), a, K, static_cast<float*>(rew_out), done_out,
+                                                                           nullptr, nullptr, static_cast<float*>(states_out));
+    }
     Q3_HIP(hipGetLastError());
     return QR_OK;
+}
+
+int q3_step_many(q3_env* e, const float* actions, int K, void* rew_out, uint8_t* done_out, void* states_out, void* stream) {
+    return q3_launch_rollout(e, actions, K, nullptr, rew_out, done_out, nullptr, states_out, stream);
+}
+
+int q3_rollout(q3_env* e, const float* actions, int K, void* states_steps_out, void* rew_out, uint8_t* done_out, uint8_t* trunc_out,
+               void* stream) {
+    if (!states_steps_out) return q3fail(QR_E_INVALID, "states_steps_out_dev is null (q3_step_many is the form without per-step rows)");
+    return q3_launch_rollout(e, actions, K, states_steps_out, rew_out, done_out, trunc_out, nullptr, stream);
 }
 
 int q3_get_state(q3_env* e, void* states, int32_t* target, int32_t* steps, void* stream) {

@@ -167,6 +167,22 @@ class _Quad3DBase(_Base):
                                         _ptr(self._states_d) if want_states else None, self._stream()))
         return rew, done, (self._states_d if want_states else None)
 
+    def rollout_states_device(self, actions, out=None):
+        """K steps in ONE kernel WITH the per-step rows a trainer consumes (q3_rollout): actions float32 CUDA [K,N,4] ->
+        (states [K,N,16] = what step_wait() returns after each step, rewards [K,N], dones [K,N] u8, truncs [K,N] u8).  Bit for bit
+        K x step_device()."""
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.dim() != 3 or \
+                tuple(actions.shape[1:]) != (self.num_envs, 4) or actions.device != self.device:
+            raise ValueError("actions must be a contiguous float32 tensor [K, num_envs, 4] on the env's device")
+        K, n = int(actions.shape[0]), self.num_envs
+        if out is None:
+            out = (torch.empty((K, n, 16), dtype=self.DTYPE, device=self.device), torch.empty((K, n), dtype=self.DTYPE, device=self.device),
+                   torch.empty((K, n), dtype=torch.uint8, device=self.device), torch.empty((K, n), dtype=torch.uint8, device=self.device))
+        st, rew, done, trunc = out
+        _lib.check(self._L.q3_rollout(self._h, _ptr(actions), K, _ptr(st), _ptr(rew), _ptr(done), _ptr(trunc), self._stream()))
+        self._states_d.copy_(st[K - 1])
+        return out
+
     # ---- the VecEnv surface of the reference ---------------------------------------------------------------------------
     def reset_(self, dones):
         return self.reset_device(np.asarray(dones).astype(np.uint8)).cpu().numpy()

@@ -160,6 +160,35 @@ def test_determinism_sharding_and_rollout_equivalence(kind):
     assert torch.isfinite(s1).all(dim=1).float().mean() > 0.999   # (a NaN state persists until max_steps, as upstream)
 
 
+@pytest.mark.parametrize("kind", ["hover", "gates"])
+@pytest.mark.parametrize("n", [1000, 4096])
+def test_rollout_with_per_step_rows_equals_k_steps(kind, n):
+    """q3_rollout (round 6): the fused K-step kernel WITH what a trainer consumes -- env.states after every step [K][N][16], rewards,
+    dones and truncation flags -- equals K x q3_step bit for bit, through auto-resets, for a ragged env count (1 000: part-filled last
+    workgroup and wave) and a full one; and leaves the handle in the same state (the next step agrees too)."""
+    trk = pq.gates_track()
+    K = 40
+    dev = torch.device("cuda", 0)
+    acts = (torch.rand((K, n, 4), device=dev, generator=torch.Generator(device=dev).manual_seed(3)) * 2 - 1) * 0.3
+    e = ProductImpl(kind, n, trk, seed=77).env
+    e.max_steps = 25
+    e.reset_device()
+    rows = []
+    for k in range(K):
+        rows.append([t.clone() for t in e.step_device(acts[k].contiguous())])
+    nxt = [t.clone() for t in e.step_device(acts[0].contiguous())]
+    f = ProductImpl(kind, n, trk, seed=77).env
+    f.max_steps = 25
+    f.reset_device()
+    st, rew, done, trunc = f.rollout_states_device(acts)
+    for k in range(K):
+        for got, want in zip((st[k], rew[k], done[k], trunc[k]), rows[k]):
+            assert torch.equal(got, want), (kind, n, k)
+    assert int(done.sum()) >= n and int(trunc.sum()) > 0          # every env finished at least once; time limits were hit
+    for got, want in zip(f.step_device(acts[0].contiguous()), nxt):
+        assert torch.equal(got, want)
+
+
 def test_vecenv_surface_matches_reference_classes():
     from optimal_quad_control_rl_amd import Quadcopter3DVec, Quadcopter3DVecGates
 
