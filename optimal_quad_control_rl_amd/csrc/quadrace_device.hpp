@@ -198,9 +198,18 @@ struct Env {
     static constexpr int S = (V == kE2E) ? 16 : 13;
     float s[S];   // world state
     float d[6];   // constant external disturbances (E2E only)
+    float od[4];  // E2E, kernels that keep the env in registers over many steps: the observation columns of (Mx, My, Mz, Fz) -- constant
+                  // within an episode, so computed at load / reset instead of in every step (disturbance_obs_values(); observe_with<.., true>)
     int target, steps;
     uint32_t episode;  // resets so far (24 bits are persisted next to the target gate)
 };
+
+// R:414-448: (Mx, My, Mz, Fz) mapped to [-1,1] by their ranges: 2*(d - lo)/(hi - lo) - 1 with the host-precomputed 1/(hi - lo)
+__device__ __forceinline__ void disturbance_obs_values(const Params& P, const float* d, float* od) {
+    const int col[4] = {0, 1, 2, 5};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) od[c] = fmaf(2.0f * (d[col[c]] - P.obs_lo[c]), P.obs_inv[c], -1.0f);
+}
 
 // value of one reset draw from its table row (lo, span, add, mul): ((lo + span*u) + add) * mul, no FMA contraction
 __device__ __forceinline__ float reset_value(const float4 row, uint32_t bits) {
@@ -249,16 +258,27 @@ __device__ __forceinline__ void reset_env(const Params& P, const float* __restri
 // Auto-reset from a per-lane STASH of the lane's own next reset draws (kernels that keep the env in registers over many steps and
 // have the registers: 24 / 16 floats): a reset is a masked copy; the stash is refilled for the whole wave, and only when a lane that
 // has used its stash up terminates again.  reset_values() for the lane's CURRENT episode = what reset_env() would draw: bit-identical.
+// stash_od (E2E, optional): the disturbance observation columns of the stashed episode (Env::od), formed at refill time
 template <int V>
 __device__ __forceinline__ void reset_from_stash(const Params& P, const float* __restrict__ rtab, bool need, Env<V>& e,
-                                                 uint32_t gid_lo, uint32_t gid_hi, float* __restrict__ stash, bool& stash_ok) {
+                                                 uint32_t gid_lo, uint32_t gid_hi, float* __restrict__ stash, bool& stash_ok,
+                                                 float* __restrict__ stash_od = nullptr) {
     if (__ballot(need) == 0ull) return;                 // wave-uniform
     if (__ballot(need && !stash_ok) != 0ull) {          // refill ALL lanes (a lane whose stash is intact recomputes the same values)
         reset_values<V>(P, rtab, e.episode, gid_lo, gid_hi, stash);
+        if constexpr (V == kE2E) {
+            if (stash_od) disturbance_obs_values(P, stash + 16, stash_od);
+        }
         stash_ok = true;
     }
     if (need) {
         assign_reset<V>(e, stash);
+        if constexpr (V == kE2E) {
+            if (stash_od) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) e.od[c] = stash_od[c];
+            }
+        }
         stash_ok = false;
     }
 }
@@ -781,7 +801,7 @@ __device__ __forceinline__ void read_gates_ahead(const Params& P, const float* _
     }
 }
 
-template <int V, int GA>
+template <int V, int GA, bool kCachedOd = false>
 __device__ __forceinline__ void observe_with(const Params& P, const GateRow& g, const float4* rel, const Env<V>& e, float* o) {
     constexpr int S = Env<V>::S;
     const float4 g0 = g.g0;
@@ -816,10 +836,12 @@ __device__ __forceinline__ void observe_with(const Params& P, const GateRow& g, 
     }
     if constexpr (V == kE2E) {  // R:414-448: (Mx, My, Mz, Fz) mapped to [-1,1] by their ranges
         constexpr int base = S + 4 * GA;
-        const int col[4] = {0, 1, 2, 5};
+        if constexpr (kCachedOd) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)  // 2*(d - lo)/(hi - lo) - 1 with the host-precomputed 1/(hi - lo)
-            o[base + c] = fmaf(2.0f * (e.d[col[c]] - P.obs_lo[c]), P.obs_inv[c], -1.0f);
+            for (int c = 0; c < 4; ++c) o[base + c] = e.od[c];
+        } else {
+            disturbance_obs_values(P, e.d, o + base);
+        }
     }
 }
 template <int V, int GA>

@@ -66,6 +66,20 @@ __device__ __forceinline__ void store_dist(const Params& P, int i, const Env<V>&
     }
 }
 
+// The final state of a K-step kernel leaves in 16-byte tuples.  Left alone, the compiler forms those tuples INSIDE the step loop: the
+// loop's exit values (a phi of the reset / no-reset paths) were copied into four register quads on every step -- 18 moves of ~700
+// instructions, 60 on a step with a reset -- for a store that happens once per launch.  Passing the values through an empty asm
+// defines them behind the loop (round 6: rollout_fast_mlp_kernel 701 -> 686 instructions per step, 277 -> 163 v_mov in the kernel).
+template <int V>
+__device__ __forceinline__ void define_exit_values(Env<V>& e) {
+#pragma unroll
+    for (int q = 0; q < Env<V>::S; ++q) asm volatile("" : "+v"(e.s[q]));
+    if constexpr (V == kE2E) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) asm volatile("" : "+v"(e.d[q]));
+    }
+}
+
 template <int V, int GA>
 constexpr int obs_len() { return (V == kE2E) ? 16 + 4 * GA + 4 : 13 + 4 * GA; }
 
@@ -335,6 +349,7 @@ __device__ __forceinline__ void rollout_body_impl(Params P, int K, const float4*
     }
     QR_CLOCK_STAMP(P, 2);
     if (!active) return;
+    define_exit_values<V>(e);
     P.ts[i] = pack_ts<V>(e);
     if (P.flags & kFlagPause) return;
     store_world<V>(P, i, e);
@@ -487,11 +502,14 @@ __device__ __forceinline__ void rollout_fast_body_impl(Params P, int K, const fl
     const uint32_t gid_lo = P.gid_lo + (uint32_t)ii;
     const uint32_t gid_hi = P.gid_hi + (gid_lo < P.gid_lo ? 1u : 0u);
     float stash[kLean ? 1 : reset_value_count<V>()];
+    float stash_od[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // E2E: the stashed episode's disturbance observation columns (Env::od)
     bool stash_ok = false;
     if constexpr (!kLean) {
         reset_values<V>(P, rtab, (uint32_t)ts0.x >> 8, gid_lo, gid_hi, stash);   // = what reset_from_stash() would draw on first use
+        if constexpr (V == kE2E) disturbance_obs_values(P, stash + 16, stash_od);
         stash_ok = true;
     }
+    if constexpr (V == kE2E) disturbance_obs_values(P, e.d, e.od);   // constant within an episode: refreshed by the resets below
     uint32_t* who = nullptr;
     float4* pool = nullptr;
     if constexpr (kLean) {
@@ -566,8 +584,14 @@ __device__ __forceinline__ void rollout_fast_body_impl(Params P, int K, const fl
 #pragma unroll
             for (int q = 0; q < S; ++q) e.s[q] = nw[q];
             any_reset |= done;
-            if constexpr (kLean) reset_pooled<V>(P, rtab, who, pool, lane, done && active, e, gid_lo, gid_hi, pool_ok);
-            else reset_from_stash<V>(P, rtab, done && active, e, gid_lo, gid_hi, stash, stash_ok);
+            if constexpr (kLean) {
+                reset_pooled<V>(P, rtab, who, pool, lane, done && active, e, gid_lo, gid_hi, pool_ok);
+                if constexpr (V == kE2E) {
+                    if (done && active) disturbance_obs_values(P, e.d, e.od);
+                }
+            } else {
+                reset_from_stash<V>(P, rtab, done && active, e, gid_lo, gid_hi, stash, stash_ok, (V == kE2E) ? stash_od : nullptr);
+            }
             if (active) {
                 stream_store(rew_step + i, reward);
                 stream_store(done_step + i, (uint8_t)(done ? 1 : 0));
@@ -578,7 +602,7 @@ __device__ __forceinline__ void rollout_fast_body_impl(Params P, int K, const fl
             gate = read_gate_row(gates, e.target);
             read_gates_ahead<GA>(P, gates, e.target, rel);
             float o[L];
-            observe_with<V, GA>(P, gate, rel, e, o);
+            observe_with<V, GA, true>(P, gate, rel, e, o);
             if (full_wave) {
                 obs_tile_store_rows<V, GA>(tile, lane, o);   // streamed out in the middle of the NEXT step (worth ~600 cycles per step, r04)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -597,6 +621,7 @@ __device__ __forceinline__ void rollout_fast_body_impl(Params P, int K, const fl
     QR_CLOCK_STAMP(P, 2);
     if (pending) obs_tile_flush<V, GA>(tile, obs_step - n * L, (size_t)wave_first, lane);
     if (!active) return;
+    define_exit_values<V>(e);
     P.ts[i] = pack_ts<V>(e);
     store_world<V>(P, i, e);
     if (any_reset) store_dist<V>(P, i, e);
@@ -798,6 +823,7 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
         else if (active) store_obs<V, GA>(last_obs_out, i, o);
     }
     if (!active) return;
+    define_exit_values<V>(e);
     P.ts[i] = pack_ts<V>(e);
     store_world<V>(P, i, e);
     if (any_reset) store_dist<V>(P, i, e);

@@ -93,9 +93,18 @@ void run_half(const char* name, float* out, unsigned long long* cyc, double per_
 
 // ---------------------------------------------------------------- (b) wave-specialised pair
 // a "VALU instruction" of the model streams: 8 independent v_fma chains, round robin (ILP like the step's)
+// (round 6, second model) the real step is not issue-bound but a MIX: half of its instructions sit in dependent chains (8.4 ticks each for a
+// lone wave), half have an independent neighbour (5.0): 6.7 ticks per instruction on average, as measured (3 820 cycles / 572).  V8 = four
+// dependent + four independent v_fma; -DPAIR_ILP8 restores the first model (eight independent chains, 5.2 ticks per instruction).
+#ifdef PAIR_ILP8
 #define V8(h, x) asm volatile("v_fma_f32 %0, %0, %8, %0\n v_fma_f32 %1, %1, %8, %1\n v_fma_f32 %2, %2, %8, %2\n v_fma_f32 %3, %3, %8, %3\n" \
                               "v_fma_f32 %4, %4, %8, %4\n v_fma_f32 %5, %5, %8, %5\n v_fma_f32 %6, %6, %8, %6\n v_fma_f32 %7, %7, %8, %7" \
                               : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]) : "v"(x))
+#else
+#define V8(h, x) asm volatile("v_fma_f32 %0, %0, %8, %0\n v_fma_f32 %0, %0, %8, %0\n v_fma_f32 %0, %0, %8, %0\n v_fma_f32 %0, %0, %8, %0\n" \
+                              "v_fma_f32 %4, %4, %8, %4\n v_fma_f32 %5, %5, %8, %5\n v_fma_f32 %6, %6, %8, %6\n v_fma_f32 %7, %7, %8, %7" \
+                              : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]) : "v"(x))
+#endif
 #define PERM8(h) asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n" \
                               "v_permlane32_swap_b32 %0, %2\n v_permlane32_swap_b32 %1, %3\n v_permlane32_swap_b32 %4, %6\n v_permlane32_swap_b32 %5, %7" \
                               : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]))
