@@ -801,14 +801,14 @@ def run(args, rt, env_factory=make_env, closed_loop=True):
                 result["ppo_update"] = ppo_measure(L, 16384, 65536 * 8, 100)
             except Exception as ex:  # pragma: no cover
                 result["ppo_update"] = {"error": repr(ex)}
-            try:
-                result["config5"] = config5_probe(n)
-                result["config5_mb65536"] = config5_probe(n, mb=65536)
-                # the reference splits a rollout into 20 minibatches per epoch (100 envs x 1000 steps / batch_size 5000, R:785-792):
-                # 40 steps per rollout give exactly that split with whole 64-row groups (n x 40 / 20 = 2 n rows per minibatch)
-                result["config5_ref_ratio"] = config5_probe(n, mb=(n * 40) // 20, n_steps=40)
-            except Exception as ex:  # pragma: no cover
-                result["config5"] = {"error": repr(ex)}
+            # each probe under its own guard: a failure of a later, larger one must not erase the results already measured
+            # the reference splits a rollout into 20 minibatches per epoch (100 envs x 1000 steps / batch_size 5000, R:785-792):
+            # 40 steps per rollout give exactly that split with whole 64-row groups (n x 40 / 20 = 2 n rows per minibatch)
+            for key, kw in (("config5", {}), ("config5_mb65536", {"mb": 65536}), ("config5_ref_ratio", {"mb": (n * 40) // 20, "n_steps": 40})):
+                try:
+                    result[key] = config5_probe(n, **kw)
+                except Exception as ex:  # pragma: no cover
+                    result[key] = {"error": repr(ex)}
             try:
                 result["host_numpy_path"] = host_path_probe(args.variant, n, ga)
             except Exception as ex:  # pragma: no cover

@@ -43,7 +43,10 @@ NO_VGPR_FORM = set()
 OBJ_DIR = os.path.join(PKG, "_obj")   # per-source objects (git- and gpurun-ignored): only stale sources are recompiled
 
 
-LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+def _llvm(tool):
+    """An LLVM tool of the hipcc in use (isa_lint.llvm_bin: asked of hipcc itself, checked for existence)."""
+    from . import isa_lint
+    return os.path.join(isa_lint.llvm_bin(_hipcc()), tool)
 
 
 def _deps(src):
@@ -71,19 +74,26 @@ def _compile_one(src, obj, flags, verbose=False):
         text, n_fixed = isa_lint.fix_asm_text(f.read())
     with open(dev_s, "w") as f:
         f.write(text)
-    _run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", dev_s, "-o", dev_o], verbose)
-    _run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", dev_o, "-o", hsaco], verbose)
-    _run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+    _run([_llvm("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", dev_s, "-o", dev_o], verbose)
+    _run([_llvm("lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", dev_o, "-o", hsaco], verbose)
+    _run([_llvm("clang-offload-bundler"), "-type=o", "-bundle-align=4096",
           "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + hsaco, "-output=" + fatbin], verbose)
     _run([_hipcc(), *flags, "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin, "-c", path, "-o", obj], verbose)
     if verbose:
         print("%s: %d packed-f32 instruction(s) rewritten" % (src, n_fixed))
+    with open(base + ".haskernels", "w") as f:   # does this source contribute a device code object with kernels? (the final lint counts them)
+        f.write("1" if ".amdhsa_kernel" in text else "0")
     return n_fixed
 
 
-def _obj(src, extra_flags=()):
+def _obj(src, extra_flags=(), variant=None):
+    """Object path of a source: the product's objects directly under _obj/, those of an experiment / profiling variant (`out=`) in a
+    subdirectory of their own, so that a variant built with the product's flags never shares intermediate files with a concurrent
+    product build."""
     tag = ("_" + "_".join(f.lstrip("-") for f in extra_flags)) if extra_flags else ""
-    return os.path.join(OBJ_DIR, os.path.splitext(src)[0] + tag.replace("=", "-").replace("/", "-") + ".o")
+    d = os.path.join(OBJ_DIR, "variant_" + variant) if variant else OBJ_DIR
+    os.makedirs(d, exist_ok=True)
+    return os.path.join(d, os.path.splitext(src)[0] + tag.replace("=", "-").replace("/", "-") + ".o")
 
 
 def needs_build():
@@ -105,7 +115,8 @@ def build_native(force=False, verbose=False, extra_flags=(), out=None, drop_flag
     objs, jobs = [], []
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:   # sources compile concurrently
         for src in SOURCES:
-            obj = _obj(src, tuple(extra_flags) + tuple("no" + f for f in drop_flags))
+            obj = _obj(src, tuple(extra_flags) + tuple("no" + f for f in drop_flags),
+                       variant=os.path.splitext(os.path.basename(out))[0] if out else None)
             objs.append(obj)
             if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src)):
                 flags = [f for f in compile_flags if not (src in NO_VGPR_FORM and f in ("-mllvm", "-amdgpu-mfma-vgpr-form"))]
@@ -119,7 +130,15 @@ def build_native(force=False, verbose=False, extra_flags=(), out=None, drop_flag
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    bad = isa_lint.lint_library(tmp)   # the final code objects, by disassembly: whatever the compiler and the rewrite did
+    stats = {}
+    bad = isa_lint.lint_library(tmp, stats)   # the final code objects, by disassembly: whatever the compiler and the rewrite did
+    expected = sum(open(o[:-2] + ".haskernels").read() == "1" for o in objs if os.path.exists(o[:-2] + ".haskernels"))
+    if stats["code_objects"] < max(1, expected):
+        os.unlink(tmp)
+        raise RuntimeError("isa_lint saw %d code objects in the linked library, %d sources contain kernels: the lint does not cover the "
+                           "library (bundle layout changed?)" % (stats["code_objects"], expected))
+    if verbose:
+        print("isa_lint: %(code_objects)d code objects, %(symbols)d symbols, %(instructions)d instructions, %(packed_f32)d packed-f32" % stats)
     if bad:
         os.unlink(tmp)
         raise RuntimeError("libquadrace.so would contain %d hazardous instruction(s) (isa_lint.py: packed-f32 form / store-data overwrite): %s ..." % (len(bad), bad[:3]))

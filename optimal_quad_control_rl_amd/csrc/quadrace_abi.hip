@@ -311,11 +311,16 @@ int qr_set_residual(qr_env* e, const float* blob, size_t n_floats) {
         return QR_OK;
     }
     if (n_floats != QR_RESIDUAL_FLOATS) return fail(QR_E_INVALID, "qr_set_residual: expected 740 floats");
-    // layer 1 runs on f16 matrix-core operands (each weight as two f16 pieces): a weight that is not finite or beyond the f16 range
-    // would turn into inf - inf = NaN pieces where the reference's float32 layer gives a finite value -- refused, not approximated
-    for (size_t k = 0; k < n_floats; ++k)
-        if (!std::isfinite(blob[k]) || std::fabs(blob[k]) > 65504.0f)
-            return fail(QR_E_INVALID, "qr_set_residual: weights must be finite and within +-65504 (the f16 range of the matrix-core operands)");
+    // layer 1 (W1, b1 of both networks) runs on f16 matrix-core operands, each weight as two f16 pieces: a weight beyond the f16 range
+    // would turn into inf - inf = NaN pieces where the reference's float32 layer gives a finite value -- refused, not approximated.
+    // Layer 2 (W2, b2) is float32 arithmetic like the reference's: any finite value is accepted there.
+    for (size_t k = 0; k < n_floats; ++k) {
+        const bool layer1 = k < 224 + 32 || (k >= 289 && k < 289 + 320 + 32);
+        if (!std::isfinite(blob[k]))
+            return fail(QR_E_INVALID, "qr_set_residual: weights must be finite");
+        if (layer1 && std::fabs(blob[k]) > 65504.0f)
+            return fail(QR_E_INVALID, "qr_set_residual: first-layer weights and biases must be within +-65504 (the f16 range of the matrix-core operands)");
+    }
     // reference order (c_code/nn_thrust.c, nn_moment.c): W1[out][in], b1, W2[out][in], b2 per network
     const float* tW1 = blob;         const float* tb1 = tW1 + 224;
     const float* tW2 = tb1 + 32;     const float* tb2 = tW2 + 32;

@@ -235,9 +235,18 @@ def test_residual_weights_outside_the_f16_range_are_refused(residual_blob):
 
     env = Quadcopter3DGates(64, *square_track(), gates_ahead=1, seed=1, infos_mode="none")
     for bad in (np.inf, -np.inf, np.nan, 7.0e4, -1.0e5):
+        for k in (300, 10, 240, 620):                                 # first-layer weights / biases of either network
+            b = np.array(residual_blob, np.float32, copy=True)
+            b[k] = bad
+            with pytest.raises(QuadraceError, match="finite" if not np.isfinite(bad) else "f16 range"):
+                env.set_residual(b)
+    # the second layer is float32 arithmetic like the reference's: large finite values pass, non-finite ones do not
+    for k in (260, 288, 650, 738):
         b = np.array(residual_blob, np.float32, copy=True)
-        b[300] = bad
-        with pytest.raises(QuadraceError, match="f16 range"):
+        b[k] = 1.0e5
+        env.set_residual(b)
+        b[k] = np.inf
+        with pytest.raises(QuadraceError, match="finite"):
             env.set_residual(b)
     env.set_residual(residual_blob)
     env.close()
