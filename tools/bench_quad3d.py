@@ -27,6 +27,9 @@ BYTES = {"hover": 417, "gates": 229}   # per-step kernel: algorithmic = measured
 # (16 B in) and its reward + done flag out: hover 16 + 8 + 1, gates 16 + 4 + 1 -- that kernel is VALU / latency bound
 # (f64 arithmetic for hover), and an HBM fraction built on the per-step bytes would exceed 1
 FUSED_BYTES = {"hover": 25, "gates": 21}
+# fused rollout WITH the rows a trainer consumes (q3_rollout, round 6): action 16 B in; env.states after the step (16 x 8 / 16 x 4),
+# reward, done and truncation flag out -- the kernel whose HBM fraction is comparable to the race env's fused rollout
+ROLLOUT_BYTES = {"hover": 16 + 128 + 8 + 1 + 1, "gates": 16 + 64 + 4 + 1 + 1}
 VALU_F32_PEAK_TF, VALU_F64_PEAK_TF = 157.3, 78.6
 
 
@@ -93,6 +96,16 @@ def measure(kind, n=65536, K=200, repeats=3, cpu_seconds=3.0):
                                          "flop_per_env_step": flop,
                                          "hbm": {"achieved": fgbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fgbs / HBM_PEAK_GBS,
                                                  "bytes_per_env_step": FUSED_BYTES[kind]}}}
+    env.rollout_states_device(acts[: min(K, 64)])
+    Kr = min(K, 256 if kind == "hover" else 512)        # [K][N][16] rows: 128 / 64 B per env-step
+    bufs = env.rollout_states_device(acts[:Kr])
+    t_rows = _time_region(lambda: env.rollout_states_device(acts[:Kr], bufs), repeats)
+    rgbs = ROLLOUT_BYTES[kind] * n * Kr / t_rows / 1e9
+    out["fused_rollout_with_rows"] = {"what": "q3_rollout: K steps in one kernel writing env.states, reward, done, trunc of EVERY step (what a trainer consumes)",
+                                      "steps": Kr, "us_per_step": t_rows / Kr * 1e6, "env_steps_per_s": n * Kr / t_rows,
+                                      "roofline": {"bound": "hbm", "achieved": rgbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rgbs / HBM_PEAK_GBS,
+                                                   "bytes_per_env_step": ROLLOUT_BYTES[kind]}}
+    del bufs
     if cpu_seconds > 0:
         from oracle import quad3d as q3
 
