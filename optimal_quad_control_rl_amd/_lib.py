@@ -57,6 +57,7 @@ SIGNATURES = {
     "qr_policy_last_error": (C.c_char_p, []),
     "qr_policy_set_weights": (C.c_int, [_vp] + [_f32p] * 8),
     "qr_policy_forward": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
+    "qr_policy_forward_f32class": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "qr_rollout_policy": (C.c_int, [_vp, _vp, C.c_int32, _f32p, C.c_uint64, C.c_uint64, C.c_int32, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp]),
     "qr_profile_steps": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _f32p, _f32p]),
@@ -94,7 +95,7 @@ SIGNATURES = {
 }
 
 
-ADDED_IN_ROUND_5 = ("qr_set_rollout_form", "qr_ppo_create_ex")
+ADDED_IN_ROUND_5 = ("qr_set_rollout_form", "qr_ppo_create_ex", "q3_rollout", "qr_policy_forward_f32class")   # (and round 6)
 
 
 class QuadraceError(RuntimeError):

@@ -74,13 +74,146 @@ hipError_t launch_policy(int L, const half8* w, int n, const float* obs, float* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Reference-precision ("f32-class") forward of the same network (round 6).  The reference evaluates the policy
+// in float32 (SB3 / torch, R:783-795; generated C twin c_code/neural_network.c:397-430); policy_kernel above rounds every operand to
+// one f16 (max |d mean| 7e-4 against nn_forward).  Here BOTH operands of every layer are split into two f16 pieces, exactly like
+// layer 1 of the residual MLPs (quadrace_device.hpp residual_mlp):
+//     x = X0 + X1,  X0 = f16(x), X1 = f16(x - X0)          w = W0 + W1 (host side, once)
+//     w x  ~  W0 X0 + W1 X0 + W0 X1                         (the dropped W1 X1 is <= 2^-22 |w x|; f32 accumulation on the matrix core)
+// -- three matrix instructions per K-step instead of one, same operand layouts, same "accumulator registers are the next layer's k-slots"
+// trick, so the chain still never leaves the registers.  The low-piece image W1 is read from global memory (80 KB, L2-resident, shared by
+// every workgroup); W0 is staged in LDS like policy_kernel's image.  Not hand-scheduled: this is the accuracy path (evaluation,
+// precision="f32" collection), the f16 kernel stays the throughput path.
+// |x| beyond the f16 range: X0 saturates at +-65504 and X1 carries the rest (up to 131 008: no observation or activation gets there).
+__device__ __forceinline__ void split_pack(const float* v, half8& p0, half8& p1) {
+    float r[8];
+    p0 = sat_pack(v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = v[j] - (float)p0[j];   // exact in f32 (NaN -> p0 = 0, r = NaN -> sat_pack gives 0)
+    p1 = sat_pack(r);
+}
+
+template <int KS>
+__device__ __forceinline__ void policy_layer_f32class(const half8* __restrict__ W0, const half8* __restrict__ W1g, int lane,
+                                                      const half8 (&in0)[2][KS], const half8 (&in1)[2][KS], half8 (&out0)[2][8],
+                                                      half8 (&out1)[2][8]) {
+    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x16p acc[2] = {zero, zero};
+#pragma unroll
+        for (int g = 0; g < KS; ++g) {
+            const half8 a0 = W0[(t * KS + g) * 64 + lane], a1 = W1g[(t * KS + g) * 64 + lane];
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {   // small terms first
+                acc[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, in0[et][g], acc[et], 0, 0, 0);
+                acc[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, in1[et][g], acc[et], 0, 0, 0);
+                acc[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, in0[et][g], acc[et], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[et][8 * sh + j], 0.0f);   // ReLU in f32 (torch semantics; the bias unit's 1 stays 1)
+                split_pack(v, out0[et][2 * t + sh], out1[et][2 * t + sh]);
+            }
+    }
+}
+
+template <int L>
+__global__ void __launch_bounds__(kPolBlock, 1)
+policy_f32class_kernel(const half8* __restrict__ w0, const half8* __restrict__ w1, int n, const float* __restrict__ obs,
+                       float4* __restrict__ mean_out) {
+    using D = PolicyDims<L>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half8* W = reinterpret_cast<half8*>(smem);
+    const int i = blockIdx.x * kPolBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int ii = i < n ? i : 0;  // ragged-tail lanes shadow env 0 (MFMA / swaps are wave-wide)
+    float o[L];
+    const float* row = obs + (size_t)ii * L;
+#pragma unroll
+    for (int k = 0; k < L; ++k) o[k] = row[k];
+    stage_policy(w0, W, D::kTotalHalf8);
+    __syncthreads();
+    half8 in0[2][D::kSteps1], in1[2][D::kSteps1];
+#pragma unroll
+    for (int s = 0; s < D::kSteps1; ++s) {   // layer-1 B operands as in policy_forward(), both pieces
+        float t0[8], t1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k0 = 16 * s + j, k1 = 16 * s + 8 + j;
+            const float x0 = (k0 < L) ? o[k0 < L ? k0 : 0] : (k0 == L ? 1.0f : 0.0f);
+            const float x1 = (k1 < L) ? o[k1 < L ? k1 : 0] : (k1 == L ? 1.0f : 0.0f);
+            swap32(x0, x1, t0[j], t1[j]);
+        }
+        split_pack(t0, in0[0][s], in1[0][s]);
+        split_pack(t1, in0[1][s], in1[1][s]);
+    }
+    half8 h0[2][8], h1[2][8], g0[2][8], g1[2][8];
+    policy_layer_f32class<D::kSteps1>(W, w1, lane, in0, in1, h0, h1);
+    policy_layer_f32class<8>(W + D::kOff2, w1 + D::kOff2, lane, h0, h1, g0, g1);
+    policy_layer_f32class<8>(W + D::kOff3, w1 + D::kOff3, lane, g0, g1, h0, h1);
+    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    f32x16p accO[2] = {zero, zero};
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const half8 a0 = W[D::kOff4 + g * 64 + lane], a1 = w1[D::kOff4 + g * 64 + lane];
+#pragma unroll
+        for (int et = 0; et < 2; ++et) {
+            accO[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, h0[et][g], accO[et], 0, 0, 0);
+            accO[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, h1[et][g], accO[et], 0, 0, 0);
+            accO[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, h0[et][g], accO[et], 0, 0, 0);
+        }
+    }
+    float mean[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // rows 0..3 live in registers 0..3 of lanes 0..31 of each env tile: tile 1 to lanes 32..63
+        float lo, hi;
+        swap32(accO[0][r], accO[1][r], lo, hi);
+        mean[r] = lo;
+    }
+    if (i < n) mean_out[i] = make_float4(mean[0], mean[1], mean[2], mean[3]);
+}
+
+template <int L>
+hipError_t launch_policy_f32class_L(const half8* w0, const half8* w1, int n, const float* obs, float* mean, hipStream_t st) {
+    const size_t lds = (size_t)PolicyDims<L>::kTotalHalf8 * 16;
+    static unsigned long long configured = 0;   // per device ordinal
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(policy_f32class_kernel<L>), lds, configured)) return e;
+    hipLaunchKernelGGL(policy_f32class_kernel<L>, dim3((n + kPolBlock - 1) / kPolBlock), dim3(kPolBlock), lds, st, w0, w1, n, obs,
+                       reinterpret_cast<float4*>(mean));
+    return hipGetLastError();
+}
+
+hipError_t launch_policy_f32class(int L, const half8* w0, const half8* w1, int n, const float* obs, float* mean, hipStream_t st) {
+    switch (L) {
+        case 13: return launch_policy_f32class_L<13>(w0, w1, n, obs, mean, st);
+        case 17: return launch_policy_f32class_L<17>(w0, w1, n, obs, mean, st);
+        case 21: return launch_policy_f32class_L<21>(w0, w1, n, obs, mean, st);
+        case 25: return launch_policy_f32class_L<25>(w0, w1, n, obs, mean, st);
+        case 29: return launch_policy_f32class_L<29>(w0, w1, n, obs, mean, st);
+        case 20: return launch_policy_f32class_L<20>(w0, w1, n, obs, mean, st);
+        case 24: return launch_policy_f32class_L<24>(w0, w1, n, obs, mean, st);
+        case 28: return launch_policy_f32class_L<28>(w0, w1, n, obs, mean, st);
+        case 32: return launch_policy_f32class_L<32>(w0, w1, n, obs, mean, st);
+        case 36: return launch_policy_f32class_L<36>(w0, w1, n, obs, mean, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 }  // namespace qr
 
 struct qr_policy {
     int L = 0, device = 0;
     int steps1 = 0;
     size_t total_half8 = 0;
-    qr::half8* d_weights = nullptr;
+    qr::half8* d_weights = nullptr;      // W0 = f16(w): the image of the f16-operand kernels
+    qr::half8* d_weights_lo = nullptr;   // W1 = f16(w - W0): the low pieces, same layout (f32-class forward only)
     bool has_weights = false;
 };
 
@@ -119,7 +252,9 @@ int qr_policy_create(int32_t obs_len, int32_t device, qr_policy** out) {
     p->device = device;
     p->steps1 = (obs_len + 1 + 15) / 16;
     p->total_half8 = (size_t)4 * p->steps1 * 64 + 2 * 4 * 8 * 64 + 8 * 64;
-    if (hipMalloc((void**)&p->d_weights, p->total_half8 * 16) != hipSuccess) {
+    if (hipMalloc((void**)&p->d_weights, p->total_half8 * 16) != hipSuccess ||
+        hipMalloc((void**)&p->d_weights_lo, p->total_half8 * 16) != hipSuccess) {
+        if (p->d_weights) (void)hipFree(p->d_weights);
         delete p;
         return pfail(QR_E_HIP, "qr_policy_create: hipMalloc failed");
     }
@@ -132,6 +267,7 @@ int qr_policy_destroy(qr_policy* p) {
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
     if (p->d_weights) (void)hipFree(p->d_weights);
+    if (p->d_weights_lo) (void)hipFree(p->d_weights_lo);
     delete p;
     return QR_OK;
 }
@@ -142,7 +278,20 @@ int qr_policy_set_weights(qr_policy* p, const float* w1, const float* b1, const 
     if (!p || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w4 || !b4)
         return pfail(QR_E_INVALID, "qr_policy_set_weights: null argument");
     const int L = p->L, H = qr::kPolHidden, HP = qr::kPolHiddenPad, BU = qr::kPolBiasUnit;
-    std::vector<__half> img(p->total_half8 * 8, __float2half(0.0f));
+    std::vector<__half> img(p->total_half8 * 8, __float2half(0.0f)), img_lo(p->total_half8 * 8, __float2half(0.0f));
+    // every packed value as two f16 pieces: W0 = f16(w) (the f16-operand image), W1 = f16(w - W0) (exact difference in f32; the image
+    // of the low pieces for the f32-class forward).  A weight beyond the f16 range saturates in W0 and W1 carries the rest.
+    auto put = [&](size_t idx, float w) {
+        float c = w;
+        if (c > 65504.0f) c = 65504.0f;
+        if (c < -65504.0f) c = -65504.0f;
+        const __half h0 = __float2half(c);
+        img[idx] = __float2half(w);   // (unchanged behaviour of the f16 image: inf beyond the range, as before)
+        float r = w - __half2float(h0);
+        if (r > 65504.0f) r = 65504.0f;
+        if (r < -65504.0f) r = -65504.0f;
+        img_lo[idx] = (w == w) ? __float2half(r) : __float2half(0.0f);
+    };
     // padded weight accessors incl. the bias column and the constant-1 unit
     auto W1 = [&](int row, int k) -> float {  // row < 128, k < 16*steps1 ; input k == L is the constant 1
         if (row < H) return k < L ? w1[row * L + k] : (k == L ? b1[row] : 0.0f);
@@ -160,7 +309,7 @@ int qr_policy_set_weights(qr_policy* p, const float* w1, const float* b1, const 
     for (int t = 0; t < 4; ++t)
         for (int s = 0; s < p->steps1; ++s)
             for (int l = 0; l < 64; ++l, ++e)
-                for (int j = 0; j < 8; ++j) img[e * 8 + j] = __float2half(W1(32 * t + (l & 31), 16 * s + 8 * (l >> 5) + j));
+                for (int j = 0; j < 8; ++j) put(e * 8 + j, W1(32 * t + (l & 31), 16 * s + 8 * (l >> 5) + j));
     for (int layer = 0; layer < 2; ++layer) {
         const float* w = layer == 0 ? w2 : w3;
         const float* b = layer == 0 ? b2 : b3;
@@ -169,20 +318,21 @@ int qr_policy_set_weights(qr_policy* p, const float* w1, const float* b1, const 
                 for (int l = 0; l < 64; ++l, ++e)
                     for (int j = 0; j < 8; ++j) {
                         const int hid = 32 * (sp >> 1) + rho(8 * (sp & 1) + j, l >> 5);
-                        img[e * 8 + j] = __float2half(WH(w, b, 32 * t + (l & 31), hid));
+                        put(e * 8 + j, WH(w, b, 32 * t + (l & 31), hid));
                     }
     }
     for (int sp = 0; sp < 8; ++sp)
         for (int l = 0; l < 64; ++l, ++e)
             for (int j = 0; j < 8; ++j) {
                 const int hid = 32 * (sp >> 1) + rho(8 * (sp & 1) + j, l >> 5);
-                img[e * 8 + j] = __float2half(W4(l & 31, hid));
+                put(e * 8 + j, W4(l & 31, hid));
             }
     (void)HP;
     if (e != p->total_half8) return pfail(QR_E_STATE, "qr_policy_set_weights: internal packing size mismatch");
     if (hipSetDevice(p->device) != hipSuccess) return pfail(QR_E_HIP, "hipSetDevice failed");
     if (hipDeviceSynchronize() != hipSuccess) return pfail(QR_E_HIP, "hipDeviceSynchronize failed");
-    if (hipMemcpy(p->d_weights, img.data(), img.size() * sizeof(__half), hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy(p->d_weights, img.data(), img.size() * sizeof(__half), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->d_weights_lo, img_lo.data(), img_lo.size() * sizeof(__half), hipMemcpyHostToDevice) != hipSuccess)
         return pfail(QR_E_HIP, "qr_policy_set_weights: upload failed");
     p->has_weights = true;
     return QR_OK;
@@ -193,6 +343,14 @@ int qr_policy_forward(qr_policy* p, int32_t n, const float* obs_dev, float* mean
     if (!p->has_weights) return pfail(QR_E_STATE, "qr_policy_forward: qr_policy_set_weights has not been called");
     hipError_t e = qr::launch_policy(p->L, p->d_weights, n, obs_dev, mean_out_dev, (hipStream_t)stream);
     if (e != hipSuccess) return pfail(QR_E_HIP, std::string("qr_policy_forward: ") + hipGetErrorString(e));
+    return QR_OK;
+}
+
+int qr_policy_forward_f32class(qr_policy* p, int32_t n, const float* obs_dev, float* mean_out_dev, void* stream) {
+    if (!p || !obs_dev || !mean_out_dev || n < 1) return pfail(QR_E_INVALID, "qr_policy_forward_f32class: bad argument");
+    if (!p->has_weights) return pfail(QR_E_STATE, "qr_policy_forward_f32class: qr_policy_set_weights has not been called");
+    hipError_t e = qr::launch_policy_f32class(p->L, p->d_weights, p->d_weights_lo, n, obs_dev, mean_out_dev, (hipStream_t)stream);
+    if (e != hipSuccess) return pfail(QR_E_HIP, std::string("qr_policy_forward_f32class: ") + hipGetErrorString(e));
     return QR_OK;
 }
 

@@ -64,14 +64,19 @@ class MfmaPolicy:
         assert len(lin) == 4
         return self.set_weights([(m.weight, m.bias) for m in lin])
 
-    def forward(self, obs, out=None):
-        """obs: float32 CUDA tensor [n, obs_len] -> action means [n, 4] (not clipped).  Enqueued on the current stream."""
+    def forward(self, obs, out=None, precision="f16-operands"):
+        """obs: float32 CUDA tensor [n, obs_len] -> action means [n, 4] (not clipped).  Enqueued on the current stream.
+        precision: "f16-operands" (the throughput kernel) or "f32" (qr_policy_forward_f32class: every operand as two f16 pieces,
+        float32-class results -- the reference's precision, ~3 x the matrix work)."""
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.obs_len
+        if precision not in ("f16-operands", "f32"):
+            raise ValueError("precision must be 'f16-operands' or 'f32'")
         n = obs.shape[0]
         if out is None:
             out = torch.empty((n, 4), dtype=torch.float32, device=obs.device)
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = self._L.qr_policy_forward(self._h, n, C.c_void_p(obs.data_ptr()), C.c_void_p(out.data_ptr()), st)
+        fn = self._L.qr_policy_forward if precision == "f16-operands" else self._L.qr_policy_forward_f32class
+        rc = fn(self._h, n, C.c_void_p(obs.data_ptr()), C.c_void_p(out.data_ptr()), st)
         if rc:
             raise _lib.QuadraceError(rc, self._L.qr_policy_last_error().decode())
         return out

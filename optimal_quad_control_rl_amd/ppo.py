@@ -61,8 +61,10 @@ class ActorCritic(nn.Module):
         return lp, ent
 
     @torch.no_grad()
-    def act(self, obs, deterministic=False):
-        mean = self.pi(obs)
+    def act(self, obs, deterministic=False, mean=None):
+        """`mean`: action means already evaluated elsewhere (the f32-class matrix-core forward, policy.MfmaPolicy.forward(precision="f32"))."""
+        if mean is None:
+            mean = self.pi(obs)
         if deterministic:
             return mean, None, None
         std = self.log_std.exp()
@@ -270,7 +272,7 @@ class PPO:
     def __init__(self, env, n_steps=32, batch_size=None, n_epochs=5, gamma=0.999, gae_lambda=0.95, clip_range=0.2,
                  learning_rate=3e-4, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, net_arch=(120, 120, 120),
                  log_std_init=0.0, seed=0, target_kl=None, lr_final_frac=1.0, total_timesteps_hint=None,
-                 fused_collect=False, native_update=False, truncation_bootstrap=True):
+                 fused_collect=False, native_update=False, truncation_bootstrap=True, policy_forward="torch"):
         self.env = env
         self.n_envs, self.dev = env.num_envs, env.device
         self.n_steps, self.n_epochs = n_steps, n_epochs
@@ -326,9 +328,16 @@ class PPO:
         # noise -- ADVICE r03)
         self.noise_step = 0
         self._mfma = None
-        if fused_collect:
+        # policy_forward="f32class" (per-step collection only): the action means of collect() come from the hand-written
+        # reference-precision forward (qr_policy_forward_f32class: every operand as two f16 pieces, float32-class results) instead of
+        # torch's per-layer kernels; sampling, log-probabilities and values stay torch float32.  The weights are re-packed once per rollout.
+        if policy_forward not in ("torch", "f32class"):
+            raise ValueError("policy_forward must be 'torch' or 'f32class'")
+        self.policy_forward = policy_forward if not fused_collect else "torch"
+        if fused_collect or self.policy_forward == "f32class":
             from .policy import MfmaPolicy
 
+            assert tuple(net_arch) == (120, 120, 120), "the matrix-core policy kernels are built for the reference's 3 x 120 network"
             self._mfma = MfmaPolicy(obs_dim, self.dev.index)
             self._last_obs = None
         if self.truncation_bootstrap:  # the kernels write the pre-reset observation of finished envs here
@@ -390,8 +399,11 @@ class PPO:
         if self.fused_collect:
             return self.collect_fused()
         fin_ret = fin_len = fin_gates = fin_n = 0.0
+        f32class = self.policy_forward == "f32class"
+        if f32class:
+            self._mfma.load_torch(self.policy.pi)
         for t in range(self.n_steps):
-            actions, lp, val = self.policy.act(self.obs)
+            actions, lp, val = self.policy.act(self.obs, mean=self._mfma.forward(self.obs.contiguous(), precision="f32") if f32class else None)
             self.buf_obs[t].copy_(self.obs)
             self.buf_act[t].copy_(actions)
             self.buf_lp[t].copy_(lp)

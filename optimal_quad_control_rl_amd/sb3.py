@@ -186,12 +186,14 @@ class PPO:
                  fused_collect="auto",          # (+) rollouts as one closed-loop kernel
                  precision=None,                # (+) "f16-operands" (default) | "f32": see below
                  _init_trainer=True):
-        # precision: the hand-written policy / PPO kernels compute with f16 matrix-core operands and f32 accumulation (policy mean within
-        # 7e-4 of the reference's float32 nn_forward, gradient cosine >= 0.9985 against float32 autograd).  precision="f32" is the
-        # REFERENCE-PRECISION mode: the policy forward of the collect phase and the whole update (forward, loss, backward, clipping,
-        # Adam) run in float32 on the device through torch (the arithmetic SB3 itself uses, R:783-795), still on the env's device
-        # tensors and still around the HIP env kernels -- ~40x slower than the matrix-core path, there for A/B runs that ask whether an
-        # outcome is the recipe's or the arithmetic's.
+        # precision: the throughput kernels (closed-loop collection, PPO update) compute with f16 matrix-core operands and f32 accumulation
+        # (policy mean within 7e-4 of the reference's float32 nn_forward, gradient cosine >= 0.9985 against float32 autograd).
+        # precision="f32" is the REFERENCE-PRECISION mode: the collect phase's policy forward runs in the hand-written f32-class kernel
+        # (qr_policy_forward_f32class: every operand as two f16 pieces, 7e-7 against nn_forward -- round 6), sampling / log-probabilities /
+        # values and the whole update (forward, loss, backward, clipping, Adam) run in float32 through torch (the arithmetic SB3 itself
+        # uses, R:783-795) on the env's device tensors around the HIP env kernels.  A hand-written f32-class GRADIENT kernel does not
+        # exist: this mode is ~40 x slower than the matrix-core path and is there for A/B runs that ask whether an outcome is the
+        # recipe's or the arithmetic's.
         precision = precision or "f16-operands"
         if precision not in ("f16-operands", "f32"):
             raise ValueError("precision must be 'f16-operands' or 'f32'")
@@ -233,7 +235,8 @@ class PPO:
                                     gamma=self.gamma, gae_lambda=gae_lambda, clip_range=clip_range,
                                     learning_rate=learning_rate, vf_coef=vf_coef, ent_coef=ent_coef,
                                     max_grad_norm=max_grad_norm, net_arch=self.net_arch, log_std_init=self.log_std_init,
-                                    seed=self.seed, target_kl=target_kl, fused_collect=fused, native_update=native)
+                                    seed=self.seed, target_kl=target_kl, fused_collect=fused, native_update=native,
+                                    policy_forward="f32class" if (precision == "f32" and tuple(self.net_arch) == (120, 120, 120)) else "torch")
             self._net = self._trainer.policy
             self.observation_dim = int(core.state_len)
         else:

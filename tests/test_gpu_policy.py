@@ -52,6 +52,59 @@ def test_policy_matches_torch(L, n):
     assert err < 5e-3 * scale, (err, scale)
 
 
+def test_f32class_policy_matches_reference_nn_forward_at_float32_level():
+    """Round 6: the reference-precision forward (every operand as two f16 pieces, three matrix instructions per
+    K-step, f32 accumulation) against the reference's own generated float32 `nn_forward` (F10) and against float64: the error is at the
+    float32 rounding level of the network's outputs (nn_forward itself differs from float64 by about as much), 300 x below the
+    f16-operand kernel's."""
+    from optimal_quad_control_rl_amd.policy import MfmaPolicy
+
+    d = P.load("f10_policy")
+    pol = MfmaPolicy(24).set_weights(_layers(d))
+    obs = torch.as_tensor(d["obs"]).cuda()
+    out = pol.forward(obs, precision="f32").cpu().numpy()
+    out16 = pol.forward(obs).cpu().numpy()
+    x = d["obs"].astype(np.float64)
+    for k, (w, b) in enumerate(_layers(d)):
+        x = x @ np.asarray(w, np.float64).T + np.asarray(b, np.float64)
+        if k < 3:
+            x = np.maximum(x, 0.0)
+    e_ref, e64, e16 = np.abs(out - d["mean"]).max(), np.abs(out - x).max(), np.abs(out16 - d["mean"]).max()
+    ref64 = np.abs(d["mean"] - x).max()
+    print("f32-class: max |mean - nn_forward| = %.3e, vs float64 %.3e (nn_forward vs float64 %.3e); f16-operand kernel %.3e" % (e_ref, e64, ref64, e16))
+    assert e_ref <= 2e-6 * max(1.0, np.abs(d["mean"]).max())
+    assert e64 <= 2e-6 * max(1.0, np.abs(x).max())
+    assert e16 > 50 * e_ref                     # the two kernels really are different arithmetic
+
+
+@pytest.mark.parametrize("L", [13, 17, 20, 24, 36])
+@pytest.mark.parametrize("n", [1, 63, 1000, 65536])
+def test_f32class_policy_matches_float64_torch(L, n):
+    """... for every observation length, ragged and full launches, large inputs (rates up to 1000 rad/s) and a non-trivial output head:
+    against the float64 evaluation of the same float32 parameters, error <= 4e-6 of the output scale (float32 torch: the same level)."""
+    from optimal_quad_control_rl_amd.policy import MfmaPolicy
+    from optimal_quad_control_rl_amd.ppo import ActorCritic
+
+    torch.manual_seed(L * 1000 + n % 997)
+    net = ActorCritic(L, 4).cuda()
+    with torch.no_grad():
+        for m in net.pi:
+            if isinstance(m, torch.nn.Linear):
+                m.bias.uniform_(-0.3, 0.3)
+        net.pi[-1].weight.mul_(30.0)
+    obs = (torch.randn(n, L, device="cuda") * 2.0).contiguous()
+    obs[:, min(9, L - 1)] *= 300.0                      # a body-rate column near the 1000 rad/s guard
+    pol = MfmaPolicy(L).load_torch(net.pi)
+    out = pol.forward(obs, precision="f32")
+    with torch.no_grad():
+        ref64 = net.pi.double()(obs.double())
+        ref32 = net.pi.float()(obs)
+    scale = max(1.0, ref64.abs().max().item())
+    err, err32 = (out.double() - ref64).abs().max().item(), (ref32.double() - ref64).abs().max().item()
+    assert out.shape == (n, 4)
+    assert err <= 4e-6 * scale, (err, err32, scale)
+
+
 def test_policy_errors():
     import ctypes as C
     from optimal_quad_control_rl_amd import _lib
@@ -184,3 +237,37 @@ def test_ppo_native_update_learns():
     obs = env.reset_device()
     a = model.act_device(obs)
     assert a.shape == (8192, 4) and torch.isfinite(a).all() and float(a.abs().max()) <= 1.0
+
+
+def test_f32_precision_trainer_collects_through_the_f32class_kernel():
+    """precision='f32' of the SB3-shaped PPO (round 6): the collect phase's action means come from qr_policy_forward_f32class, everything
+    else from torch float32.  Same seed, same env: the rollout buffers of that trainer and of the plain torch trainer agree at the
+    float32 level over a whole rollout with auto-resets (identical done flags; actions within 2e-5; both use the same torch noise)."""
+    from optimal_quad_control_rl_amd.ppo import PPO
+
+    def run(policy_forward):
+        env = _make("e2e", 2048, seed=11)
+        env.max_steps = 10                          # every env is reset (and restarted) inside the 24-step rollout
+        torch.manual_seed(123)
+        t = PPO(env, n_steps=24, batch_size=2048 * 6, n_epochs=1, seed=3, policy_forward=policy_forward)
+        with torch.no_grad():
+            t.policy.pi[-1].weight.mul_(20.0)
+        torch.manual_seed(777)                      # the sampling noise of both runs
+        t.collect()
+        out = (t.buf_obs.clone(), t.buf_act.clone(), t.buf_lp.clone(), t.buf_done.clone(), t.buf_rew.clone())
+        used = t._mfma is not None
+        env.close()
+        return out, used
+
+    (o1, a1, l1, d1, r1), used1 = run("torch")
+    (o2, a2, l2, d2, r2), used2 = run("f32class")
+    assert not used1 and used2
+    assert float(d1.sum()) > 0                                                    # auto-resets inside the window
+    assert torch.equal(o1[0], o2[0])                                              # same start
+    assert 0 < float((a1[0] - a2[0]).abs().max()) <= 2e-5                         # different arithmetic, same precision class
+    # a terminated env restarts from a fresh state, so an env whose termination falls on a threshold within float32 noise may part ways:
+    # compare the envs whose done flags agree throughout (nearly all), over the whole rollout
+    same = (d1 == d2).all(dim=0)
+    assert float(same.float().mean()) > 0.995, float(same.float().mean())
+    assert float((a1 - a2)[:, same].abs().max()) <= 1e-3 and float((o1 - o2)[:, same].abs().max()) <= 2e-2
+    assert float((r1 - r2)[:, same].abs().max()) <= 2e-2 and float((l1 - l2)[:, same].abs().max()) <= 2e-2
