@@ -54,12 +54,12 @@ FUSED_BYTES_PER_ENV_STEP = {"e2e": lambda ga: 16 + 4 * (20 + 4 * ga) + 6, "indi"
 MIN_TIMED_MS = 20.0
 # Numbers in the line that were NOT measured by this run: PMC counter figures collected by the builder with rocprofv3 (separate
 # --pmc passes) and committed under profiles/.  They are labelled with the file and the commit that added it.
-PMC_TRAFFIC_FILE = ("profiles", "r05_pmc_traffic.json")     # tools/run_pmc.sh: FETCH_SIZE / WRITE_SIZE passes, keyed by kernel symbol
-PMC_COMPUTE_FILE = ("profiles", "r05_pmc_compute.json")     # tools/run_pmc_compute.sh: SQ instruction / cycle counters, by kernel symbol
+PMC_TRAFFIC_FILE = ("profiles", "r06_pmc_traffic.json")     # tools/run_pmc.sh: FETCH_SIZE / WRITE_SIZE passes, keyed by kernel symbol
+PMC_COMPUTE_FILE = ("profiles", "r06_pmc_compute.json")     # tools/run_pmc_compute.sh: SQ instruction / cycle counters, by kernel symbol
 PMC_SOURCES = {
-    "traffic": "builder-measured, not this run: profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+    "traffic": "builder-measured, not this run: profiles/r06_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
                "tools/run_pmc.sh; the file records the commit and the kernel symbols it was collected on)",
-    "flop": "builder-measured, not this run: profiles/r05_pmc_compute.json (rocprofv3 --pmc SQ_INSTS_VALU_* / MFMA_MOPS, tools/run_pmc_compute.sh)",
+    "flop": "builder-measured, not this run: profiles/r06_pmc_compute.json (rocprofv3 --pmc SQ_INSTS_VALU_* / MFMA_MOPS, tools/run_pmc_compute.sh)",
     "launch_floor": "builder-measured, not this run: profiles/r02_launch_floor.json @ 333de90 (tools/ubench/launch_floor.hip)",
 }
 
@@ -350,7 +350,7 @@ def measure_env(rt, env, variant, n, K, W, ga, repeats, closed_loop=True):
                 "valu": {"bound": "valu", "achieved": tf, "peak": VALU_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": None if tf is None else tf / VALU_F32_PEAK_TF, "flop_per_env_step": flop,
                          "flop_source": "PMC: 64 x (ADD + MUL + TRANS + 2 FMA f32 wave-instructions) + 512 x MFMA_MOPS_F32 per env-step, "
-                                        "profiles/r05_pmc_compute.json; the larger of the two fractions names the binding roof"}}
+                                        "profiles/r06_pmc_compute.json; the larger of the two fractions names the binding roof"}}
     roofline["frac_on_8d_bytes"] = bytes_per_step * K / launch_s / 1e9 / HBM_PEAK_GBS
     roofline["frac_on_8d_bytes_note"] = ("SURVEY 8(d)'s %d B per env-step (state read + written every step) divided by this kernel's time: "
                                          "NOT its traffic (the state stays in registers) -- BASELINE.md section 4's throughput yardstick only"

@@ -56,7 +56,7 @@ def commit_id():
         return "unknown"
 
 
-def main(variant, n, fetch_csv, write_csv, out="profiles/r05_pmc_traffic.json"):
+def main(variant, n, fetch_csv, write_csv, out="profiles/r06_pmc_traffic.json"):
     n = int(n)
     f_cal, f = per_symbol(load(fetch_csv, "FETCH_SIZE"))
     w_cal, w = per_symbol(load(write_csv, "WRITE_SIZE"))

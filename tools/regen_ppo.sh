@@ -1,8 +1,8 @@
 #!/bin/bash
-# GPU box: regenerate the round-5 PPO-UPDATE evidence under gpurun_out/profiles/ (copy what should be judged into profiles/).
-#   QR_COMMIT=<short hash> bash tools/regen_ppo_r05.sh
+# GPU box: regenerate the PPO-UPDATE evidence under gpurun_out/profiles/ (copy what should be judged into profiles/).
+#   QR_COMMIT=<short hash> bash tools/regen_ppo.sh
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profiles; mkdir -p $O; cd $R
-T=r05
+T=${QR_TAG:-r06}
 for B in 16384 65536 131072; do python tools/bench_ppo_update.py --obs-len 24 --minibatch $B --iters 200 2>/dev/null | tail -1; done > $O/${T}_ppo_update_bench.json
 # rocprofv3 per-kernel averages of the same command (16 384 and 65 536 rows)
 for B in 16384 65536; do

@@ -1,10 +1,10 @@
 #!/bin/bash
-# GPU box: regenerate the round-5 ENV-KERNEL evidence under gpurun_out/profiles/ (copy what should be judged into profiles/).
-#   QR_COMMIT=<short hash> bash tools/regen_profiles_r05.sh
+# GPU box: regenerate the ENV-KERNEL evidence under gpurun_out/profiles/ (copy what should be judged into profiles/).
+#   QR_COMMIT=<short hash> bash tools/regen_profiles.sh
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profiles; mkdir -p $O; cd $R
-T=r05
+T=${QR_TAG:-r06}
 # counters first: bench.py looks the traffic of its kernels up in profiles/r05_pmc_*.json
-bash tools/run_pmc.sh > $O/${T}_run_pmc.log 2>&1; cp $O/${T}_pmc_traffic.json profiles/ 2>/dev/null
+QR_TAG=$T bash tools/run_pmc.sh > $O/${T}_run_pmc.log 2>&1; cp $O/${T}_pmc_traffic.json profiles/ 2>/dev/null
 QR_PMC_ONLY_ENV=1 bash tools/run_pmc_compute.sh ${T} > $O/${T}_run_pmc_compute.log 2>&1; cp gpurun_out/${T}_pmc_compute.json $O/; cp gpurun_out/${T}_pmc_compute.json profiles/
 QR_PMC_ENVS=1048576 QR_PMC_ONLY_ENV=1 bash tools/run_pmc_compute.sh ${T}_n1Mi > $O/${T}_run_pmc_compute_1Mi.log 2>&1; cp gpurun_out/${T}_n1Mi_pmc_compute.json $O/
 python bench.py --steps 20 --warmup 5 > $O/${T}_bench_e2e_k20.json 2> $O/${T}_bench_e2e_k20.full.json
