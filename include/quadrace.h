@@ -206,8 +206,11 @@ int qr_policy_forward_f32class(qr_policy* policy, int32_t n, const float* obs_de
  * (obs_t the action was computed from, unclipped action_t, log-prob_t of that action, reward_t, done_t[, trunc_t]);
  * last_obs_dev [N][obs_len] (may be NULL) receives the observation after the last step (value bootstrap).
  * log_std: host float[4].  Action noise is Philox4x32-10 + Box-Muller keyed by (noise_seed, global env id,
- * first_step + t): pass the number of steps already taken as first_step.  deterministic != 0: action = mean.
+ * first_step + t): pass the number of steps already taken as first_step.  `deterministic` is a set of flags (0 / 1 as before):
+ * QR_ROLLOUT_DETERMINISTIC: action = mean; QR_ROLLOUT_F32CLASS (round 6): the policy forward inside the kernel is the reference-precision
+ * one of qr_policy_forward_f32class (slower: three matrix instructions per K-step, low-piece weights read from global memory).
  * qr_last_step_many_ms() reports this launch too. */
+enum { QR_ROLLOUT_DETERMINISTIC = 1, QR_ROLLOUT_F32CLASS = 2 };
 int qr_rollout_policy(qr_env* env, qr_policy* policy, int32_t num_steps, const float* log_std, uint64_t noise_seed,
                       uint64_t first_step, int32_t deterministic, float* obs_out_dev, float* act_out_dev,
                       float* logp_out_dev, float* rew_out_dev, uint8_t* done_out_dev, uint8_t* trunc_out_dev,

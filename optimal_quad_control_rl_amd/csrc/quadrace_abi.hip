@@ -23,6 +23,7 @@ hipError_t launch_rollout_policy(int variant, const Params& P, const PolicyArgs&
                                  float* logp, float* rew, uint8_t* done, uint8_t* trunc, float* last_obs,
                                  hipStream_t st);
 const half8* policy_weights(const qr_policy* p);
+const half8* policy_weights_lo(const qr_policy* p);
 int policy_obs_len(const qr_policy* p);
 int policy_device(const qr_policy* p);
 hipError_t launch_reset(int variant, const Params& P, const uint8_t* mask, float* obs, hipStream_t st);
@@ -525,8 +526,12 @@ int qr_rollout_policy(qr_env* e, qr_policy* policy, int32_t K, const float* log_
     if (!w) return fail(QR_E_STATE, "qr_rollout_policy: the policy has no weights");
     if (qr::policy_obs_len(policy) != e->L) return fail(QR_E_INVALID, "qr_rollout_policy: policy obs_len != env obs_len");
     if (qr::policy_device(policy) != e->cfg.device) return fail(QR_E_INVALID, "qr_rollout_policy: policy on another GPU");
+    if (deterministic < 0 || deterministic > (QR_ROLLOUT_DETERMINISTIC | QR_ROLLOUT_F32CLASS))
+        return fail(QR_E_INVALID, "qr_rollout_policy: `deterministic` takes QR_ROLLOUT_DETERMINISTIC | QR_ROLLOUT_F32CLASS");
     qr::PolicyArgs A{};
     A.weights = w;
+    A.weights_lo = qr::policy_weights_lo(policy);
+    A.f32class = (deterministic & QR_ROLLOUT_F32CLASS) ? 1 : 0;
     float sum_log_std = 0.0f;
     for (int c = 0; c < 4; ++c) {
         A.std[c] = expf(log_std[c]);
@@ -540,7 +545,7 @@ int qr_rollout_policy(qr_env* e, qr_policy* policy, int32_t K, const float* log_
     A.seed_hi = (uint32_t)(noise_seed >> 32) ^ 0x85EBCA6Bu;
     A.step_lo = (uint32_t)first_step;
     A.step_hi = (uint32_t)(first_step >> 32);
-    A.deterministic = deterministic ? 1 : 0;
+    A.deterministic = (deterministic & QR_ROLLOUT_DETERMINISTIC) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool ev = want_events(e, st);
     if (ev) QR_HIP(hipEventRecord(e->ev0, st));

@@ -694,7 +694,9 @@ rollout_stash_kernel(Params P, int K, const float4* __restrict__ actions, float*
 // clipped to the Box [-1, 1] (what SB3 does, R:785); reward_t / done_t follow; the post-step observation feeds the
 // next step.  This is PPO's collect phase (R:820 -> SB3 collect_rollouts) without leaving the chip.
 // ---------------------------------------------------------------------------------------------------
-template <int V, int GA>
+// kF32: the reference-precision forward (policy_forward_f32class: every operand as two f16 pieces, the low-piece image read from global
+// memory) instead of the hand-scheduled f16-operand one; noise and the observation store then simply run in front of it.
+template <int V, int GA, bool kF32 = false>
 __global__ void __launch_bounds__(kBlock, 1)
 rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out, float4* __restrict__ act_out,
                       float* __restrict__ logp_out, float* __restrict__ rew_out, uint8_t* __restrict__ done_out,
@@ -783,7 +785,15 @@ rollout_policy_kernel(Params P, PolicyArgs A, int K, float* __restrict__ obs_out
             if (slot == 0 && full_wave) obs_tile_write<V, GA>(tile, lane, o);
             if (slot == 2 && full_wave) obs_tile_flush<V, GA>(tile, obs_out + (size_t)k * n * L, (size_t)wave_first, lane);
         };
-        policy_forward<L>(W, lane, o, mean, noise_slice, obs_slice);
+        if constexpr (kF32) {
+#pragma unroll
+            for (int slot = 0; slot <= 16; ++slot) noise_slice(slot);
+            obs_slice(0);
+            obs_slice(2);
+            policy_forward_f32class<L>(W, A.weights_lo, lane, o, mean);
+        } else {
+            policy_forward<L>(W, lane, o, mean, noise_slice, obs_slice);
+        }
         QR_TICK(P, 9);
         float a[4] = {mean[0], mean[1], mean[2], mean[3]};
         float logp = A.logp_const;
@@ -1129,7 +1139,13 @@ hipError_t launch_rollout_policy_vg(const Params& P, const PolicyArgs& A, int K,
     constexpr int L = obs_len<V, GA>();
     const size_t lds = (size_t)PolicyDims<L>::kTotalHalf8 * 16 +
                        sizeof(float) * (kResetTableFloats + kMaxGates * kGateStride + kBlock * L);
-    static unsigned long long configured = 0;   // per device ordinal
+    static unsigned long long configured = 0, configured32 = 0;   // per device ordinal
+    if (A.f32class) {
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(rollout_policy_kernel<V, GA, true>), lds, configured32)) return e;
+        hipLaunchKernelGGL((rollout_policy_kernel<V, GA, true>), grid_for(P.n), dim3(kBlock), lds, st, P, A, K, obs,
+                           reinterpret_cast<float4*>(act), logp, rew, done, trunc, last_obs);
+        return hipGetLastError();
+    }
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(rollout_policy_kernel<V, GA>), lds, configured)) return e;
     hipLaunchKernelGGL((rollout_policy_kernel<V, GA>), grid_for(P.n), dim3(kBlock), lds, st, P, A, K, obs,
                        reinterpret_cast<float4*>(act), logp, rew, done, trunc, last_obs);

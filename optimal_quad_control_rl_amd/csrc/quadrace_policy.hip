@@ -74,56 +74,6 @@ hipError_t launch_policy(int L, const half8* w, int n, const float* obs, float* 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Reference-precision ("f32-class") forward of the same network (round 6).  The reference evaluates the policy
-// in float32 (SB3 / torch, R:783-795; generated C twin c_code/neural_network.c:397-430); policy_kernel above rounds every operand to
-// one f16 (max |d mean| 7e-4 against nn_forward).  Here BOTH operands of every layer are split into two f16 pieces, exactly like
-// layer 1 of the residual MLPs (quadrace_device.hpp residual_mlp):
-//     x = X0 + X1,  X0 = f16(x), X1 = f16(x - X0)          w = W0 + W1 (host side, once)
-//     w x  ~  W0 X0 + W1 X0 + W0 X1                         (the dropped W1 X1 is <= 2^-22 |w x|; f32 accumulation on the matrix core)
-// -- three matrix instructions per K-step instead of one, same operand layouts, same "accumulator registers are the next layer's k-slots"
-// trick, so the chain still never leaves the registers.  The low-piece image W1 is read from global memory (80 KB, L2-resident, shared by
-// every workgroup); W0 is staged in LDS like policy_kernel's image.  Not hand-scheduled: this is the accuracy path (evaluation,
-// precision="f32" collection), the f16 kernel stays the throughput path.
-// |x| beyond the f16 range: X0 saturates at +-65504 and X1 carries the rest (up to 131 008: no observation or activation gets there).
-__device__ __forceinline__ void split_pack(const float* v, half8& p0, half8& p1) {
-    float r[8];
-    p0 = sat_pack(v);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = v[j] - (float)p0[j];   // exact in f32 (NaN -> p0 = 0, r = NaN -> sat_pack gives 0)
-    p1 = sat_pack(r);
-}
-
-template <int KS>
-__device__ __forceinline__ void policy_layer_f32class(const half8* __restrict__ W0, const half8* __restrict__ W1g, int lane,
-                                                      const half8 (&in0)[2][KS], const half8 (&in1)[2][KS], half8 (&out0)[2][8],
-                                                      half8 (&out1)[2][8]) {
-    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        f32x16p acc[2] = {zero, zero};
-#pragma unroll
-        for (int g = 0; g < KS; ++g) {
-            const half8 a0 = W0[(t * KS + g) * 64 + lane], a1 = W1g[(t * KS + g) * 64 + lane];
-#pragma unroll
-            for (int et = 0; et < 2; ++et) {   // small terms first
-                acc[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, in0[et][g], acc[et], 0, 0, 0);
-                acc[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, in1[et][g], acc[et], 0, 0, 0);
-                acc[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, in0[et][g], acc[et], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int et = 0; et < 2; ++et)
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[et][8 * sh + j], 0.0f);   // ReLU in f32 (torch semantics; the bias unit's 1 stays 1)
-                split_pack(v, out0[et][2 * t + sh], out1[et][2 * t + sh]);
-            }
-    }
-}
-
 template <int L>
 __global__ void __launch_bounds__(kPolBlock, 1)
 policy_f32class_kernel(const half8* __restrict__ w0, const half8* __restrict__ w1, int n, const float* __restrict__ obs,
@@ -140,43 +90,8 @@ policy_f32class_kernel(const half8* __restrict__ w0, const half8* __restrict__ w
     for (int k = 0; k < L; ++k) o[k] = row[k];
     stage_policy(w0, W, D::kTotalHalf8);
     __syncthreads();
-    half8 in0[2][D::kSteps1], in1[2][D::kSteps1];
-#pragma unroll
-    for (int s = 0; s < D::kSteps1; ++s) {   // layer-1 B operands as in policy_forward(), both pieces
-        float t0[8], t1[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k0 = 16 * s + j, k1 = 16 * s + 8 + j;
-            const float x0 = (k0 < L) ? o[k0 < L ? k0 : 0] : (k0 == L ? 1.0f : 0.0f);
-            const float x1 = (k1 < L) ? o[k1 < L ? k1 : 0] : (k1 == L ? 1.0f : 0.0f);
-            swap32(x0, x1, t0[j], t1[j]);
-        }
-        split_pack(t0, in0[0][s], in1[0][s]);
-        split_pack(t1, in0[1][s], in1[1][s]);
-    }
-    half8 h0[2][8], h1[2][8], g0[2][8], g1[2][8];
-    policy_layer_f32class<D::kSteps1>(W, w1, lane, in0, in1, h0, h1);
-    policy_layer_f32class<8>(W + D::kOff2, w1 + D::kOff2, lane, h0, h1, g0, g1);
-    policy_layer_f32class<8>(W + D::kOff3, w1 + D::kOff3, lane, g0, g1, h0, h1);
-    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    f32x16p accO[2] = {zero, zero};
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const half8 a0 = W[D::kOff4 + g * 64 + lane], a1 = w1[D::kOff4 + g * 64 + lane];
-#pragma unroll
-        for (int et = 0; et < 2; ++et) {
-            accO[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, h0[et][g], accO[et], 0, 0, 0);
-            accO[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, h1[et][g], accO[et], 0, 0, 0);
-            accO[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, h0[et][g], accO[et], 0, 0, 0);
-        }
-    }
     float mean[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {   // rows 0..3 live in registers 0..3 of lanes 0..31 of each env tile: tile 1 to lanes 32..63
-        float lo, hi;
-        swap32(accO[0][r], accO[1][r], lo, hi);
-        mean[r] = lo;
-    }
+    policy_forward_f32class<L>(W, w1, lane, o, mean);
     if (i < n) mean_out[i] = make_float4(mean[0], mean[1], mean[2], mean[3]);
 }
 
@@ -227,6 +142,7 @@ inline int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 namespace qr {  // accessors for the closed-loop rollout entry point in quadrace_abi.hip
 const half8* policy_weights(const qr_policy* p) { return (p && p->has_weights) ? p->d_weights : nullptr; }
+const half8* policy_weights_lo(const qr_policy* p) { return (p && p->has_weights) ? p->d_weights_lo : nullptr; }
 int policy_obs_len(const qr_policy* p) { return p ? p->L : -1; }
 int policy_device(const qr_policy* p) { return p ? p->device : -1; }
 }  // namespace qr

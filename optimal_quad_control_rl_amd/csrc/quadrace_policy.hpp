@@ -209,9 +209,104 @@ __device__ __forceinline__ void policy_forward(const half8* __restrict__ Wlds, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Reference-precision ("f32-class") forward of the same network (round 6).  The reference evaluates the policy
+// in float32 (SB3 / torch, R:783-795; generated C twin c_code/neural_network.c:397-430); policy_kernel above rounds every operand to
+// one f16 (max |d mean| 7e-4 against nn_forward).  Here BOTH operands of every layer are split into two f16 pieces, exactly like
+// layer 1 of the residual MLPs (quadrace_device.hpp residual_mlp):
+//     x = X0 + X1,  X0 = f16(x), X1 = f16(x - X0)          w = W0 + W1 (host side, once)
+//     w x  ~  W0 X0 + W1 X0 + W0 X1                         (the dropped W1 X1 is <= 2^-22 |w x|; f32 accumulation on the matrix core)
+// -- three matrix instructions per K-step instead of one, same operand layouts, same "accumulator registers are the next layer's k-slots"
+// trick, so the chain still never leaves the registers.  The low-piece image W1 is read from global memory (80 KB, L2-resident, shared by
+// every workgroup); W0 is staged in LDS like policy_kernel's image.  Not hand-scheduled: this is the accuracy path (evaluation,
+// precision="f32" collection), the f16 kernel stays the throughput path.
+// |x| beyond the f16 range: X0 saturates at +-65504 and X1 carries the rest (up to 131 008: no observation or activation gets there).
+__device__ __forceinline__ void split_pack(const float* v, half8& p0, half8& p1) {
+    float r[8];
+    p0 = sat_pack(v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = v[j] - (float)p0[j];   // exact in f32 (NaN -> p0 = 0, r = NaN -> sat_pack gives 0)
+    p1 = sat_pack(r);
+}
+
+template <int KS>
+__device__ __forceinline__ void policy_layer_f32class(const half8* __restrict__ W0, const half8* __restrict__ W1g, int lane,
+                                                      const half8 (&in0)[2][KS], const half8 (&in1)[2][KS], half8 (&out0)[2][8],
+                                                      half8 (&out1)[2][8]) {
+    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x16p acc[2] = {zero, zero};
+#pragma unroll
+        for (int g = 0; g < KS; ++g) {
+            const half8 a0 = W0[(t * KS + g) * 64 + lane], a1 = W1g[(t * KS + g) * 64 + lane];
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {   // small terms first
+                acc[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, in0[et][g], acc[et], 0, 0, 0);
+                acc[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, in1[et][g], acc[et], 0, 0, 0);
+                acc[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, in0[et][g], acc[et], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[et][8 * sh + j], 0.0f);   // ReLU in f32 (torch semantics; the bias unit's 1 stays 1)
+                split_pack(v, out0[et][2 * t + sh], out1[et][2 * t + sh]);
+            }
+    }
+}
+
+// Full f32-class forward for the wave's 64 envs: W0 = image of the high pieces (LDS), W1g = image of the low pieces (global memory).
+template <int L>
+__device__ __forceinline__ void policy_forward_f32class(const half8* __restrict__ W0, const half8* __restrict__ W1g, int lane, const float* o,
+                                                        float mean[4]) {
+    using D = PolicyDims<L>;
+    half8 in0[2][D::kSteps1], in1[2][D::kSteps1];
+#pragma unroll
+    for (int s = 0; s < D::kSteps1; ++s) {   // layer-1 B operands as in policy_forward(), both pieces
+        float t0[8], t1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k0 = 16 * s + j, k1 = 16 * s + 8 + j;
+            const float x0 = (k0 < L) ? o[k0 < L ? k0 : 0] : (k0 == L ? 1.0f : 0.0f);
+            const float x1 = (k1 < L) ? o[k1 < L ? k1 : 0] : (k1 == L ? 1.0f : 0.0f);
+            swap32(x0, x1, t0[j], t1[j]);
+        }
+        split_pack(t0, in0[0][s], in1[0][s]);
+        split_pack(t1, in0[1][s], in1[1][s]);
+    }
+    half8 h0[2][8], h1[2][8], g0[2][8], g1[2][8];
+    policy_layer_f32class<D::kSteps1>(W0, W1g, lane, in0, in1, h0, h1);
+    policy_layer_f32class<8>(W0 + D::kOff2, W1g + D::kOff2, lane, h0, h1, g0, g1);
+    policy_layer_f32class<8>(W0 + D::kOff3, W1g + D::kOff3, lane, g0, g1, h0, h1);
+    const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    f32x16p accO[2] = {zero, zero};
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const half8 a0 = W0[D::kOff4 + g * 64 + lane], a1 = W1g[D::kOff4 + g * 64 + lane];
+#pragma unroll
+        for (int et = 0; et < 2; ++et) {
+            accO[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, h0[et][g], accO[et], 0, 0, 0);
+            accO[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, h1[et][g], accO[et], 0, 0, 0);
+            accO[et] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, h0[et][g], accO[et], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // rows 0..3 live in registers 0..3 of lanes 0..31 of each env tile: tile 1 to lanes 32..63
+        float lo, hi;
+        swap32(accO[0][r], accO[1][r], lo, hi);
+        mean[r] = lo;
+    }
+}
+
 // Arguments of the closed-loop rollout (policy + sampling inside the env rollout kernel)
 struct PolicyArgs {
     const half8* weights;   // packed f16 image (PolicyDims<L> layout)
+    const half8* weights_lo;  // image of the low f16 pieces (f32-class forward); used when `f32class` is set
+    int f32class;             // 1: reference-precision forward (policy_forward_f32class) instead of the f16-operand one
     float std[4];           // exp(log_std)
     float logp_const;       // -sum(log_std) - 2*log(2*pi)
     uint32_t seed_lo, seed_hi;  // Philox key of the action noise

@@ -333,7 +333,7 @@ class PPO:
         # torch's per-layer kernels; sampling, log-probabilities and values stay torch float32.  The weights are re-packed once per rollout.
         if policy_forward not in ("torch", "f32class"):
             raise ValueError("policy_forward must be 'torch' or 'f32class'")
-        self.policy_forward = policy_forward if not fused_collect else "torch"
+        self.policy_forward = policy_forward   # with fused_collect: the precision of the forward INSIDE the closed-loop kernel
         if fused_collect or self.policy_forward == "f32class":
             from .policy import MfmaPolicy
 
@@ -369,7 +369,8 @@ class PPO:
         self.noise_step += self.n_steps
         obs, act, logp, rew, done, trunc, last_obs = self.env.rollout_policy_device(
             self._mfma, self.n_steps, self.policy.log_std, noise_seed=self.noise_seed, first_step=first_step,
-            out=(self.buf_obs, self.buf_act, self.buf_lp, self.buf_rew, self._done_u8, self._trunc_u8))
+            out=(self.buf_obs, self.buf_act, self.buf_lp, self.buf_rew, self._done_u8, self._trunc_u8),
+            precision="f32" if self.policy_forward == "f32class" else "f16-operands")
         self.buf_done.copy_(done)
         T, N = self.n_steps, self.n_envs
         self.num_timesteps += T * N

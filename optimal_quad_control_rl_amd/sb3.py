@@ -188,18 +188,18 @@ class PPO:
                  _init_trainer=True):
         # precision: the throughput kernels (closed-loop collection, PPO update) compute with f16 matrix-core operands and f32 accumulation
         # (policy mean within 7e-4 of the reference's float32 nn_forward, gradient cosine >= 0.9985 against float32 autograd).
-        # precision="f32" is the REFERENCE-PRECISION mode: the collect phase's policy forward runs in the hand-written f32-class kernel
-        # (qr_policy_forward_f32class: every operand as two f16 pieces, 7e-7 against nn_forward -- round 6), sampling / log-probabilities /
-        # values and the whole update (forward, loss, backward, clipping, Adam) run in float32 through torch (the arithmetic SB3 itself
-        # uses, R:783-795) on the env's device tensors around the HIP env kernels.  A hand-written f32-class GRADIENT kernel does not
+        # precision="f32" is the REFERENCE-PRECISION mode: the collect phase is still one closed-loop kernel, with the hand-written f32-class
+        # policy forward inside (QR_ROLLOUT_F32CLASS / qr_policy_forward_f32class: every operand as two f16 pieces, 7e-7 against nn_forward --
+        # round 6); values and the whole update (forward, loss, backward, clipping, Adam) run in float32 through torch (the arithmetic SB3
+        # itself uses, R:783-795) on the env's device tensors.  A hand-written f32-class GRADIENT kernel does not
         # exist: this mode is ~40 x slower than the matrix-core path and is there for A/B runs that ask whether an outcome is the
         # recipe's or the arithmetic's.
         precision = precision or "f16-operands"
         if precision not in ("f16-operands", "f32"):
             raise ValueError("precision must be 'f16-operands' or 'f32'")
         self.precision = precision
-        if precision == "f32":
-            native_update, fused_collect = False, False
+        if precision == "f32":   # torch float32 update; the collect phase stays ONE kernel with the f32-class forward inside (round 6)
+            native_update = False
         if policy not in ("MlpPolicy", None):
             raise ValueError("only SB3's 'MlpPolicy' exists here")
         pk = dict(policy_kwargs or {})

@@ -608,10 +608,14 @@ class Quadcopter3DGates(_Base):
             self._last_obs = obs[K - 1]
         return out
 
-    def rollout_policy_device(self, policy, num_steps, log_std, noise_seed=0, first_step=0, deterministic=False, out=None):
+    def rollout_policy_device(self, policy, num_steps, log_std, noise_seed=0, first_step=0, deterministic=False, out=None,
+                              precision="f16-operands"):
         """Closed-loop rollout in ONE kernel (qr_rollout_policy): K x [obs -> MFMA policy -> sample -> env.step].
         `policy` is an optimal_quad_control_rl_amd.policy.MfmaPolicy.  Returns device tensors
-        (obs[K,N,L], actions[K,N,4] unclipped, logp[K,N], reward[K,N], done[K,N] u8, trunc[K,N] u8, last_obs[N,L])."""
+        (obs[K,N,L], actions[K,N,4] unclipped, logp[K,N], reward[K,N], done[K,N] u8, trunc[K,N] u8, last_obs[N,L]).
+        precision="f32": the policy forward inside the kernel at the reference's precision (QR_ROLLOUT_F32CLASS)."""
+        if precision not in ("f16-operands", "f32"):
+            raise ValueError("precision must be 'f16-operands' or 'f32'")
         K, n, dev = int(num_steps), self.num_envs, self.device
         if out is None:
             out = (torch.empty((K, n, self.state_len), dtype=torch.float32, device=dev),
@@ -624,7 +628,7 @@ class Quadcopter3DGates(_Base):
         ls = np.ascontiguousarray(log_std.detach().cpu().numpy() if isinstance(log_std, torch.Tensor) else log_std,
                                   dtype=np.float32).reshape(4)
         _lib.check(self._L.qr_rollout_policy(self._h, policy._h, K, _f32p(ls), int(noise_seed), int(first_step),
-                                             int(bool(deterministic)), _ptr(obs), _ptr(act), _ptr(logp), _ptr(rew),
+                                             int(bool(deterministic)) | (2 if precision == "f32" else 0), _ptr(obs), _ptr(act), _ptr(logp), _ptr(rew),
                                              _ptr(done), _ptr(trunc), _ptr(self._obs), self._stream()))
         self._last_obs = self._obs
         return obs, act, logp, rew, done, trunc, self._obs

@@ -144,16 +144,18 @@ def _policy_for(env, gain=20.0):
 
 @pytest.mark.parametrize("variant", ["e2e", "indi"])
 @pytest.mark.parametrize("n", [65536, 1000])
-def test_closed_loop_rollout_equals_policy_plus_step_launches(variant, n):
-    """deterministic closed-loop rollout kernel == K x [policy kernel, clip, step kernel], bit for bit."""
+@pytest.mark.parametrize("precision", ["f16-operands", "f32"])
+def test_closed_loop_rollout_equals_policy_plus_step_launches(variant, n, precision):
+    """deterministic closed-loop rollout kernel == K x [policy kernel, clip, step kernel], bit for bit -- with the f16-operand forward
+    and (round 6, QR_ROLLOUT_F32CLASS) with the reference-precision forward inside the kernel."""
     K = 48
     net, pol = _policy_for(_make(variant, 8))
     a, b = _make(variant, n), _make(variant, n)
-    obs, act, logp, rew, done, trunc, last = a.rollout_policy_device(pol, K, torch.zeros(4), deterministic=True)
+    obs, act, logp, rew, done, trunc, last = a.rollout_policy_device(pol, K, torch.zeros(4), deterministic=True, precision=precision)
     o = b.states_tensor.clone()
     for k in range(K):
         assert torch.equal(obs[k], o), k
-        mean = pol.forward(o)
+        mean = pol.forward(o, precision=precision)
         assert torch.equal(act[k], mean), k
         o2, r2, d2, t2 = b.step_device(mean.clamp(-1, 1).contiguous())
         assert torch.equal(rew[k], r2) and torch.equal(done[k], d2) and torch.equal(trunc[k], t2), k
