@@ -195,8 +195,10 @@ class PPO:
         # exist: this mode is ~40 x slower than the matrix-core path and is there for A/B runs that ask whether an outcome is the
         # recipe's or the arithmetic's.
         precision = precision or "f16-operands"
-        if precision not in ("f16-operands", "f32"):
-            raise ValueError("precision must be 'f16-operands' or 'f32'")
+        # precision="f32-collect": the f32-class forward in the collect phase, the f16-operand matrix-core kernels for the update (an A/B leg
+        # that isolates the precision of the COLLECTED actions / log-probabilities at full training speed)
+        if precision not in ("f16-operands", "f32", "f32-collect"):
+            raise ValueError("precision must be 'f16-operands', 'f32' or 'f32-collect'")
         self.precision = precision
         if precision == "f32":   # torch float32 update; the collect phase stays ONE kernel with the f32-class forward inside (round 6)
             native_update = False
@@ -236,7 +238,7 @@ class PPO:
                                     learning_rate=learning_rate, vf_coef=vf_coef, ent_coef=ent_coef,
                                     max_grad_norm=max_grad_norm, net_arch=self.net_arch, log_std_init=self.log_std_init,
                                     seed=self.seed, target_kl=target_kl, fused_collect=fused, native_update=native,
-                                    policy_forward="f32class" if (precision == "f32" and tuple(self.net_arch) == (120, 120, 120)) else "torch")
+                                    policy_forward="f32class" if (precision in ("f32", "f32-collect") and tuple(self.net_arch) == (120, 120, 120)) else "torch")
             self._net = self._trainer.policy
             self.observation_dim = int(core.state_len)
         else:

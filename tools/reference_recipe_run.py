@@ -25,7 +25,8 @@ ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--steps", type=float, default=1.03e9)
 ap.add_argument("--eval-every", type=int, default=40, help="evaluate every this many checkpoints (one checkpoint = 10 rollouts = 1e6 env-steps)")
 ap.add_argument("--lap-target", type=float, default=2.6)
-ap.add_argument("--precision", default="f16-operands", help="f16-operands (hand-written matrix-core kernels) | f32 (reference precision: torch float32 on the device)")
+ap.add_argument("--precision", default="f16-operands", help="f16-operands (hand-written matrix-core kernels) | f32 (f32-class collect kernel + torch float32 update) | "
+                "f32-collect (f32-class collect kernel + the f16-operand update kernels)")
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 
