@@ -80,8 +80,8 @@ class RolloutGather:
         self.world = dist.get_world_size(group)
         self._bufs = {}
 
-    def buffers(self, K, n, L, device, obs_dtype=torch.float32):
-        key = (int(K), int(n), int(L), str(device), obs_dtype)
+    def buffers(self, K, n, L, device, obs_dtype=torch.float32, slot=0):
+        key = (int(K), int(n), int(L), str(device), obs_dtype, int(slot))
         b = self._bufs.get(key)
         if b is None:
             w = self.world
@@ -101,6 +101,33 @@ class RolloutGather:
         dist.all_gather_into_tensor(g_rew.view(self.world * K, n), rew, group=self.group)
         dist.all_gather_into_tensor(g_done.view(self.world * K, n), done, group=self.group)
         return GatheredRollout(g_obs, g_rew, g_done)
+
+    def gather_async(self, obs, rew, done, slot=0):
+        """The same three collectives started WITHOUT waiting (async_op: RCCL runs them on its own stream, so the next collect kernel on the
+        caller's stream overlaps them -- round 5's review: the blocking form leaves ~22 us per step-equivalent of xGMI time on the table).
+        Returns a PendingGather; `.wait()` gives the GatheredRollout.  `slot` (0 / 1) selects one of two sets of receive buffers: the
+        gather of rollout i may still be in flight while rollout i + 1 is collected and gathered into the other set.  The SEND buffers
+        (obs, rew, done) must not be overwritten before `.wait()` -- alternate them too (ShardedRaceEnv.rollouts_overlapped does)."""
+        assert obs.is_contiguous() and rew.is_contiguous() and done.is_contiguous()
+        assert done.dtype == torch.uint8 and rew.dtype == torch.float32
+        K, n, L = obs.shape
+        g_obs, g_rew, g_done = self.buffers(K, n, L, obs.device, obs.dtype, slot)
+        # (on RCCL the collective's stream first waits for the caller's current stream: it sees the collect kernel's writes)
+        works = [dist.all_gather_into_tensor(g_obs.view(self.world * K, n, L), obs, group=self.group, async_op=True),
+                 dist.all_gather_into_tensor(g_rew.view(self.world * K, n), rew, group=self.group, async_op=True),
+                 dist.all_gather_into_tensor(g_done.view(self.world * K, n), done, group=self.group, async_op=True)]
+        return PendingGather(works, GatheredRollout(g_obs, g_rew, g_done))
+
+
+class PendingGather:
+    def __init__(self, works, result):
+        self._works, self._result = works, result
+
+    def wait(self):
+        for w in self._works:
+            w.wait()   # (on RCCL: makes the caller's current stream wait for the collective; no host synchronisation)
+        self._works = []
+        return self._result
 
 
 class ShardedRaceEnv:
@@ -134,3 +161,27 @@ class ShardedRaceEnv:
     def gather_rollout(self, obs, rew, done):
         """All ranks receive the full rollout as a GatheredRollout (rank-major receive buffers, reused between calls)."""
         return self._gather.gather(obs, rew, done)
+
+    def rollouts_overlapped(self, action_batches):
+        """Generator over `action_batches` (local actions [K][n][4] per rollout): yields the GatheredRollout of rollout i while rollout
+        i + 1 is already being collected -- the gather of one rollout overlaps the collect kernel of the next (two alternating sets of
+        send and receive buffers).  A yielded GatheredRollout stays valid until the rollout after the next one has been gathered."""
+        pending, out_bufs = None, [None, None]
+        for i, acts in enumerate(action_batches):
+            slot = i & 1
+            out = self.env.rollout_device(acts, out_bufs[slot]) if out_bufs[slot] is not None and self._reuses_out() else self.env.rollout_device(acts)
+            out_bufs[slot] = out
+            obs, rew, done = out[0], out[1], out[2]
+            nxt = self._gather.gather_async(obs.contiguous(), rew.contiguous(), done.to(torch.uint8).contiguous(), slot)
+            if pending is not None:
+                yield pending.wait()
+            pending = nxt
+        if pending is not None:
+            yield pending.wait()
+
+    def _reuses_out(self):
+        import inspect
+        try:
+            return "out" in inspect.signature(self.env.rollout_device).parameters
+        except (TypeError, ValueError):
+            return False

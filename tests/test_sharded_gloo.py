@@ -96,6 +96,42 @@ def test_world2_sharded_rollout_and_allgather(tmp_path):
     assert (tmp_path / "ok").exists()
 
 
+def _worker_overlap(rank, world, port, n_global, K, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from optimal_quad_control_rl_amd.sharded import ShardedRaceEnv
+
+    g = torch.Generator().manual_seed(1)
+    batches = [torch.rand((K, n_global, 4), generator=g) * 2 - 1 for _ in range(5)]   # same on every rank
+    env = ShardedRaceEnv(n_global, lambda n, base: CpuStandInEnv(n, base))
+    env.reset()
+    got = []
+    for gr in env.rollouts_overlapped(b[:, env.lo:env.hi].contiguous() for b in batches):
+        o, r, d = gr.global_view()
+        got.append((o.reshape(K, n_global, -1).clone(), r.reshape(K, n_global).clone(), d.reshape(K, n_global).clone()))
+    assert len(got) == len(batches)
+    # blocking reference: same env construction, gather_rollout after every rollout
+    ref_env = ShardedRaceEnv(n_global, lambda n, base: CpuStandInEnv(n, base))
+    ref_env.reset()
+    for b, (o, r, d) in zip(batches, got):
+        obs, rew, done, _ = ref_env.rollout(b[:, ref_env.lo:ref_env.hi].contiguous())
+        fo, fr, fd = ref_env.gather_rollout(obs, rew, done.to(torch.uint8)).global_view()
+        assert torch.equal(fo.reshape(K, n_global, -1), o) and torch.equal(fr.reshape(K, n_global), r) and torch.equal(fd.reshape(K, n_global), d)
+    if rank == 0:
+        open(os.path.join(tmp, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gather_overlapped_with_the_next_collect(tmp_path):
+    """the rollout-boundary all-gather started asynchronously into alternating receive buffers, so that the
+    gather of rollout i overlaps the collect of rollout i + 1 -- same gathered rollouts as the blocking form, five rollouts in a row."""
+    port = _free_port()
+    mp.spawn(_worker_overlap, args=(2, port, 32, 40, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
 def test_shard_range_partition():
     from optimal_quad_control_rl_amd.sharded import shard_range
 
