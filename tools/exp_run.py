@@ -13,4 +13,4 @@ import bench_ppo_update as U
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 Bn = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
 r = U.measure(L=L, B=Bn, iters=100, with_torch=False)
-print(name, os.environ.get("QR_PPO_PARTIAL", "bf16"), json.dumps({k: r[k] for k in r if k.endswith("_us") or k.startswith("status_")}))
+print(name, "bf16", json.dumps({k: r[k] for k in r if k.endswith("_us") or k.startswith("status_")}))

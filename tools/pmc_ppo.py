@@ -40,7 +40,7 @@ else:
         cal = [v for v in cal if v > 0.9 * max(cal)]
         out = {"cal": sum(cal) / len(cal)}
         for name in ("ppo_adv_stats", "ppo_grad", "ppo_phase_a", "ppo_phase_b", "ppo_apply"):   # ppo_grad: the fused form (default);
-            v = [x for k, x in rows if name in k][4:]                                            # phase A / B: QR_PPO_SPLIT=1
+            v = [x for k, x in rows if name in k][4:]                                            # (the removed two-kernel form)
             if v:
                 out[name] = sum(v) / len(v)
         return out

@@ -31,7 +31,7 @@ pol = ActorCritic(L_, 4).to(dev)
 up = MfmaPpoUpdater(pol, L_, dev, Bn)
 lib = _lib.load()
 lib.qr_ppo_debug_set_ticks.argtypes = [C.c_void_p, C.c_void_p]
-grad4 = os.environ.get("QR_PPO_GRAD4") == "1" or os.environ.get("QR_PPO_SPLIT") == "1"
+grad4 = False   # (the round 1-2 kernel forms and their QR_PPO_* switches were removed in round 6: one role-split kernel)
 waves = 2 * min(Bn // 64, 256) * 2 * (1 if grad4 else 2)    # two nets x groups x two 32-sample tiles (one chain wave each) [+ as many dW waves]
 ticks = torch.zeros((waves, 16), dtype=torch.int64, device=dev)
 for k in range(5):
@@ -43,7 +43,7 @@ for k in range(12):
     torch.cuda.synchronize()
     reps.append(ticks.cpu().numpy().copy())
 t = np.stack(reps)[2:]
-split = os.environ.get("QR_PPO_SPLIT") == "1"
+split = False
 if split:
     names = ["entry", "image -> LDS + barrier", "index / obs gather, layer-1 operand, X0^T store", "fwd layer 1", "h1^T store", "fwd layer 2",
              "h2^T store", "fwd layer 3", "h3^T store", "output layer + loss gradient", "d4, d4^T store, d3", "d3^T store", "d2", "d2^T store",
