@@ -248,6 +248,13 @@ int qr_ppo_pack(qr_ppo* ppo, const float* theta_dev, void* stream);
 int qr_ppo_grad(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const float* act_dev,
                 const float* old_logp_dev, const float* adv_dev, const float* ret_dev, const int32_t* idx_dev, int32_t B,
                 float clip, float vf_coef, float ent_coef, float* grad_out_dev, float* stats_dev, void* stream);
+/* The same gradient at the reference's precision (round 6): every matrix product of the forward pass, the backward pass and the weight
+ * gradients on the matrix core with BOTH operands as two f16 pieces and f32 accumulation (csrc/quadrace_ppo_f32.hip) -- float32-class like the
+ * reference's torch update (R:783-795; cosine against float64 autograd 1 - 1e-9 level instead of 0.9985), several times slower than
+ * qr_ppo_grad.  Same arguments, same grad_out layout; theta_dev is read directly (no operand images).  Follow with qr_ppo_apply for the step. */
+int qr_ppo_grad_f32class(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const float* act_dev,
+                         const float* old_logp_dev, const float* adv_dev, const float* ret_dev, const int32_t* idx_dev, int32_t B,
+                         float clip, float vf_coef, float ent_coef, float* grad_out_dev, float* stats_dev, void* stream);
 /* one complete minibatch update of theta (and the Adam moments).  adam_step = 1, 2, ...: the caller counts the updates; adam_step = 0:
  * the library's device-resident count of optimiser steps REALLY taken is used and advanced (launches turned into no-ops by the
  * early stop or a non-finite gradient norm do not count, like torch.optim.Adam under SB3) -- see qr_ppo_adam_step.  lr >= 0 (a

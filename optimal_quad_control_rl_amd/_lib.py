@@ -67,6 +67,7 @@ SIGNATURES = {
     "qr_ppo_num_params": (C.c_int, [_vp]),
     "qr_ppo_pack": (C.c_int, [_vp, _vp, _vp]),
     "qr_ppo_grad": (C.c_int, [_vp] * 8 + [C.c_int32, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp]),
+    "qr_ppo_grad_f32class": (C.c_int, [_vp] * 8 + [C.c_int32, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp]),
     "qr_ppo_minibatch": (C.c_int, [_vp] * 10 + [C.c_int32] + [C.c_float] * 8 + [C.c_int32, _vp, _vp]),
     "qr_ppo_forward": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "qr_ppo_gae": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float] + [_vp] * 7),
@@ -95,7 +96,7 @@ SIGNATURES = {
 }
 
 
-ADDED_IN_ROUND_5 = ("qr_set_rollout_form", "qr_ppo_create_ex", "q3_rollout", "qr_policy_forward_f32class")   # (and round 6)
+ADDED_IN_ROUND_5 = ("qr_set_rollout_form", "qr_ppo_create_ex", "q3_rollout", "qr_policy_forward_f32class", "qr_ppo_grad_f32class")   # (and round 6)
 
 
 class QuadraceError(RuntimeError):

@@ -13,7 +13,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libquadrace.so")
-SOURCES = ["quadrace_kernels.hip", "quadrace_kernels_mlp.hip", "quadrace_abi.hip", "quadrace_policy.hip", "quadrace_ppo.hip", "quad3d.hip"]
+SOURCES = ["quadrace_kernels.hip", "quadrace_kernels_mlp.hip", "quadrace_abi.hip", "quadrace_policy.hip", "quadrace_ppo.hip", "quadrace_ppo_f32.hip",
+           "quad3d.hip"]
 HEADERS = ["quadrace_device.hpp", "quadrace_policy.hpp", os.path.join("..", "..", "include", "quadrace.h"),
            os.path.join("..", "..", "include", "quad3d.h"), "quadrace_kernels.hip"]   # (quadrace_kernels_mlp.hip includes quadrace_kernels.hip)
 # quadrace_kernels_mlp.hip = the two fused E2E + residual-MLP rollout kernels, without the SLP vectoriser: at two waves per SIMD a

@@ -1625,6 +1625,8 @@ struct qr_ppo {
         float clip = 0, vf_coef = 0, ent_coef = 0, max_grad_norm = 0, beta1 = 0, beta2 = 0, eps = 0, target_kl = 0;
     } eg;
     hipStream_t capture_stream = nullptr;
+    void* f32_scratch = nullptr;           // activations / deltas of the f32-class gradient path (quadrace_ppo_f32.hip), allocated on first use
+    size_t f32_scratch_bytes = 0;
     unsigned long long shuffle_seed = 0;   // key of the on-device epoch permutations (qr_ppo_shuffle_state)
 };
 
@@ -1632,6 +1634,14 @@ namespace qr {
 int set_last_error(int code, const std::string& msg);  // quadrace_abi.hip
 hipError_t launch_policy(int L, const half8* w, int n, const float* obs, float* mean, hipStream_t st);  // quadrace_policy.hip
 const half8* ppo_policy_image(const qr_ppo* p) { return p ? p->d_images : nullptr; }
+// what quadrace_ppo_f32.hip needs of a handle
+int ppo_handle_info(const qr_ppo* p, int* L, int* device, int* max_B, int* num_params) {
+    if (!p) return QR_E_INVALID;
+    *L = p->L; *device = p->device; *max_B = p->max_B; *num_params = p->num_params;
+    return QR_OK;
+}
+void** ppo_f32_scratch_slot(qr_ppo* p) { return &p->f32_scratch; }
+size_t* ppo_f32_scratch_bytes(qr_ppo* p) { return &p->f32_scratch_bytes; }
 }  // namespace qr
 
 namespace {
@@ -1833,6 +1843,7 @@ int qr_ppo_destroy(qr_ppo* p) {
     (void)hipFree(p->d_wave);
     (void)hipFree(p->d_ctrl);
     (void)hipFree(p->d_mbstats);
+    if (p->f32_scratch) (void)hipFree(p->f32_scratch);
     if (p->eg.exec) (void)hipGraphExecDestroy(p->eg.exec);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     delete p;

@@ -88,7 +88,10 @@ class MfmaPpoUpdater:
 
     force_data_parallel = False   # test hook: take the all-reduce path on a single rank
 
-    def __init__(self, policy, obs_len, device, max_minibatch, betas=(0.9, 0.999), eps=1e-5, flags=0):
+    def __init__(self, policy, obs_len, device, max_minibatch, betas=(0.9, 0.999), eps=1e-5, flags=0, precision="f16-operands"):
+        if precision not in ("f16-operands", "f32"):
+            raise ValueError("precision must be 'f16-operands' or 'f32'")
+        self.precision = precision   # "f32": grad() / minibatch() run the reference-precision gradient kernels (qr_ppo_grad_f32class)
         import ctypes as C
 
         from . import _lib
@@ -163,11 +166,13 @@ class MfmaPpoUpdater:
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
         assert idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()
 
-    def grad(self, obs, act, old_lp, adv, ret, idx, clip=0.2, vf_coef=0.5, ent_coef=0.0, stats=False):
-        """Flat gradient of the PPO loss on the rows `idx` (no clipping, no optimiser step)."""
+    def grad(self, obs, act, old_lp, adv, ret, idx, clip=0.2, vf_coef=0.5, ent_coef=0.0, stats=False, precision=None):
+        """Flat gradient of the PPO loss on the rows `idx` (no clipping, no optimiser step).  precision="f32": the reference-precision
+        kernels (qr_ppo_grad_f32class: every GEMM operand as two f16 pieces); default = this updater's `precision`."""
         self._check(obs, act, old_lp, adv, ret, idx)
         g = torch.empty(self.theta.numel() + 4, dtype=torch.float32, device=self.device)  # gradient + minibatch statistics
-        self._lib.check(self._L.qr_ppo_grad(self._h, self._p(self.theta), self._p(obs), self._p(act), self._p(old_lp), self._p(adv),
+        fn = self._L.qr_ppo_grad_f32class if (precision or self.precision) == "f32" else self._L.qr_ppo_grad
+        self._lib.check(fn(self._h, self._p(self.theta), self._p(obs), self._p(act), self._p(old_lp), self._p(adv),
                                             self._p(ret), self._p(idx), int(idx.numel()), clip, vf_coef, ent_coef, self._p(g),
                                             self._p(self.stats) if stats else None, self._stream()))
         return g
@@ -234,6 +239,9 @@ class MfmaPpoUpdater:
                                              self._p(self.stats) if stats else None, self._stream()))
 
     def minibatch(self, obs, act, old_lp, adv, ret, idx, lr, clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5):
+        if self.precision == "f32":   # reference-precision gradient kernels, then the (f32) apply kernel; averaged across ranks when data parallel
+            g = self.grad(obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef, stats=False)
+            return self.apply(average_across_ranks(g) if self.data_parallel() else g, lr, int(idx.numel()), max_grad_norm)
         if self.data_parallel():
             # data parallel: every rank holds the same parameters and its own envs; average the gradient (and the minibatch
             # statistics that ride behind it: every rank then takes the same target-KL decision)
@@ -272,7 +280,7 @@ class PPO:
     def __init__(self, env, n_steps=32, batch_size=None, n_epochs=5, gamma=0.999, gae_lambda=0.95, clip_range=0.2,
                  learning_rate=3e-4, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, net_arch=(120, 120, 120),
                  log_std_init=0.0, seed=0, target_kl=None, lr_final_frac=1.0, total_timesteps_hint=None,
-                 fused_collect=False, native_update=False, truncation_bootstrap=True, policy_forward="torch"):
+                 fused_collect=False, native_update=False, truncation_bootstrap=True, policy_forward="torch", update_precision="f16-operands"):
         self.env = env
         self.n_envs, self.dev = env.num_envs, env.device
         self.n_steps, self.n_epochs = n_steps, n_epochs
@@ -318,8 +326,10 @@ class PPO:
         self._updater = None
         if native_update:
             assert tuple(net_arch) == (120, 120, 120), "the matrix-core update is built for the reference's 3 x 120 networks"
-            assert self.batch_size >= 64 and (T * N) % self.batch_size == 0
-            self._updater = MfmaPpoUpdater(self.policy, obs_dim, self.dev, self.batch_size)
+            assert self.batch_size >= (2 if update_precision == "f32" else 64) and (T * N) % self.batch_size == 0
+            # update_precision="f32": the reference-precision gradient kernels (qr_ppo_grad_f32class, three bf16 pieces per GEMM operand) + the
+            # f32 apply kernel, one minibatch at a time (no epoch graph); values of the collect phase then come from torch float32
+            self._updater = MfmaPpoUpdater(self.policy, obs_dim, self.dev, self.batch_size, precision=update_precision)
             self._updater.set_shuffle(0x5EED0000 + int(seed))   # on-device epoch permutations (single-process native update)
         self.fused_collect = fused_collect
         self.noise_seed = seed
@@ -374,7 +384,8 @@ class PPO:
         self.buf_done.copy_(done)
         T, N = self.n_steps, self.n_envs
         self.num_timesteps += T * N
-        value = (lambda o: self._updater.forward(1, o.contiguous()).contiguous()) if self._updater is not None else self.policy.value
+        f16_values = self._updater is not None and self._updater.precision != "f32"
+        value = (lambda o: self._updater.forward(1, o.contiguous()).contiguous()) if f16_values else self.policy.value
         if self.truncation_bootstrap:
             # rows that ended by the time limit (rare: at most one per env per max_steps): V of their terminal observation
             self.buf_term_val.zero_()
@@ -565,7 +576,7 @@ class PPO:
         if getattr(self, "_perm_buf", None) is None or self._perm_buf.numel() != B:
             self._perm_buf = torch.empty(B, dtype=torch.int32, device=self.dev)
         perm = self._perm_buf
-        if not up.data_parallel():
+        if not up.data_parallel() and up.precision != "f32":
             # the permutations are drawn on the device too (a keyed bijection per epoch, no sort); without the early stop ALL
             # epochs of this train() are one graph launch, with it one launch per epoch and one status read in between
             hp = (self.batch_size, lr, self.clip, self.vf_coef, self.ent_coef, self.max_grad_norm)
@@ -579,7 +590,8 @@ class PPO:
         else:
             for _ in range(self.n_epochs):
                 perm.copy_(torch.randperm(B, device=self.dev, generator=self._gen))
-                up.begin_epoch(adv, perm, self.batch_size)
+                if up.precision != "f32":   # (the f32-class gradient kernels form each minibatch's advantage statistics themselves)
+                    up.begin_epoch(adv, perm, self.batch_size)
                 for s in range(0, B, self.batch_size):
                     up.minibatch(obs, act, old_lp, adv, ret, perm[s:s + self.batch_size], lr, self.clip, self.vf_coef, self.ent_coef,
                                  self.max_grad_norm)

@@ -188,20 +188,19 @@ class PPO:
                  _init_trainer=True):
         # precision: the throughput kernels (closed-loop collection, PPO update) compute with f16 matrix-core operands and f32 accumulation
         # (policy mean within 7e-4 of the reference's float32 nn_forward, gradient cosine >= 0.9985 against float32 autograd).
-        # precision="f32" is the REFERENCE-PRECISION mode: the collect phase is still one closed-loop kernel, with the hand-written f32-class
-        # policy forward inside (QR_ROLLOUT_F32CLASS / qr_policy_forward_f32class: every operand as two f16 pieces, 7e-7 against nn_forward --
-        # round 6); values and the whole update (forward, loss, backward, clipping, Adam) run in float32 through torch (the arithmetic SB3
-        # itself uses, R:783-795) on the env's device tensors.  A hand-written f32-class GRADIENT kernel does not
-        # exist: this mode is ~40 x slower than the matrix-core path and is there for A/B runs that ask whether an outcome is the
-        # recipe's or the arithmetic's.
+        # precision="f32" is the REFERENCE-PRECISION mode, hand-written end to end since round 6: the collect phase is one closed-loop
+        # kernel with the f32-class policy forward inside (7e-7 against nn_forward), every minibatch update runs in the f32-class
+        # gradient kernels (three bf16 pieces per GEMM operand: cosine 1 - 1e-13 against float64 autograd) + the f32 apply kernel; only the
+        # value estimates of the collect phase come from torch float32.  Several times slower than the default path; for A/B runs that
+        # ask whether an outcome is the recipe's or the arithmetic's.
         precision = precision or "f16-operands"
         # precision="f32-collect": the f32-class forward in the collect phase, the f16-operand matrix-core kernels for the update (an A/B leg
         # that isolates the precision of the COLLECTED actions / log-probabilities at full training speed)
         if precision not in ("f16-operands", "f32", "f32-collect"):
             raise ValueError("precision must be 'f16-operands', 'f32' or 'f32-collect'")
         self.precision = precision
-        if precision == "f32":   # torch float32 update; the collect phase stays ONE kernel with the f32-class forward inside (round 6)
-            native_update = False
+        # precision="f32" (round 6): the collect phase stays ONE kernel with the f32-class forward inside, and the update runs in the
+        # hand-written reference-precision gradient kernels (qr_ppo_grad_f32class) + the f32 apply kernel -- no torch in the loop
         if policy not in ("MlpPolicy", None):
             raise ValueError("only SB3's 'MlpPolicy' exists here")
         pk = dict(policy_kwargs or {})
@@ -229,7 +228,7 @@ class PPO:
             # below 32 768 nodes) -- anything else, e.g. SB3's own defaults batch_size=64 x n_steps=2048 on > 128 envs, takes the
             # torch update on the same device tensors instead of failing inside learn()
             minibatches = rows // self.batch_size if self.batch_size > 0 else 0
-            shapes_ok = (tuple(self.net_arch) == (120, 120, 120) and self.batch_size >= 64 and rows % self.batch_size == 0
+            shapes_ok = (tuple(self.net_arch) == (120, 120, 120) and self.batch_size >= (2 if precision == "f32" else 64) and rows % self.batch_size == 0
                          and minibatches <= 4096 and minibatches * self.n_epochs <= 16384)
             native = shapes_ok if native_update == "auto" else bool(native_update)
             fused = (tuple(self.net_arch) == (120, 120, 120)) if fused_collect == "auto" else bool(fused_collect)
@@ -238,7 +237,8 @@ class PPO:
                                     learning_rate=learning_rate, vf_coef=vf_coef, ent_coef=ent_coef,
                                     max_grad_norm=max_grad_norm, net_arch=self.net_arch, log_std_init=self.log_std_init,
                                     seed=self.seed, target_kl=target_kl, fused_collect=fused, native_update=native,
-                                    policy_forward="f32class" if (precision in ("f32", "f32-collect") and tuple(self.net_arch) == (120, 120, 120)) else "torch")
+                                    policy_forward="f32class" if (precision in ("f32", "f32-collect") and tuple(self.net_arch) == (120, 120, 120)) else "torch",
+                                    update_precision="f32" if precision == "f32" else "f16-operands")
             self._net = self._trainer.policy
             self.observation_dim = int(core.state_len)
         else:

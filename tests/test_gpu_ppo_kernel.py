@@ -406,3 +406,104 @@ def test_fused_gradient_is_deterministic_and_stateless_across_minibatch_sizes():
     assert torch.equal(g1, g2) and torch.equal(gb, gb2)
     assert torch.isfinite(g1).all() and torch.isfinite(gb).all() and float(gb[:-4].abs().max()) > 0
     up.close()
+
+
+@pytest.mark.parametrize("L,B,clip", [(17, 1024, 0.2), (24, 5000, 0.2), (24, 16384, 50.0), (36, 256, 0.2), (13, 100, 50.0), (24, 40000, 0.2)])
+def test_f32class_gradient_matches_float64_autograd(L, B, clip):
+    """Round 6: the reference-precision gradient kernels (qr_ppo_grad_f32class: every GEMM operand of the forward pass,
+    the backward pass and the weight gradients as two f16 pieces, f32 accumulation) against FLOAT64 autograd on the same rows: cosine
+    >= 1 - 1e-6 over the whole gradient and per tensor, relative error per tensor at the float32 level (float32 torch autograd sits at the
+    same level), identical minibatch statistics -- where the f16-operand kernel has cosine >= 0.9985.  With clip = 0.2 a sample whose ratio
+    sits within float32 noise of the clip edge may take the other branch: the bound is looser there but still 100 x below the f16 kernel's."""
+    from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
+
+    rows = max(3000, 2 * B)
+    pol, ref, up16, obs, act, old_lp, adv, ret = _setup(L, rows, seed=L + 1, max_minibatch=max(4096, B))
+    up = MfmaPpoUpdater(pol, L, obs.device, max(4096, B), precision="f32")
+    idx = torch.randperm(rows, device=obs.device)[:B].to(torch.int32).contiguous()
+    vf_coef, ent_coef = 0.5, 0.01
+    up.stats.zero_()
+    g = up.grad(obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef, stats=True)
+    g16 = up16.grad(obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef)
+    ref64 = copy.deepcopy(ref).double()
+    loss, pg, vl, ratio = _torch_loss(ref64, obs.double(), act.double(), old_lp.double(), adv.double(), ret.double(), idx, clip, vf_coef, ent_coef)
+    loss.backward()
+    want = torch.cat(_flat_ref_grads(ref64))
+    n = want.numel()
+    assert g.numel() == n + 4 and torch.isfinite(g).all()
+    cos = float(torch.dot(g[:n].double(), want) / (g[:n].double().norm() * want.norm()))
+    cos16 = float(torch.dot(g16[:n].double(), want) / (g16[:n].double().norm() * want.norm()))
+    rel = float((g[:n].double() - want).norm() / want.norm())
+    print("L=%d B=%d clip=%g: f32-class cosine 1 - %.2e, relative error %.2e | f16-operand kernel cosine 1 - %.2e" % (L, B, clip, 1 - cos, rel, 1 - cos16))
+    assert cos >= 1 - 1e-6 and rel <= (2e-5 if clip > 1 else 1.5e-3), (cos, rel)
+    assert (1 - cos) * 50 < (1 - cos16)                                   # and it really is another class of arithmetic
+    names = [f"{nn}.{l}.{k}" for nn in ("pi", "vf") for l in (1, 2, 3, 4) for k in ("w", "b")] + ["log_std"]
+    off = 0
+    for name, r in zip(names, _flat_ref_grads(ref64)):
+        mine = g[off:off + r.numel()].double()
+        off += r.numel()
+        err = float((mine - r).norm() / (r.norm() + 1e-30))
+        assert err <= (5e-5 if clip > 1 or name.startswith("vf") else 5e-3), (name, err)
+    st = up.stats.cpu().numpy()
+    assert np.allclose(g[n:].cpu().numpy(), st, rtol=1e-6, atol=1e-6)
+    assert abs(st[0] / B - float(pg)) < 1e-5 * max(1.0, abs(float(pg))) and abs(st[1] / B - float(vl)) < 1e-5 * max(1.0, abs(float(vl)))
+    up.close()
+
+
+def test_f32class_minibatch_update_tracks_float64_adam():
+    """grad_f32class -> qr_ppo_apply: three minibatch updates of MfmaPpoUpdater(precision='f32') against torch.optim.Adam on float64
+    autograd gradients with the same clipping: parameters agree to 2e-6 (the f16-operand update: 1e-4 level)."""
+    from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
+
+    L, B, rows = 24, 4096, 16384
+    pol, ref, up16, obs, act, old_lp, adv, ret = _setup(L, rows, seed=9, max_minibatch=B)
+    up = MfmaPpoUpdater(pol, L, obs.device, B, precision="f32")
+    ref64 = copy.deepcopy(ref).double()
+    opt = torch.optim.Adam(ref64.parameters(), lr=3e-4, eps=1e-5)
+    perm = torch.randperm(rows, device=obs.device).to(torch.int32)
+    for k in range(3):
+        idx = perm[k * B:(k + 1) * B].contiguous()
+        up.minibatch(obs, act, old_lp, adv, ret, idx, lr=3e-4, clip=50.0, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5)
+        opt.zero_grad()
+        loss, *_ = _torch_loss(ref64, obs.double(), act.double(), old_lp.double(), adv.double(), ret.double(), idx, 50.0, 0.5, 0.0)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref64.parameters(), 0.5)
+        opt.step()
+    want = torch.cat([p.detach().reshape(-1) for net in (ref64.pi, ref64.vf) for m in net if isinstance(m, torch.nn.Linear) for p in (m.weight, m.bias)] + [ref64.log_std.detach()])
+    err = float((up.theta.double() - want).abs().max())
+    print("max |theta - float64 Adam| after 3 updates: %.2e" % err)
+    assert err <= 2e-6
+    up.close()
+
+
+def test_sb3_precision_f32_trains_on_the_hand_written_reference_precision_kernels():
+    """precision='f32' of the SB3-shaped PPO (round 6): the reference's own recipe shape (100 envs x 1000 steps, batch_size 5000, 10 epochs)
+    runs WITHOUT torch in the loop -- one closed-loop collect kernel with the f32-class policy forward, every minibatch update in the
+    f32-class gradient kernels + the f32 apply kernel -- and takes every one of its 2 x 10 x 20 optimiser steps with finite results;
+    after the same two rollouts its parameters stay close to the f16-operand path's (same seeds, same noise stream: the two differ by
+    arithmetic only)."""
+    from optimal_quad_control_rl_amd import PPO, Quadcopter3DGates, TRAIN_DISTURBANCE_RANGES, square_track
+
+    kw = dict(policy_kwargs=dict(activation_fn=torch.nn.ReLU, net_arch=[dict(pi=[120, 120, 120], vf=[120, 120, 120])]),
+              n_steps=1000, batch_size=5000, n_epochs=10, gamma=0.999, seed=5)
+    thetas = {}
+    for precision in ("f32", "f16-operands"):
+        env = Quadcopter3DGates(100, *square_track(), gates_ahead=1, infos_mode="none", seed=3)
+        env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+        m = PPO("MlpPolicy", env, precision=precision, **kw)
+        tr = m._trainer
+        assert tr.native_update and tr.fused_collect
+        assert tr._updater.precision == ("f32" if precision == "f32" else "f16-operands")
+        assert tr.policy_forward == ("f32class" if precision == "f32" else "torch")
+        theta0 = tr._updater.theta.clone()
+        m.learn(total_timesteps=2 * 100 * 1000)
+        st = tr.stats
+        assert m.num_timesteps == 200000 and st["updates"] == 2 * 10 * 20 and st["skipped_nonfinite"] == 0 and np.isfinite(st["loss"])
+        assert torch.isfinite(tr._updater.theta).all() and not torch.equal(tr._updater.theta, theta0)
+        thetas[precision] = (theta0, tr._updater.theta.clone())
+        env.close()
+    assert torch.equal(thetas["f32"][0], thetas["f16-operands"][0])                  # same initialisation
+    moved = float((thetas["f32"][1] - thetas["f32"][0]).norm())
+    apart = float((thetas["f32"][1] - thetas["f16-operands"][1]).norm())
+    print("parameters moved %.3f, the two precisions ended %.3f apart" % (moved, apart))
+    assert apart < moved                                                              # they went the same way
