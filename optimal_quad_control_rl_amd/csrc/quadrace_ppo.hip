@@ -1627,6 +1627,7 @@ struct qr_ppo {
     hipStream_t capture_stream = nullptr;
     void* f32_scratch = nullptr;           // activations / deltas of the f32-class gradient path (quadrace_ppo_f32.hip), allocated on first use
     size_t f32_scratch_bytes = 0;
+    void* f32_graphs = nullptr;            // its cached graphs (one per distinct argument set), released by qr::ppo_f32_release_graphs
     unsigned long long shuffle_seed = 0;   // key of the on-device epoch permutations (qr_ppo_shuffle_state)
 };
 
@@ -1642,6 +1643,10 @@ int ppo_handle_info(const qr_ppo* p, int* L, int* device, int* max_B, int* num_p
 }
 void** ppo_f32_scratch_slot(qr_ppo* p) { return &p->f32_scratch; }
 size_t* ppo_f32_scratch_bytes(qr_ppo* p) { return &p->f32_scratch_bytes; }
+void** ppo_f32_graphs_slot(qr_ppo* p) { return &p->f32_graphs; }
+hipStream_t* ppo_capture_stream_slot(qr_ppo* p) { return &p->capture_stream; }
+bool ppo_uses_graphs(const qr_ppo* p) { return p->epoch_graph; }
+void ppo_f32_release_graphs(void* cache);   // quadrace_ppo_f32.hip
 }  // namespace qr
 
 namespace {
@@ -1843,6 +1848,7 @@ int qr_ppo_destroy(qr_ppo* p) {
     (void)hipFree(p->d_wave);
     (void)hipFree(p->d_ctrl);
     (void)hipFree(p->d_mbstats);
+    qr::ppo_f32_release_graphs(p->f32_graphs);
     if (p->f32_scratch) (void)hipFree(p->f32_scratch);
     if (p->eg.exec) (void)hipGraphExecDestroy(p->eg.exec);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);

@@ -21,6 +21,8 @@
 
 #include <cmath>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/quadrace.h"
 #include "quadrace_policy.hpp"
@@ -33,6 +35,11 @@ void** ppo_f32_scratch_slot(qr_ppo* p);                                         
 size_t* ppo_f32_scratch_bytes(qr_ppo* p);
 
 constexpr int kHid = kPolHidden;   // 120
+constexpr int kF32Slices = 64, kF32Ld = 128;   // split-K layers of a weight gradient; row stride of its partial tiles
+void** ppo_f32_graphs_slot(qr_ppo* p);   // quadrace_ppo.hip: owned by the handle, released through ppo_f32_release_graphs
+hipStream_t* ppo_capture_stream_slot(qr_ppo* p);
+bool ppo_uses_graphs(const qr_ppo* p);
+void ppo_f32_release_graphs(void* cache);
 
 struct GemmArgs {
     const float* A; long sAm, sAk; const int* idxA;   // rowA(m) = idxA ? idxA[m] : m
@@ -60,16 +67,25 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& p0, bf16x8& p1, b
     }
 }
 
-// 256 threads = 4 waves = 4 consecutive 32-row tiles of C (blockIdx.y), one 32-column tile (blockIdx.x), K slice blockIdx.z.
-__global__ void __launch_bounds__(256) gemm_f32class_kernel(GemmArgs g) {
+// One launch serves the same layer of BOTH networks (the policy's and the value function's chains are independent).
+struct GemmPair { GemmArgs g[2]; int slices; };   // blockIdx.z = net * slices + K slice
+
+// 256 threads = 4 waves, one 32-column tile of C (blockIdx.x), network and K slice blockIdx.z.
+//   kWaveK = false (weight gradients: K = the minibatch's rows, split over blockIdx.z): the waves are 4 consecutive 32-row tiles (blockIdx.y).
+//   kWaveK = true  (layers: K <= 120, many row tiles): ONE 32-row tile (blockIdx.y) whose K-steps go round the 4 waves -- a chain of 2
+//                  K-steps per wave instead of 8, four times the waves in flight -- and whose 4 accumulators are summed through LDS in wave order.
+template <bool kWaveK>
+__global__ void __launch_bounds__(256) gemm_f32class_kernel(GemmPair pr) {
+    const int z_net = blockIdx.z / pr.slices, z_slice = blockIdx.z - z_net * pr.slices;
+    const GemmArgs& g = pr.g[z_net];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tm = blockIdx.y * 4 + wave, tn = blockIdx.x;
-    if (tm * 32 >= g.M) return;                               // wave-uniform
+    const int tm = kWaveK ? blockIdx.y : blockIdx.y * 4 + wave, tn = blockIdx.x;
+    if (tm * 32 >= g.M) return;                               // wave-uniform (kWaveK: workgroup-uniform)
     const int c = lane & 31, h = lane >> 5;
     const int m = tm * 32 + c, n = tn * 32 + c;
     const bool m_ok = m < g.M, n_ok = n < g.N;
     const long rowA = m_ok ? (long)(g.idxA ? g.idxA[m] : m) * g.sAm : 0;
-    const int k_lo = blockIdx.z * g.k_per_slice;
+    const int k_lo = z_slice * g.k_per_slice;
     const int k_hi = min(g.K, k_lo + g.k_per_slice);
     const f32x16p zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     f32x16p acc = zero;
@@ -104,11 +120,13 @@ __global__ void __launch_bounds__(256) gemm_f32class_kernel(GemmArgs g) {
             }
         }
     };
+    constexpr int kStride = kWaveK ? 64 : 16;
+    const int k_first = k_lo + (kWaveK ? 16 * wave : 0);
     float a[8], b[8], an[8], bn[8];
-    load(k_lo, a, b);
-    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
-        const bool more = k0 + 16 < k_hi;
-        if (more) load(k0 + 16, an, bn);          // the next K-step's loads fly while this one is split and multiplied
+    if (k_first < k_hi) load(k_first, a, b);
+    for (int k0 = k_first; k0 < k_hi; k0 += kStride) {
+        const bool more = k0 + kStride < k_hi;
+        if (more) load(k0 + kStride, an, bn);     // the next K-step's loads fly while this one is split and multiplied
         bf16x8 a0, a1, a2, b0, b1, b2;
         split8(a, a0, a1, a2);
         split8(b, b0, b1, b2);
@@ -124,17 +142,29 @@ __global__ void __launch_bounds__(256) gemm_f32class_kernel(GemmArgs g) {
             for (int j = 0; j < 8; ++j) { a[j] = an[j]; b[j] = bn[j]; }
         }
     }
-    if (!n_ok) return;
-    float* C = g.C + (long)blockIdx.z * g.c_slice;
-    const float bias = g.bias ? g.bias[n] : 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {   // lane l, register r: row (r & 3) + 8 (r >> 2) + 4 h of the tile, column c
+    float* C = g.C + (long)z_slice * g.c_slice;
+    const float bias = (g.bias && n_ok) ? g.bias[n] : 0.0f;
+    auto finish = [&](int r, float sum) {   // lane l, register r: row (r & 3) + 8 (r >> 2) + 4 h of the tile, column c
         const int mm = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (mm >= g.M) continue;
-        float v = acc[r] + bias;
+        if (mm >= g.M || !n_ok) return;
+        float v = sum + bias;
         if (g.relu) v = fmaxf(v, 0.0f);
         if (g.mask && !(g.mask[(long)mm * g.sMask + n] > 0.0f)) v = 0.0f;
         C[(long)mm * g.sCm + n] = v;
+    };
+    if constexpr (kWaveK) {
+        __shared__ float red[4][16][64];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {        // wave w finishes registers 4 w .. 4 w + 3
+            const int r = 4 * wave + j;
+            finish(r, ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) finish(r, acc[r]);
     }
 }
 
@@ -229,17 +259,26 @@ __global__ void __launch_bounds__(64) f32_finish_kernel(const float* __restrict_
     }
 }
 
-// weight gradient of one layer from its split-K partial tiles: dW[out][in] and db[out] (column `in` of the partial) x 1 / B, fixed order
-__global__ void __launch_bounds__(256) f32_dw_reduce_kernel(const float* __restrict__ partial, int slices, long slice_stride, int out_dim, int in_dim,
-                                                            int ld, float scale, float* __restrict__ gw, float* __restrict__ gb) {
+// weight gradient of one layer (both networks: blockIdx.y) from its split-K partial tiles: dW[out][in] and db[out] (column `in` of the
+// partial) x 1 / B, fixed order
+struct ReduceArgs { const float* partial[2]; int out_dim[2]; float* gw[2]; float* gb[2]; int slices; long slice_stride; int in_dim, ld; float scale; };
+__global__ void __launch_bounds__(256) f32_dw_reduce_kernel(ReduceArgs a) {
+    const int net = blockIdx.y;
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= out_dim * (in_dim + 1)) return;
-    const int m = e / (in_dim + 1), n = e % (in_dim + 1);
-    float s = 0.0f;
-    for (int z = 0; z < slices; ++z) s += partial[(size_t)z * slice_stride + (size_t)m * ld + n];
-    s *= scale;
-    if (n < in_dim) gw[(size_t)m * in_dim + n] = s;
-    else gb[m] = s;
+    if (e >= a.out_dim[net] * (a.in_dim + 1)) return;
+    const int m = e / (a.in_dim + 1), n = e % (a.in_dim + 1);
+    const float* partial = a.partial[net];
+    const float* q = partial + (size_t)m * a.ld + n;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;   // four interleaved chains (the loads of one round fly together), fixed order
+    int z = 0;
+    for (; z + 4 <= a.slices; z += 4) {
+        s0 += q[(size_t)z * a.slice_stride]; s1 += q[(size_t)(z + 1) * a.slice_stride];
+        s2 += q[(size_t)(z + 2) * a.slice_stride]; s3 += q[(size_t)(z + 3) * a.slice_stride];
+    }
+    for (; z < a.slices; ++z) s0 += q[(size_t)z * a.slice_stride];
+    float s = ((s0 + s1) + (s2 + s3)) * a.scale;
+    if (n < a.in_dim) a.gw[net][(size_t)m * a.in_dim + n] = s;
+    else a.gb[net][m] = s;
 }
 
 }  // namespace qr
@@ -264,12 +303,129 @@ NetOff32 net_off32(int L, int O) {   // = net_off() of quadrace_ppo.hip: [w1 b1 
     return o;
 }
 
-void launch_gemm(const qr::GemmArgs& g, int slices, hipStream_t st) {
-    dim3 grid((g.N + 31) / 32, ((g.M + 31) / 32 + 3) / 4, slices);
-    hipLaunchKernelGGL(qr::gemm_f32class_kernel, grid, dim3(256), 0, st, g);
+void launch_gemm(const qr::GemmArgs& g0, const qr::GemmArgs& g1, int slices, hipStream_t st) {
+    qr::GemmPair pr;
+    pr.g[0] = g0; pr.g[1] = g1; pr.slices = slices;
+    const int M = g0.M > g1.M ? g0.M : g1.M, N = g0.N > g1.N ? g0.N : g1.N;
+    const int tiles_m = (M + 31) / 32;
+    if (slices == 1) {   // a layer: K-steps round the waves of one row tile
+        hipLaunchKernelGGL(qr::gemm_f32class_kernel<true>, dim3((N + 31) / 32, tiles_m, 2), dim3(256), 0, st, pr);
+    } else {             // a weight gradient: split-K over the grid
+        hipLaunchKernelGGL(qr::gemm_f32class_kernel<false>, dim3((N + 31) / 32, (tiles_m + 3) / 4, 2 * slices), dim3(256), 0, st, pr);
+    }
+}
+
+// One call's arguments: the key of its cached graph (the launches address nothing else that changes from call to call).
+struct GradCall {
+    const float *theta, *obs, *act, *old_logp, *adv, *ret; const int32_t* idx; int32_t B; float clip, vf_coef, ent_coef; float *grad, *stats;
+    bool operator==(const GradCall& o) const {
+        return theta == o.theta && obs == o.obs && act == o.act && old_logp == o.old_logp && adv == o.adv && ret == o.ret && idx == o.idx && B == o.B &&
+               clip == o.clip && vf_coef == o.vf_coef && ent_coef == o.ent_coef && grad == o.grad && stats == o.stats;
+    }
+};
+struct GraphCache {
+    static constexpr size_t kMax = 256;   // a training loop revisits the same (minibatch offset, buffers) set every epoch; beyond this the oldest goes
+    std::vector<std::pair<GradCall, hipGraphExec_t>> entries;
+    size_t next_victim = 0;
+};
+
+// the launches of one gradient evaluation, in order, on `st`
+void enqueue_grad(const GradCall& c, int L, int max_B, int np, float* base, hipStream_t st) {
+    const int H = qr::kHid, B = c.B;
+    constexpr int kSlices = qr::kF32Slices, kLd = qr::kF32Ld;
+    const size_t R = (size_t)max_B, n_h = R * H, n_o = R * 4;
+    float* Hn[2][3]; float* OUT[2]; float* DA[2]; float* DB[2]; float* D4[2]; float* PART[2];
+    float* q = base;
+    for (int net = 0; net < 2; ++net) {
+        for (int l = 0; l < 3; ++l) { Hn[net][l] = q; q += n_h; }
+        OUT[net] = q; q += n_o;
+        DA[net] = q; q += n_h;
+        DB[net] = q; q += n_h;
+        D4[net] = q; q += n_o;
+        PART[net] = q; q += (size_t)kSlices * H * kLd;
+    }
+    float* LOSSP = q; q += ((R + 255) / 256) * 8;
+    double* ADV = reinterpret_cast<double*>(q);   // 8-byte aligned: every block above is a multiple of 2 floats
+    const int outs[2] = {4, 1};
+    const NetOff32 off[2] = {net_off32(L, 4), net_off32(L, 1)};
+    const float* th[2] = {c.theta, c.theta + off[0].total};
+    const float* log_std = c.theta + off[0].total + off[1].total;
+    const int in[4] = {L, H, H, H};
+    // ---- forward, both nets per launch
+    for (int l = 0; l < 4; ++l) {
+        qr::GemmArgs g[2];
+        for (int net = 0; net < 2; ++net) {
+            g[net] = qr::GemmArgs{};
+            if (l == 0) { g[net].A = c.obs; g[net].sAm = L; g[net].sAk = 1; g[net].idxA = c.idx; }
+            else { g[net].A = Hn[net][l - 1]; g[net].sAm = H; g[net].sAk = 1; }
+            g[net].B = th[net] + off[net].w[l]; g[net].sBk = 1; g[net].sBn = in[l]; g[net].b_ones_col = -1;      // B(k, n) = W[n][k]
+            g[net].C = l < 3 ? Hn[net][l] : OUT[net]; g[net].sCm = l < 3 ? H : 4;
+            g[net].M = B; g[net].N = l < 3 ? H : outs[net]; g[net].K = in[l]; g[net].k_per_slice = in[l];
+            g[net].bias = th[net] + off[net].b[l]; g[net].relu = l < 3;
+        }
+        launch_gemm(g[0], g[1], 1, st);
+    }
+    // ---- loss
+    hipLaunchKernelGGL(qr::f32_adv_stats_kernel, dim3(1), dim3(1024), 0, st, c.adv, c.idx, B, ADV);
+    qr::LossArgs la{};
+    la.mean = OUT[0]; la.value = OUT[1]; la.act = c.act; la.old_logp = c.old_logp; la.adv = c.adv; la.ret = c.ret; la.log_std = log_std;
+    la.idx = c.idx; la.adv_acc = ADV; la.B = B; la.clip = c.clip; la.vf_coef = c.vf_coef; la.d_mean = D4[0]; la.d_value = D4[1]; la.partial = LOSSP;
+    const int lblocks = (B + 255) / 256;
+    hipLaunchKernelGGL(qr::f32_loss_kernel, dim3(lblocks), dim3(256), 0, st, la);
+    hipLaunchKernelGGL(qr::f32_finish_kernel, dim3(1), dim3(64), 0, st, LOSSP, lblocks, B, c.ent_coef, c.grad, np, c.stats);
+    // ---- backward + weight gradients, layer 4 down to 1, both nets per launch
+    const int k_per_slice = (((B + kSlices - 1) / kSlices) + 15) / 16 * 16;
+    const int slices = (B + k_per_slice - 1) / k_per_slice;
+    const float* delta[2] = {D4[0], D4[1]};     // [B][ld_delta]
+    int ld_delta = 4;
+    for (int l = 3; l >= 0; --l) {
+        // dW_l [out][in + 1] = delta^T x [h_(l-1) | 1], K = the minibatch's rows, split over `slices` workgroup layers
+        qr::GemmArgs g[2];
+        qr::ReduceArgs r{};
+        for (int net = 0; net < 2; ++net) {
+            const int out = l < 3 ? H : outs[net];
+            float* gnet = c.grad + (net == 0 ? 0 : off[0].total);
+            g[net] = qr::GemmArgs{};
+            g[net].A = delta[net]; g[net].sAm = 1; g[net].sAk = ld_delta;                              // A(m = unit, k = row) = delta[row][m]
+            if (l == 0) { g[net].B = c.obs; g[net].sBk = L; g[net].sBn = 1; g[net].idxB = c.idx; }
+            else { g[net].B = Hn[net][l - 1]; g[net].sBk = H; g[net].sBn = 1; }
+            g[net].b_ones_col = in[l];
+            g[net].C = PART[net]; g[net].sCm = kLd; g[net].c_slice = (long)H * kLd;
+            g[net].M = out; g[net].N = in[l] + 1; g[net].K = B; g[net].k_per_slice = k_per_slice;
+            r.partial[net] = PART[net]; r.out_dim[net] = out; r.gw[net] = gnet + off[net].w[l]; r.gb[net] = gnet + off[net].b[l];
+        }
+        launch_gemm(g[0], g[1], slices, st);
+        r.slices = slices; r.slice_stride = (long)H * kLd; r.in_dim = in[l]; r.ld = kLd; r.scale = 1.0f / (float)B;
+        hipLaunchKernelGGL(qr::f32_dw_reduce_kernel, dim3((H * (in[l] + 1) + 255) / 256, 2), dim3(256), 0, st, r);
+        if (l == 0) break;
+        // delta_(l-1) [B][in] = (delta_l [B][out] x W_l [out][in]) where h_(l-1) > 0
+        qr::GemmArgs b[2];
+        for (int net = 0; net < 2; ++net) {
+            const int out = l < 3 ? H : outs[net];
+            b[net] = qr::GemmArgs{};
+            b[net].A = delta[net]; b[net].sAm = ld_delta; b[net].sAk = 1;
+            b[net].B = th[net] + off[net].w[l]; b[net].sBk = in[l]; b[net].sBn = 1; b[net].b_ones_col = -1;   // B(k = out unit, n = in unit) = W[k][n]
+            float* dst = (delta[net] == DA[net]) ? DB[net] : DA[net];
+            b[net].C = dst; b[net].sCm = H;
+            b[net].M = B; b[net].N = in[l]; b[net].K = out; b[net].k_per_slice = out;
+            b[net].mask = Hn[net][l - 1]; b[net].sMask = H;
+        }
+        launch_gemm(b[0], b[1], 1, st);
+        for (int net = 0; net < 2; ++net) delta[net] = b[net].C;
+        ld_delta = H;
+    }
 }
 
 }  // namespace
+
+namespace qr {
+void ppo_f32_release_graphs(void* cache) {   // qr_ppo_destroy
+    GraphCache* gc = static_cast<GraphCache*>(cache);
+    if (!gc) return;
+    for (auto& e : gc->entries) (void)hipGraphExecDestroy(e.second);
+    delete gc;
+}
+}  // namespace qr
 
 extern "C" {
 
@@ -281,15 +437,14 @@ int qr_ppo_grad_f32class(qr_ppo* p, const float* theta_dev, const float* obs_dev
     if (!theta_dev || !obs_dev || !act_dev || !old_logp_dev || !adv_dev || !ret_dev || !idx_dev || !grad_out_dev)
         return f32fail(QR_E_INVALID, "qr_ppo_grad_f32class: null argument");
     if (B < 2 || B > max_B) return f32fail(QR_E_INVALID, "qr_ppo_grad_f32class: minibatch size must be >= 2 and <= max_minibatch");
+    if (net_off32(L, 4).total + net_off32(L, 1).total + 4 != np) return f32fail(QR_E_STATE, "qr_ppo_grad_f32class: parameter layout mismatch");
     F32_HIP(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;
     const int H = qr::kHid;
-    // ---- scratch (one block per handle, sized for max_minibatch): per net H1 H2 H3 [R][120], OUT [R][4]; deltas DA DB [R][120], D4 [R][4];
-    //      weight-gradient partial tiles [kSlices][120][128]; loss partial sums; advantage sums
-    constexpr int kSlices = 64, kLd = 128;
+    // ---- scratch (one block per handle, sized for max_minibatch), per net: H1 H2 H3 [R][120], OUT [R][4], deltas DA DB [R][120], D4 [R][4],
+    //      weight-gradient partial tiles [kF32Slices][120][128]; then the loss partial sums and the advantage sums
     const size_t R = (size_t)max_B;
-    const size_t n_h = R * H, n_o = R * 4;
-    const size_t floats = 2 * (3 * n_h + n_o) + 2 * n_h + 2 * n_o + (size_t)kSlices * H * kLd + ((R + 255) / 256) * 8 + 8;
+    const size_t floats = 2 * (5 * R * H + 2 * R * 4 + (size_t)qr::kF32Slices * H * qr::kF32Ld) + ((R + 255) / 256) * 8 + 8;
     void** slot = qr::ppo_f32_scratch_slot(p);
     size_t* have = qr::ppo_f32_scratch_bytes(p);
     if (*slot == nullptr || *have < floats * sizeof(float)) {
@@ -297,79 +452,46 @@ int qr_ppo_grad_f32class(qr_ppo* p, const float* theta_dev, const float* obs_dev
         F32_HIP(hipMalloc(slot, floats * sizeof(float)));
         *have = floats * sizeof(float);
     }
-    float* base = static_cast<float*>(*slot);
-    float* Hn[2][3]; float* OUT[2];
-    float* q = base;
-    for (int net = 0; net < 2; ++net) { for (int l = 0; l < 3; ++l) { Hn[net][l] = q; q += n_h; } OUT[net] = q; q += n_o; }
-    float* DA = q; q += n_h;
-    float* DB = q; q += n_h;
-    float* D4[2] = {q, q + n_o}; q += 2 * n_o;
-    float* PART = q; q += (size_t)kSlices * H * kLd;
-    float* LOSSP = q; q += ((R + 255) / 256) * 8;
-    double* ADV = reinterpret_cast<double*>(q);   // 8-byte aligned: every block above is a multiple of 2 floats
-    const int outs[2] = {4, 1};
-    const NetOff32 off[2] = {net_off32(L, 4), net_off32(L, 1)};
-    const float* th[2] = {theta_dev, theta_dev + off[0].total};
-    const float* log_std = theta_dev + off[0].total + off[1].total;
-    if (off[0].total + off[1].total + 4 != np) return f32fail(QR_E_STATE, "qr_ppo_grad_f32class: parameter layout mismatch");
-    // ---- forward, both nets
-    for (int net = 0; net < 2; ++net) {
-        const int in[4] = {L, H, H, H}, out[4] = {H, H, H, outs[net]};
-        for (int l = 0; l < 4; ++l) {
-            qr::GemmArgs g{};
-            if (l == 0) { g.A = obs_dev; g.sAm = L; g.sAk = 1; g.idxA = idx_dev; }
-            else { g.A = Hn[net][l - 1]; g.sAm = H; g.sAk = 1; }
-            g.B = th[net] + off[net].w[l]; g.sBk = 1; g.sBn = in[l]; g.b_ones_col = -1;      // B(k, n) = W[n][k]
-            g.C = l < 3 ? Hn[net][l] : OUT[net]; g.sCm = l < 3 ? H : 4;
-            g.M = B; g.N = out[l]; g.K = in[l]; g.k_per_slice = in[l];
-            g.bias = th[net] + off[net].b[l]; g.relu = l < 3;
-            launch_gemm(g, 1, st);
+    const GradCall call{theta_dev, obs_dev, act_dev, old_logp_dev, adv_dev, ret_dev, idx_dev, B, clip, vf_coef, ent_coef, grad_out_dev, stats_dev};
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool caller_captures = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+    if (caller_captures || !qr::ppo_uses_graphs(p)) {   // a graph launch cannot be captured: plain nodes into the caller's graph
+        enqueue_grad(call, L, max_B, np, static_cast<float*>(*slot), st);
+        F32_HIP(hipGetLastError());
+        return QR_OK;
+    }
+    // ~20 dependent launches of microseconds each: replayed as one graph per distinct argument set (a training loop's minibatch
+    // offsets into its permutation buffer recur every epoch), captured on first sight
+    void** gslot = qr::ppo_f32_graphs_slot(p);
+    if (!*gslot) *gslot = new GraphCache();
+    GraphCache& gc = *static_cast<GraphCache*>(*gslot);
+    hipGraphExec_t exec = nullptr;
+    for (auto& e : gc.entries)
+        if (e.first == call) { exec = e.second; break; }
+    if (!exec) {
+        hipStream_t* cap = qr::ppo_capture_stream_slot(p);
+        if (!*cap) F32_HIP(hipStreamCreateWithFlags(cap, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        F32_HIP(hipStreamBeginCapture(*cap, hipStreamCaptureModeRelaxed));
+        enqueue_grad(call, L, max_B, np, static_cast<float*>(*slot), *cap);
+        const hipError_t end = hipStreamEndCapture(*cap, &graph);
+        if (end != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return f32fail(QR_E_HIP, std::string("qr_ppo_grad_f32class: graph capture failed: ") + hipGetErrorString(end));
+        }
+        const hipError_t inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (inst != hipSuccess) return f32fail(QR_E_HIP, std::string("qr_ppo_grad_f32class: hipGraphInstantiate: ") + hipGetErrorString(inst));
+        if (gc.entries.size() < GraphCache::kMax) {
+            gc.entries.emplace_back(call, exec);
+        } else {   // the replaced graph may still be running on the caller's stream
+            F32_HIP(hipDeviceSynchronize());
+            (void)hipGraphExecDestroy(gc.entries[gc.next_victim].second);
+            gc.entries[gc.next_victim] = std::make_pair(call, exec);
+            gc.next_victim = (gc.next_victim + 1) % GraphCache::kMax;
         }
     }
-    // ---- loss
-    hipLaunchKernelGGL(qr::f32_adv_stats_kernel, dim3(1), dim3(1024), 0, st, adv_dev, idx_dev, B, ADV);
-    qr::LossArgs la{};
-    la.mean = OUT[0]; la.value = OUT[1]; la.act = act_dev; la.old_logp = old_logp_dev; la.adv = adv_dev; la.ret = ret_dev; la.log_std = log_std;
-    la.idx = idx_dev; la.adv_acc = ADV; la.B = B; la.clip = clip; la.vf_coef = vf_coef; la.d_mean = D4[0]; la.d_value = D4[1]; la.partial = LOSSP;
-    const int lblocks = (B + 255) / 256;
-    hipLaunchKernelGGL(qr::f32_loss_kernel, dim3(lblocks), dim3(256), 0, st, la);
-    hipLaunchKernelGGL(qr::f32_finish_kernel, dim3(1), dim3(64), 0, st, LOSSP, lblocks, B, ent_coef, grad_out_dev, np, stats_dev);
-    // ---- backward + weight gradients, net by net, layer 4 down to 1
-    const int k_per_slice = (((B + kSlices - 1) / kSlices) + 15) / 16 * 16;
-    const int slices = (B + k_per_slice - 1) / k_per_slice;
-    const float scale = 1.0f / (float)B;
-    for (int net = 0; net < 2; ++net) {
-        const int in[4] = {L, H, H, H}, out[4] = {H, H, H, outs[net]};
-        float* gnet = grad_out_dev + (net == 0 ? 0 : off[0].total);
-        const float* delta = D4[net];     // [B][ld_delta]
-        int ld_delta = 4;
-        for (int l = 3; l >= 0; --l) {
-            // dW_l [out][in + 1] = delta^T x [h_(l-1) | 1], K = the minibatch's rows, split over `slices` workgroup layers
-            qr::GemmArgs g{};
-            g.A = delta; g.sAm = 1; g.sAk = ld_delta;                                         // A(m = unit, k = row) = delta[row][m]
-            if (l == 0) { g.B = obs_dev; g.sBk = L; g.sBn = 1; g.idxB = idx_dev; }
-            else { g.B = Hn[net][l - 1]; g.sBk = H; g.sBn = 1; }
-            g.b_ones_col = in[l];
-            g.C = PART; g.sCm = kLd; g.c_slice = (long)H * kLd;
-            g.M = out[l]; g.N = in[l] + 1; g.K = B; g.k_per_slice = k_per_slice;
-            launch_gemm(g, slices, st);
-            const int elems = out[l] * (in[l] + 1);
-            hipLaunchKernelGGL(qr::f32_dw_reduce_kernel, dim3((elems + 255) / 256), dim3(256), 0, st, PART, slices, (long)H * kLd, out[l], in[l], kLd,
-                               scale, gnet + off[net].w[l], gnet + off[net].b[l]);
-            if (l == 0) break;
-            // delta_(l-1) [B][in] = (delta_l [B][out] x W_l [out][in]) where h_(l-1) > 0
-            qr::GemmArgs b{};
-            b.A = delta; b.sAm = ld_delta; b.sAk = 1;
-            b.B = th[net] + off[net].w[l]; b.sBk = in[l]; b.sBn = 1; b.b_ones_col = -1;      // B(k = out unit, n = in unit) = W[k][n]
-            float* dst = (delta == DA) ? DB : DA;
-            b.C = dst; b.sCm = H;
-            b.M = B; b.N = in[l]; b.K = out[l]; b.k_per_slice = out[l];
-            b.mask = Hn[net][l - 1]; b.sMask = H;
-            launch_gemm(b, 1, st);
-            delta = dst; ld_delta = H;
-        }
-    }
-    F32_HIP(hipGetLastError());
+    F32_HIP(hipGraphLaunch(exec, st));
     return QR_OK;
 }
 

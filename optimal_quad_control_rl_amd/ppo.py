@@ -166,11 +166,12 @@ class MfmaPpoUpdater:
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
         assert idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()
 
-    def grad(self, obs, act, old_lp, adv, ret, idx, clip=0.2, vf_coef=0.5, ent_coef=0.0, stats=False, precision=None):
+    def grad(self, obs, act, old_lp, adv, ret, idx, clip=0.2, vf_coef=0.5, ent_coef=0.0, stats=False, precision=None, out=None):
         """Flat gradient of the PPO loss on the rows `idx` (no clipping, no optimiser step).  precision="f32": the reference-precision
-        kernels (qr_ppo_grad_f32class: every GEMM operand as two f16 pieces); default = this updater's `precision`."""
+        kernels (qr_ppo_grad_f32class: every GEMM operand as three bf16 pieces, replayed as one cached graph per distinct argument
+        set -- pass the same `out` buffer from call to call to hit it); default = this updater's `precision`."""
         self._check(obs, act, old_lp, adv, ret, idx)
-        g = torch.empty(self.theta.numel() + 4, dtype=torch.float32, device=self.device)  # gradient + minibatch statistics
+        g = out if out is not None else torch.empty(self.theta.numel() + 4, dtype=torch.float32, device=self.device)  # gradient + minibatch statistics
         fn = self._L.qr_ppo_grad_f32class if (precision or self.precision) == "f32" else self._L.qr_ppo_grad
         self._lib.check(fn(self._h, self._p(self.theta), self._p(obs), self._p(act), self._p(old_lp), self._p(adv),
                                             self._p(ret), self._p(idx), int(idx.numel()), clip, vf_coef, ent_coef, self._p(g),
@@ -240,7 +241,9 @@ class MfmaPpoUpdater:
 
     def minibatch(self, obs, act, old_lp, adv, ret, idx, lr, clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5):
         if self.precision == "f32":   # reference-precision gradient kernels, then the (f32) apply kernel; averaged across ranks when data parallel
-            g = self.grad(obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef, stats=False)
+            if getattr(self, "_g32", None) is None:
+                self._g32 = torch.empty(self.theta.numel() + 4, dtype=torch.float32, device=self.device)
+            g = self.grad(obs, act, old_lp, adv, ret, idx, clip, vf_coef, ent_coef, stats=False, out=self._g32)
             return self.apply(average_across_ranks(g) if self.data_parallel() else g, lr, int(idx.numel()), max_grad_norm)
         if self.data_parallel():
             # data parallel: every rank holds the same parameters and its own envs; average the gradient (and the minibatch

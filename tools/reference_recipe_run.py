@@ -25,8 +25,10 @@ ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--steps", type=float, default=1.03e9)
 ap.add_argument("--eval-every", type=int, default=40, help="evaluate every this many checkpoints (one checkpoint = 10 rollouts = 1e6 env-steps)")
 ap.add_argument("--lap-target", type=float, default=2.6)
-ap.add_argument("--precision", default="f16-operands", help="f16-operands (hand-written matrix-core kernels) | f32 (f32-class collect kernel + torch float32 update) | "
-                "f32-collect (f32-class collect kernel + the f16-operand update kernels)")
+ap.add_argument("--precision", default="f16-operands", help="f16-operands (hand-written matrix-core kernels) | f32 (f32-class collect kernel + f32-class gradient kernels: "
+                "the reference's precision end to end) | f32-collect (f32-class collect kernel + the f16-operand update kernels)")
+ap.add_argument("--stop-when-reached", action="store_true", help="end the run at the first evaluation that reaches the reference's level (lap-target, <= 0.1 crashes / 12 s): "
+                "answers 'does this seed reach it' at a fraction of the 1.03e9 steps; the result says so (stopped_when_reached)")
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 
@@ -38,7 +40,7 @@ policy_kwargs = dict(activation_fn=torch.nn.ReLU, net_arch=[dict(pi=[120, 120, 1
 model = PPO("MlpPolicy", env, policy_kwargs=policy_kwargs, verbose=0, n_steps=1000, batch_size=5000, n_epochs=10, gamma=0.999,
             seed=a.seed, precision=a.precision)                                                                             # R:785-795
 tr = model._trainer
-assert a.precision == "f32" or (tr.native_update and tr.fused_collect), "the default precision must run on the matrix-core path"
+assert tr.native_update and tr.fused_collect, "every precision runs on the hand-written kernels (collect + update)"
 
 n_eval, G, dt = 4096, 4, 0.01
 ev = Quadcopter3DGates(n_eval, *trk, gates_ahead=1, infos_mode="none", seed=99)
@@ -97,6 +99,8 @@ while model.num_timesteps < a.steps:
         curve.append(r)
         torch.cuda.synchronize()
         paused += time.perf_counter() - e0
+        if a.stop_when_reached and r["flying_lap"] is not None and r["flying_lap"] <= a.lap_target and r["crashes_per_12s"] <= 0.1:
+            break
 torch.cuda.synchronize()
 train_s = time.perf_counter() - t0 - paused
 ok = [c for c in curve if c["flying_lap"] is not None]
@@ -104,7 +108,7 @@ good = [c for c in ok if c["flying_lap"] <= a.lap_target and c["crashes_per_12s"
 best = min(ok, key=lambda c: (c["crashes_per_12s"] > 0.1, c["flying_lap"])) if ok else None
 res = dict(what="reference training cell (R:765, 783-795, 816-831): 100 envs x n_steps 1000, batch_size 5000, 10 epochs, gamma 0.999, constant lr "
                 "3e-4, checkpoint every 10 rollouts, via optimal_quad_control_rl_amd.PPO.learn / .save; 4-gate square track",
-           seed=a.seed, precision=a.precision, native_update=bool(tr.native_update), fused_collect=bool(tr.fused_collect), train_steps=int(model.num_timesteps), train_seconds=train_s,
+           seed=a.seed, precision=a.precision, stopped_when_reached=bool(a.stop_when_reached and model.num_timesteps < a.steps), native_update=bool(tr.native_update), fused_collect=bool(tr.fused_collect), train_steps=int(model.num_timesteps), train_seconds=train_s,
            env_steps_per_s=model.num_timesteps / train_s, seconds_in_save=save_s, checkpoints=n_ckpt,
            updates_applied=tr.stats.get("updates"), updates_skipped_nonfinite=tr.stats.get("skipped_nonfinite", 0),
            final=curve[-1] if curve else None, best_checkpoint=best,
