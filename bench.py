@@ -669,8 +669,9 @@ def headline(result):
     pu, c5, c5b = result.get("ppo_update") or {}, result.get("config5") or {}, result.get("config5_mb65536") or {}
     c5r = result.get("config5_ref_ratio") or {}
     if pu or c5:
-        h["ppo"] = {"dtype": "f16 matrix-core operands, f32 accumulation / parameters / Adam (precision='f32' = float32 via torch: A/B mode, not timed here)",
+        h["ppo"] = {"dtype": "f16 matrix-core operands, f32 accumulation / parameters / Adam (precision='f32' = f32-class kernels, three bf16 pieces per operand: A/B path, update_f32class_*)",
                     "update_us_per_16384_rows": pu.get("epoch_us"), "update_useful_TFLOPs": pu.get("epoch_useful_TFLOPs"),
+                    "update_f32class_us_per_16384_rows": pu.get("f32class_us"), "update_f32class_us_per_5000_rows": pu.get("f32class_us_5000_rows"),
                     "update_mfma_frac": None if pu.get("epoch_useful_TFLOPs") is None else pu["epoch_useful_TFLOPs"] / MFMA_F16_PEAK_TF,
                     "update_launch": "qr_ppo_epoch: one replayed graph per epoch (what training calls)",
                     "stream_launch_us_per_update": pu.get("native_us"), "torch_us": pu.get("torch_us"),

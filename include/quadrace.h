@@ -198,7 +198,7 @@ int qr_policy_forward(qr_policy* policy, int32_t n, const float* obs_dev, float*
 /* The same network at the reference's precision (round 6): both operands of every layer as two f16 pieces (w x ~ W0 X0 + W1 X0 + W0 X1,
  * f32 accumulation on the matrix core: three matrix instructions per K-step) -- float32-class results (max |d mean| vs the reference's
  * generated nn_forward, c_code/neural_network.c:397-430, at the 1e-6 level instead of 7e-4) for evaluation and for precision="f32"
- * collection; qr_policy_forward stays the throughput path.  Same arguments. */
+ * collection (its update half is qr_ppo_grad_f32class below); qr_policy_forward stays the throughput path.  Same arguments. */
 int qr_policy_forward_f32class(qr_policy* policy, int32_t n, const float* obs_dev, float* mean_out_dev, void* stream);
 
 /* Closed-loop rollout: K steps of  obs -> policy -> a ~ N(mean, exp(log_std)^2) -> env.step(clip(a, -1, 1))  in ONE

@@ -411,7 +411,7 @@ def test_fused_gradient_is_deterministic_and_stateless_across_minibatch_sizes():
 @pytest.mark.parametrize("L,B,clip", [(17, 1024, 0.2), (24, 5000, 0.2), (24, 16384, 50.0), (36, 256, 0.2), (13, 100, 50.0), (24, 40000, 0.2)])
 def test_f32class_gradient_matches_float64_autograd(L, B, clip):
     """Round 6: the reference-precision gradient kernels (qr_ppo_grad_f32class: every GEMM operand of the forward pass,
-    the backward pass and the weight gradients as two f16 pieces, f32 accumulation) against FLOAT64 autograd on the same rows: cosine
+    the backward pass and the weight gradients as three bf16 pieces, f32 accumulation) against FLOAT64 autograd on the same rows: cosine
     >= 1 - 1e-6 over the whole gradient and per tensor, relative error per tensor at the float32 level (float32 torch autograd sits at the
     same level), identical minibatch statistics -- where the f16-operand kernel has cosine >= 0.9985.  With clip = 0.2 a sample whose ratio
     sits within float32 noise of the clip edge may take the other branch: the bound is looser there but still 100 x below the f16 kernel's."""
@@ -507,3 +507,35 @@ def test_sb3_precision_f32_trains_on_the_hand_written_reference_precision_kernel
     apart = float((thetas["f32"][1] - thetas["f16-operands"][1]).norm())
     print("parameters moved %.3f, the two precisions ended %.3f apart" % (moved, apart))
     assert apart < moved                                                              # they went the same way
+
+
+def test_f32class_graph_replay_is_bit_identical_to_plain_launches_and_survives_eviction():
+    """qr_ppo_grad_f32class replays its ~20 launches as one cached hipGraph per distinct argument set (quadrace_ppo_f32.hip): a first call
+    (capture), a second call with the same arguments (cache hit) and a handle created with QR_PPO_NO_EPOCH_GRAPH (plain launches) give the
+    SAME bits; 300 distinct minibatch offsets push the 256-entry cache through its replacement path and the first offset, captured again
+    afterwards, still gives the same bits."""
+    from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
+
+    L, B, rows = 24, 96, 300 * 8 + 96
+    pol, ref, up16, obs, act, old_lp, adv, ret = _setup(L, rows, seed=11, max_minibatch=4096)
+    graphs = MfmaPpoUpdater(pol, L, obs.device, 4096, precision="f32")
+    plain = MfmaPpoUpdater(pol, L, obs.device, 4096, precision="f32", flags=8)
+    perm = torch.randperm(rows, device=obs.device).to(torch.int32).contiguous()
+    out = torch.empty(graphs.theta.numel() + 4, dtype=torch.float32, device=obs.device)
+    out_plain = torch.empty_like(out)
+
+    def run(up, buf, off):
+        buf.fill_(float("nan"))
+        return up.grad(obs, act, old_lp, adv, ret, perm[off:off + B], 0.2, 0.5, 0.01, out=buf).clone()
+
+    first = run(graphs, out, 0)                      # capture
+    again = run(graphs, out, 0)                      # cache hit
+    want = run(plain, out_plain, 0)                  # no graph
+    assert torch.isfinite(first).all()
+    assert torch.equal(first, again) and torch.equal(first, want)
+    for k in range(1, 300):                          # 299 more argument sets: the cache holds 256
+        got = run(graphs, out, 8 * k)
+        if k % 37 == 0:
+            assert torch.equal(got, run(plain, out_plain, 8 * k)), k
+    assert torch.equal(run(graphs, out, 0), want)    # offset 0 was replaced by then: captured again, same bits
+    graphs.close(); plain.close()

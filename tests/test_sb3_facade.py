@@ -92,7 +92,8 @@ def test_vecmonitor_passthrough_reaches_the_env():
     assert e.disturbance_ranges is not None and w.num_envs == 4
 
 
-# ---- the reference-precision mode (precision="f32"): float32 through torch, pinned at float32 level ------------------------------
+# ---- the reference-precision mode (precision="f32"): on a GPU it runs on hand-written f32-class kernels (tests/test_gpu_policy.py,
+# ---- tests/test_gpu_ppo_kernel.py compare them with float64); here, on the CPU, the float32 definition they are held to is pinned ----
 def _f10_net():
     """the reference's own generated policy (c_code/neural_network.c weights + 512 rows of its nn_forward, fixture F10) in the
     trainer's network"""
@@ -109,8 +110,9 @@ def _f10_net():
 
 
 def test_f32_mode_policy_forward_matches_the_reference_nn_forward():
-    """<= 1e-5 against c_code/neural_network.c:397-430 nn_forward on F10 for the float32 policy forward (what
-    precision='f32' evaluates in the collect phase; the f16-operand kernel sits at 7e-4, tests/test_gpu_policy.py)"""
+    """<= 1e-5 against c_code/neural_network.c:397-430 nn_forward on F10 for the float32 policy forward in torch -- the
+    level precision='f32' is held to (its f32-class matrix-core kernel sits at 7e-7 of nn_forward, the f16-operand kernel at 7e-4:
+    tests/test_gpu_policy.py)"""
     net, d = _f10_net()
     with torch.no_grad():
         out = net.pi(torch.as_tensor(d["obs"])).numpy()
@@ -118,8 +120,9 @@ def test_f32_mode_policy_forward_matches_the_reference_nn_forward():
 
 
 def test_f32_mode_gradient_is_at_float32_level():
-    """the update of precision='f32' is torch autograd in float32: its PPO-loss gradient agrees with the float64 evaluation of the
-    same loss to <= 1e-4 of each tensor's scale (the f16-operand kernel: 2-5 percent elementwise, cosine 0.9985-0.999)"""
+    """float32 autograd of the PPO loss agrees with the float64 evaluation of the same loss to <= 1e-4 of each tensor's scale: the
+    level the f32-class gradient kernels of precision='f32' are held to against float64 on the GPU (tests/test_gpu_ppo_kernel.py:
+    cosine >= 0.999999; the f16-operand kernel: 2-5 percent elementwise, cosine 0.9985-0.999)"""
     net, d = _f10_net()
     g = torch.Generator().manual_seed(0)
     B = 4096

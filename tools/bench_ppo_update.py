@@ -53,6 +53,17 @@ def measure(L=17, B=16384, R=65536 * 8, iters=100, with_torch=True):
     st = up.status()   # (stopped, optimiser steps, skipped non-finite, barrier timeouts): the last two must be 0
     out.update(status_skipped_nonfinite=st[2], status_barrier_timeouts=st[3])
     up.close()
+    # the reference-precision update (precision="f32": qr_ppo_grad_f32class, three bf16 pieces per GEMM operand, + qr_ppo_apply), the A/B path:
+    # the same rows, and the reference recipe's own minibatch of 5 000 rows (R:785-792)
+    try:
+        for rows_f32, key in ((B, "f32class_us"), (5000, "f32class_us_5000_rows")):
+            up32 = MfmaPpoUpdater(pol, L, dev, rows_f32, precision="f32")
+            nb32 = min(R // rows_f32, 32)
+            t32 = timed(lambda k: up32.minibatch(obs, act, old_lp, adv, ret, perm[(k % nb32) * rows_f32:(k % nb32 + 1) * rows_f32], 3e-4), max(40, iters // 2))
+            out[key] = t32 * 1e6
+            up32.close()
+    except Exception as ex:  # pragma: no cover
+        out["f32class_error"] = repr(ex)
     if with_torch:
         ref = ActorCritic(L, 4).to(dev)
         opt = torch.optim.Adam(ref.parameters(), lr=3e-4, eps=1e-5)
