@@ -249,9 +249,12 @@ int qr_ppo_grad(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const
                 const float* old_logp_dev, const float* adv_dev, const float* ret_dev, const int32_t* idx_dev, int32_t B,
                 float clip, float vf_coef, float ent_coef, float* grad_out_dev, float* stats_dev, void* stream);
 /* The same gradient at the reference's precision (round 6): every matrix product of the forward pass, the backward pass and the weight
- * gradients on the matrix core with BOTH operands as two f16 pieces and f32 accumulation (csrc/quadrace_ppo_f32.hip) -- float32-class like the
- * reference's torch update (R:783-795; cosine against float64 autograd 1 - 1e-9 level instead of 0.9985), several times slower than
- * qr_ppo_grad.  Same arguments, same grad_out layout; theta_dev is read directly (no operand images).  Follow with qr_ppo_apply for the step. */
+ * gradients on the matrix core with BOTH operands as three bf16 pieces (x = X0 + X1 + X2 exactly; six matrix instructions per K-step) and f32
+ * accumulation, fixed summation order (csrc/quadrace_ppo_f32.hip) -- float32-class like the reference's torch update (R:783-795; cosine against
+ * float64 autograd 1 - 1e-13 instead of 0.9985), several times slower than qr_ppo_grad.  Same arguments, same grad_out layout; theta_dev is read
+ * directly (no operand images); B >= 2.  Follow with qr_ppo_apply for the step.  Its ~20 launches are replayed as one graph per distinct
+ * argument set (up to 256 sets per handle are kept): pass the same buffers from call to call to hit it; QR_PPO_NO_EPOCH_GRAPH or a capturing
+ * `stream` gives plain launches. */
 int qr_ppo_grad_f32class(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const float* act_dev,
                          const float* old_logp_dev, const float* adv_dev, const float* ret_dev, const int32_t* idx_dev, int32_t B,
                          float clip, float vf_coef, float ent_coef, float* grad_out_dev, float* stats_dev, void* stream);

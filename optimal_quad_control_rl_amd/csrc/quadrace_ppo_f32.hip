@@ -8,7 +8,8 @@
 // f32 accumulation -- the idea of the residual MLPs' split first layer (quadrace_device.hpp) and of policy_forward_f32class, as ONE generic
 // strided GEMM kernel that serves the forward layers, the backward layers and the weight gradients:
 //     C[m][n] = sum_k A(m, k) B(k, n)     A(m, k) = A[rowA(m) sAm + k sAk],  B(k, n) = B[rowB(k) sBk + n sBn]   (+ bias, ReLU, ReLU mask)
-// Activations and deltas live in f32 scratch (HBM); nothing is hand-scheduled: 26 GEMM launches + 4 small kernels per minibatch.  The result
+// Activations and deltas live in f32 scratch (HBM).  One launch serves the same product of BOTH networks: 11 GEMM launches + 4 reductions + 3
+// loss kernels per minibatch, replayed as one cached hipGraph per distinct argument set (187 us per 5 000-row update on MI355X).  The result
 // goes to qr_ppo_apply (global-norm clip, Adam, operand re-pack: f32 arithmetic already), like the data-parallel path's gradient.
 //   * deltas are kept UNSCALED (the 1 / B of the batch mean is applied when the weight gradients are reduced);
 //   * bf16 pieces, not f16: a first version with two f16 pieces per operand (as in the forward kernels) lost the low piece of every value
@@ -70,17 +71,15 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& p0, bf16x8& p1, b
 // One launch serves the same layer of BOTH networks (the policy's and the value function's chains are independent).
 struct GemmPair { GemmArgs g[2]; int slices; };   // blockIdx.z = net * slices + K slice
 
-// 256 threads = 4 waves, one 32-column tile of C (blockIdx.x), network and K slice blockIdx.z.
-//   kWaveK = false (weight gradients: K = the minibatch's rows, split over blockIdx.z): the waves are 4 consecutive 32-row tiles (blockIdx.y).
-//   kWaveK = true  (layers: K <= 120, many row tiles): ONE 32-row tile (blockIdx.y) whose K-steps go round the 4 waves -- a chain of 2
-//                  K-steps per wave instead of 8, four times the waves in flight -- and whose 4 accumulators are summed through LDS in wave order.
-template <bool kWaveK>
+// 256 threads = 4 waves = ONE 32 x 32 tile of C (blockIdx.x: column tile, blockIdx.y: row tile), network and K slice blockIdx.z.  The slice's
+// K-steps go round the 4 waves -- a layer (K <= 120, one slice) is a chain of 2 K-steps per wave, a weight gradient (K = the minibatch's rows,
+// >= 256 rows per slice) of >= 4 -- and the 4 accumulators are summed through LDS in wave order.
 __global__ void __launch_bounds__(256) gemm_f32class_kernel(GemmPair pr) {
     const int z_net = blockIdx.z / pr.slices, z_slice = blockIdx.z - z_net * pr.slices;
     const GemmArgs& g = pr.g[z_net];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tm = kWaveK ? blockIdx.y : blockIdx.y * 4 + wave, tn = blockIdx.x;
-    if (tm * 32 >= g.M) return;                               // wave-uniform (kWaveK: workgroup-uniform)
+    const int tm = blockIdx.y, tn = blockIdx.x;
+    if (tm * 32 >= g.M) return;                               // workgroup-uniform
     const int c = lane & 31, h = lane >> 5;
     const int m = tm * 32 + c, n = tn * 32 + c;
     const bool m_ok = m < g.M, n_ok = n < g.N;
@@ -120,8 +119,8 @@ __global__ void __launch_bounds__(256) gemm_f32class_kernel(GemmPair pr) {
             }
         }
     };
-    constexpr int kStride = kWaveK ? 64 : 16;
-    const int k_first = k_lo + (kWaveK ? 16 * wave : 0);
+    constexpr int kStride = 64;
+    const int k_first = k_lo + 16 * wave;
     float a[8], b[8], an[8], bn[8];
     if (k_first < k_hi) load(k_first, a, b);
     for (int k0 = k_first; k0 < k_hi; k0 += kStride) {
@@ -152,19 +151,14 @@ __global__ void __launch_bounds__(256) gemm_f32class_kernel(GemmPair pr) {
         if (g.mask && !(g.mask[(long)mm * g.sMask + n] > 0.0f)) v = 0.0f;
         C[(long)mm * g.sCm + n] = v;
     };
-    if constexpr (kWaveK) {
-        __shared__ float red[4][16][64];
+    __shared__ float red[4][16][64];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-        __syncthreads();
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {        // wave w finishes registers 4 w .. 4 w + 3
-            const int r = 4 * wave + j;
-            finish(r, ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane]);
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) finish(r, acc[r]);
+    for (int j = 0; j < 4; ++j) {        // wave w finishes registers 4 w .. 4 w + 3
+        const int r = 4 * wave + j;
+        finish(r, ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane]);
     }
 }
 
@@ -308,11 +302,8 @@ void launch_gemm(const qr::GemmArgs& g0, const qr::GemmArgs& g1, int slices, hip
     pr.g[0] = g0; pr.g[1] = g1; pr.slices = slices;
     const int M = g0.M > g1.M ? g0.M : g1.M, N = g0.N > g1.N ? g0.N : g1.N;
     const int tiles_m = (M + 31) / 32;
-    if (slices == 1) {   // a layer: K-steps round the waves of one row tile
-        hipLaunchKernelGGL(qr::gemm_f32class_kernel<true>, dim3((N + 31) / 32, tiles_m, 2), dim3(256), 0, st, pr);
-    } else {             // a weight gradient: split-K over the grid
-        hipLaunchKernelGGL(qr::gemm_f32class_kernel<false>, dim3((N + 31) / 32, (tiles_m + 3) / 4, 2 * slices), dim3(256), 0, st, pr);
-    }
+    // every product in the wave-K form: a layer is one slice, a weight gradient `slices` of them over blockIdx.z
+    hipLaunchKernelGGL(qr::gemm_f32class_kernel, dim3((N + 31) / 32, tiles_m, 2 * slices), dim3(256), 0, st, pr);
 }
 
 // One call's arguments: the key of its cached graph (the launches address nothing else that changes from call to call).
@@ -374,7 +365,9 @@ void enqueue_grad(const GradCall& c, int L, int max_B, int np, float* base, hipS
     hipLaunchKernelGGL(qr::f32_loss_kernel, dim3(lblocks), dim3(256), 0, st, la);
     hipLaunchKernelGGL(qr::f32_finish_kernel, dim3(1), dim3(64), 0, st, LOSSP, lblocks, B, c.ent_coef, c.grad, np, c.stats);
     // ---- backward + weight gradients, layer 4 down to 1, both nets per launch
-    const int k_per_slice = (((B + kSlices - 1) / kSlices) + 15) / 16 * 16;
+    // >= 256 rows per slice (4 K-steps per wave), at most kSlices slices: few enough partial tiles that their traffic stays below the operands'
+    int k_per_slice = (((B + kSlices - 1) / kSlices) + 63) / 64 * 64;
+    if (k_per_slice < 256) k_per_slice = 256;
     const int slices = (B + k_per_slice - 1) / k_per_slice;
     const float* delta[2] = {D4[0], D4[1]};     // [B][ld_delta]
     int ld_delta = 4;

@@ -539,3 +539,29 @@ def test_f32class_graph_replay_is_bit_identical_to_plain_launches_and_survives_e
             assert torch.equal(got, run(plain, out_plain, 8 * k)), k
     assert torch.equal(run(graphs, out, 0), want)    # offset 0 was replaced by then: captured again, same bits
     graphs.close(); plain.close()
+
+
+@pytest.mark.parametrize("L,B", [(24, 2), (24, 3), (20, 31), (21, 33), (25, 63), (28, 65), (29, 255), (32, 257), (36, 513), (13, 4097), (17, 769), (24, 1025)])
+def test_f32class_gradient_ragged_minibatches_and_every_observation_length(L, B):
+    """Edge shapes of qr_ppo_grad_f32class against float64 autograd: the smallest minibatch the entry accepts (2 rows), sizes one row either
+    side of the 32-row tile, the 64-row wave round and the 256-row weight-gradient slice (a slice of ONE row), and every observation length
+    of the race envs (only 24 and 32 take the 16-byte load path of layer 1; the rest the 4-byte one).  clip = 50: no sample sits on a clip
+    edge, so the bound is the float32-level one."""
+    from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
+
+    rows = max(3000, 2 * B)
+    pol, ref, up16, obs, act, old_lp, adv, ret = _setup(L, rows, seed=100 + L + B, max_minibatch=max(4096, B))
+    up = MfmaPpoUpdater(pol, L, obs.device, max(4096, B), precision="f32")
+    idx = torch.randperm(rows, device=obs.device)[:B].to(torch.int32).contiguous()
+    g = up.grad(obs, act, old_lp, adv, ret, idx, 50.0, 0.5, 0.01)
+    ref64 = copy.deepcopy(ref).double()
+    loss, pg, vl, ratio = _torch_loss(ref64, obs.double(), act.double(), old_lp.double(), adv.double(), ret.double(), idx, 50.0, 0.5, 0.01)
+    loss.backward()
+    want = torch.cat(_flat_ref_grads(ref64))
+    n = want.numel()
+    assert g.numel() == n + 4 and torch.isfinite(g).all()
+    cos = float(torch.dot(g[:n].double(), want) / (g[:n].double().norm() * want.norm()))
+    rel = float((g[:n].double() - want).norm() / want.norm())
+    print("L=%d B=%d: cosine 1 - %.2e, relative error %.2e" % (L, B, 1 - cos, rel))
+    assert cos >= 1 - 1e-6 and rel <= 2e-5, (L, B, cos, rel)
+    up.close()
