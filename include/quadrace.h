@@ -252,7 +252,7 @@ int qr_ppo_grad(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const
  * gradients on the matrix core with BOTH operands as three bf16 pieces (x = X0 + X1 + X2 exactly; six matrix instructions per K-step) and f32
  * accumulation, fixed summation order (csrc/quadrace_ppo_f32.hip) -- float32-class like the reference's torch update (R:783-795; cosine against
  * float64 autograd 1 - 1e-13 instead of 0.9985), several times slower than qr_ppo_grad.  Same arguments, same grad_out layout; theta_dev is read
- * directly (no operand images); B >= 2.  Follow with qr_ppo_apply for the step.  Its ~20 launches are replayed as one graph per distinct
+ * directly (no operand images); 2 <= B <= 2 097 120.  Follow with qr_ppo_apply for the step.  Its ~20 launches are replayed as one graph per distinct
  * argument set (up to 256 sets per handle are kept): pass the same buffers from call to call to hit it; QR_PPO_NO_EPOCH_GRAPH or a capturing
  * `stream` gives plain launches. */
 int qr_ppo_grad_f32class(qr_ppo* ppo, const float* theta_dev, const float* obs_dev, const float* act_dev,

@@ -430,6 +430,8 @@ int qr_ppo_grad_f32class(qr_ppo* p, const float* theta_dev, const float* obs_dev
     if (!theta_dev || !obs_dev || !act_dev || !old_logp_dev || !adv_dev || !ret_dev || !idx_dev || !grad_out_dev)
         return f32fail(QR_E_INVALID, "qr_ppo_grad_f32class: null argument");
     if (B < 2 || B > max_B) return f32fail(QR_E_INVALID, "qr_ppo_grad_f32class: minibatch size must be >= 2 and <= max_minibatch");
+    if ((B + 31) / 32 > 65535)   // the layer GEMMs put the 32-row tiles on grid.y
+        return f32fail(QR_E_INVALID, "qr_ppo_grad_f32class: at most 2 097 120 rows per minibatch");
     if (net_off32(L, 4).total + net_off32(L, 1).total + 4 != np) return f32fail(QR_E_STATE, "qr_ppo_grad_f32class: parameter layout mismatch");
     F32_HIP(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;

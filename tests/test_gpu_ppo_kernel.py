@@ -565,3 +565,22 @@ def test_f32class_gradient_ragged_minibatches_and_every_observation_length(L, B)
     print("L=%d B=%d: cosine 1 - %.2e, relative error %.2e" % (L, B, 1 - cos, rel))
     assert cos >= 1 - 1e-6 and rel <= 2e-5, (L, B, cos, rel)
     up.close()
+
+
+def test_f32class_gradient_rejects_bad_minibatch_sizes():
+    """qr_ppo_grad_f32class: B < 2, B > max_minibatch and B beyond the 65 535 row tiles a launch can hold are QR_E_INVALID with a message, not
+    a failed launch"""
+    from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
+
+    L, rows = 24, 4096
+    pol, ref, up16, obs, act, old_lp, adv, ret = _setup(L, rows, seed=5, max_minibatch=4096)
+    up = MfmaPpoUpdater(pol, L, obs.device, 4096, precision="f32")
+    idx = torch.arange(rows, device=obs.device, dtype=torch.int32)
+    with pytest.raises(Exception, match="minibatch size"):
+        up.grad(obs, act, old_lp, adv, ret, idx[:1])
+    up.close()
+    big = MfmaPpoUpdater(pol, L, obs.device, 2097152 + 64, precision="f32")
+    idx_big = torch.zeros(2097152 + 64, device=obs.device, dtype=torch.int32)
+    with pytest.raises(Exception, match="2 097 120"):
+        big.grad(obs, act, old_lp, adv, ret, idx_big)
+    big.close()
