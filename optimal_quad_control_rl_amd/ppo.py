@@ -331,7 +331,8 @@ class PPO:
             assert tuple(net_arch) == (120, 120, 120), "the matrix-core update is built for the reference's 3 x 120 networks"
             assert self.batch_size >= (2 if update_precision == "f32" else 64) and (T * N) % self.batch_size == 0
             # update_precision="f32": the reference-precision gradient kernels (qr_ppo_grad_f32class, three bf16 pieces per GEMM operand) + the
-            # f32 apply kernel, one minibatch at a time (no epoch graph); values of the collect phase then come from torch float32
+            # f32 apply kernel, one minibatch at a time (no epoch graph); the collect phase's values then come from the f32-class forward
+            # kernel too (_value_f32class below) when policy_forward="f32class", from torch float32 otherwise
             self._updater = MfmaPpoUpdater(self.policy, obs_dim, self.dev, self.batch_size, precision=update_precision)
             self._updater.set_shuffle(0x5EED0000 + int(seed))   # on-device epoch permutations (single-process native update)
         self.fused_collect = fused_collect
@@ -341,6 +342,7 @@ class PPO:
         # noise -- ADVICE r03)
         self.noise_step = 0
         self._mfma = None
+        self._mfma_vf = None
         # policy_forward="f32class" (per-step collection only): the action means of collect() come from the hand-written
         # reference-precision forward (qr_policy_forward_f32class: every operand as two f16 pieces, float32-class results) instead of
         # torch's per-layer kernels; sampling, log-probabilities and values stay torch float32.  The weights are re-packed once per rollout.
@@ -353,9 +355,23 @@ class PPO:
             assert tuple(net_arch) == (120, 120, 120), "the matrix-core policy kernels are built for the reference's 3 x 120 network"
             self._mfma = MfmaPolicy(obs_dim, self.dev.index)
             self._last_obs = None
+            # reference precision end to end: the VALUE network of the fused collect phase through the same f32-class forward kernel (its one
+            # output row padded to the kernel's four: the value is column 0), so that no network is evaluated by torch in that mode
+            self._mfma_vf = (MfmaPolicy(obs_dim, self.dev.index)
+                             if (self.policy_forward == "f32class" and fused_collect and self._updater is not None and self._updater.precision == "f32") else None)
         if self.truncation_bootstrap:  # the kernels write the pre-reset observation of finished envs here
             self._term_obs = torch.zeros((T, N, obs_dim) if fused_collect else (N, obs_dim), **f32)
             env.set_terminal_obs_buffer(self._term_obs)
+
+    @torch.no_grad()
+    def _value_f32class_loader(self):
+        """Load the current value network into the second policy-kernel handle (last layer [1, 120] zero-padded to [4, 120]) and return
+        obs [n, L] -> V [n] through qr_policy_forward_f32class (float32-class: 7e-7 of a float32 evaluation)."""
+        lin = [m for m in self.policy.vf if isinstance(m, nn.Linear)]
+        w4 = torch.zeros((4, 120), dtype=torch.float32, device=lin[3].weight.device); w4[0] = lin[3].weight[0]
+        b4 = torch.zeros(4, dtype=torch.float32, device=lin[3].bias.device); b4[0] = lin[3].bias[0]
+        self._mfma_vf.set_weights([(lin[0].weight, lin[0].bias), (lin[1].weight, lin[1].bias), (lin[2].weight, lin[2].bias), (w4, b4)])
+        return lambda o: self._mfma_vf.forward(o.contiguous(), precision="f32")[:, 0].contiguous()
 
     @torch.no_grad()
     def _episode_stats(self, rew, done):
@@ -388,7 +404,12 @@ class PPO:
         T, N = self.n_steps, self.n_envs
         self.num_timesteps += T * N
         f16_values = self._updater is not None and self._updater.precision != "f32"
-        value = (lambda o: self._updater.forward(1, o.contiguous()).contiguous()) if f16_values else self.policy.value
+        if f16_values:
+            value = lambda o: self._updater.forward(1, o.contiguous()).contiguous()
+        elif self._mfma_vf is not None:
+            value = self._value_f32class_loader()
+        else:
+            value = self.policy.value
         if self.truncation_bootstrap:
             # rows that ended by the time limit (rare: at most one per env per max_steps): V of their terminal observation
             self.buf_term_val.zero_()

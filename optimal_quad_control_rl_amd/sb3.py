@@ -190,8 +190,8 @@ class PPO:
         # (policy mean within 7e-4 of the reference's float32 nn_forward, gradient cosine >= 0.9985 against float32 autograd).
         # precision="f32" is the REFERENCE-PRECISION mode, hand-written end to end since round 6: the collect phase is one closed-loop
         # kernel with the f32-class policy forward inside (7e-7 against nn_forward), every minibatch update runs in the f32-class
-        # gradient kernels (three bf16 pieces per GEMM operand: cosine 1 - 1e-13 against float64 autograd) + the f32 apply kernel; only the
-        # value estimates of the collect phase come from torch float32.  Several times slower than the default path; for A/B runs that
+        # gradient kernels (three bf16 pieces per GEMM operand: cosine 1 - 1e-13 against float64 autograd) + the f32 apply kernel; the
+        # value estimates of the collect phase come from the same f32-class forward kernel (no network is evaluated by torch).  Several times slower than the default path; for A/B runs that
         # ask whether an outcome is the recipe's or the arithmetic's.
         precision = precision or "f16-operands"
         # precision="f32-collect": the f32-class forward in the collect phase, the f16-operand matrix-core kernels for the update (an A/B leg

@@ -478,8 +478,8 @@ def test_f32class_minibatch_update_tracks_float64_adam():
 
 def test_sb3_precision_f32_trains_on_the_hand_written_reference_precision_kernels():
     """precision='f32' of the SB3-shaped PPO (round 6): the reference's own recipe shape (100 envs x 1000 steps, batch_size 5000, 10 epochs)
-    runs WITHOUT torch in the loop -- one closed-loop collect kernel with the f32-class policy forward, every minibatch update in the
-    f32-class gradient kernels + the f32 apply kernel -- and takes every one of its 2 x 10 x 20 optimiser steps with finite results;
+    runs WITHOUT a torch-evaluated network in the loop -- one closed-loop collect kernel with the f32-class policy forward, the value
+    estimates through the same f32-class forward kernel, every minibatch update in the f32-class gradient kernels + the f32 apply kernel -- and takes every one of its 2 x 10 x 20 optimiser steps with finite results;
     after the same two rollouts its parameters stay close to the f16-operand path's (same seeds, same noise stream: the two differ by
     arithmetic only)."""
     from optimal_quad_control_rl_amd import PPO, Quadcopter3DGates, TRAIN_DISTURBANCE_RANGES, square_track
@@ -501,6 +501,17 @@ def test_sb3_precision_f32_trains_on_the_hand_written_reference_precision_kernel
         assert m.num_timesteps == 200000 and st["updates"] == 2 * 10 * 20 and st["skipped_nonfinite"] == 0 and np.isfinite(st["loss"])
         assert torch.isfinite(tr._updater.theta).all() and not torch.equal(tr._updater.theta, theta0)
         thetas[precision] = (theta0, tr._updater.theta.clone())
+        if precision == "f32":
+            # no network is evaluated by torch in this mode: the collect phase's value estimates come from the f32-class forward kernel
+            # too (second policy-kernel handle, value head padded to four rows) and sit at float32 level of the torch evaluation
+            assert tr._mfma_vf is not None
+            tr.collect_fused()
+            want = tr.policy.value(tr.buf_obs.view(-1, tr.buf_obs.shape[-1])).view_as(tr.buf_val)
+            err = float((tr.buf_val - want).abs().max()) / max(1.0, float(want.abs().max()))
+            print("collect-phase values, f32-class kernel vs torch float32: max relative difference %.2e" % err)
+            assert err <= 3e-6
+        else:
+            assert tr._mfma_vf is None
         env.close()
     assert torch.equal(thetas["f32"][0], thetas["f16-operands"][0])                  # same initialisation
     moved = float((thetas["f32"][1] - thetas["f32"][0]).norm())
