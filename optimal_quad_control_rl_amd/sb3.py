@@ -299,7 +299,7 @@ class PPO:
     def _data(self):
         return dict(format_version=FORMAT_VERSION, algo="PPO", policy_class="MlpPolicy", observation_dim=self.observation_dim,
                     action_dim=4, net_arch=list(self.net_arch), activation_fn="ReLU", log_std_init=self.log_std_init,
-                    num_timesteps=int(self.num_timesteps), seed=self.seed, **self.hyper)
+                    num_timesteps=int(self.num_timesteps), seed=self.seed, precision=self.precision, **self.hyper)
 
     def save(self, path):
         """SB3 appends '.zip' to a path without an extension (R:823 passes none)."""
@@ -350,6 +350,8 @@ class PPO:
         kwargs = dict(kwargs)
         seed = kwargs.pop("seed", data["seed"])           # explicit keywords win over the checkpoint's, without colliding with it
         device = kwargs.pop("device", device)
+        # a run saved in the reference-precision mode resumes in it (checkpoints written before round 6 carry no entry: the default path)
+        kwargs.setdefault("precision", data.get("precision", "f16-operands"))
         hyper.update(kwargs)
         pk = dict(activation_fn=nn.ReLU, net_arch=dict(pi=data["net_arch"], vf=data["net_arch"]), log_std_init=data["log_std_init"])
         model = cls("MlpPolicy", env, policy_kwargs=pk, seed=seed, device=device,

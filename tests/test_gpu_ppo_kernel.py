@@ -595,3 +595,36 @@ def test_f32class_gradient_rejects_bad_minibatch_sizes():
     with pytest.raises(Exception, match="2 097 120"):
         big.grad(obs, act, old_lp, adv, ret, idx_big)
     big.close()
+
+
+def test_sb3_precision_f32_checkpoint_resumes_in_that_precision_bit_for_bit(tmp_path):
+    """A model trained with precision='f32' and saved is, after PPO.load onto a fresh env, the SAME model in the SAME arithmetic: the
+    checkpoint carries the precision (an explicit keyword still wins), and one more learn() on the original and on the reloaded copy gives
+    identical parameters and Adam state -- the f32-class collect kernel, value kernel, gradient kernels (fixed summation order, cached graph
+    or not) and the apply kernel are all deterministic."""
+    from optimal_quad_control_rl_amd import PPO, Quadcopter3DGates, TRAIN_DISTURBANCE_RANGES, VecMonitor, square_track
+
+    def make(**kw):
+        env = VecMonitor(Quadcopter3DGates(1024, *square_track(), gates_ahead=1, infos_mode="none", seed=3))
+        env.venv.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
+        pk = dict(activation_fn=torch.nn.ReLU, net_arch=[dict(pi=[120, 120, 120], vf=[120, 120, 120])], log_std_init=0)
+        return PPO("MlpPolicy", env, policy_kwargs=pk, verbose=0, n_steps=16, batch_size=4096, n_epochs=2, gamma=0.999, seed=5, **kw), env
+
+    model, env = make(precision="f32")
+    tr = model._trainer
+    assert tr.native_update and tr.fused_collect and tr._updater.precision == "f32" and tr._mfma_vf is not None
+    steps = model.n_steps * env.num_envs * 2
+    model.learn(total_timesteps=steps, reset_num_timesteps=False)
+    path = model.save(str(tmp_path / "f32" / str(model.num_timesteps)))
+    _, env2 = make()                                                     # a fresh env built with the same arguments
+    loaded = PPO.load(path, env=env2)
+    assert loaded.precision == "f32" and loaded._trainer._updater.precision == "f32" and loaded._trainer._mfma_vf is not None
+    assert PPO.load(path, precision="f16-operands").precision == "f16-operands"      # an explicit keyword wins
+    model.learn(total_timesteps=steps, reset_num_timesteps=False)
+    loaded.learn(total_timesteps=steps, reset_num_timesteps=False)
+    assert loaded.num_timesteps == model.num_timesteps == 2 * steps
+    sd_a, sd_b = model.policy.state_dict(), loaded.policy.state_dict()
+    for k in sd_a:
+        assert torch.equal(sd_a[k], sd_b[k]), k
+    assert torch.equal(tr._updater.m, loaded._trainer._updater.m) and torch.equal(tr._updater.v, loaded._trainer._updater.v)
+    assert tr._updater.step == loaded._trainer._updater.step and tr.stats["skipped_nonfinite"] == 0

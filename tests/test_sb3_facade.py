@@ -151,8 +151,11 @@ def test_f32_mode_gradient_is_at_float32_level():
         assert (a32 - a64).abs().max() <= 1e-4 * max(a64.abs().max().item(), 1e-12)
 
 
-def test_precision_keyword():
+def test_precision_keyword(tmp_path):
     m = PPO("MlpPolicy", None, observation_dim=24, seed=0, device="cpu", precision="f32", **REF_KW)
     assert m.precision == "f32"
+    path = m.save(str(tmp_path / "p"))                       # the checkpoint carries it; an explicit keyword wins
+    assert PPO.load(path, device="cpu").precision == "f32"
+    assert PPO.load(path, device="cpu", precision="f16-operands").precision == "f16-operands"
     with pytest.raises(ValueError):
         PPO("MlpPolicy", None, observation_dim=24, device="cpu", precision="bf16", **REF_KW)
