@@ -26,6 +26,8 @@ ap.add_argument("--target-kl", type=float, default=0.02)
 ap.add_argument("--lr-final", type=float, default=0.1)
 ap.add_argument("--fused", action="store_true", help="collect with the closed-loop rollout kernel (qr_rollout_policy)")
 ap.add_argument("--native-update", action="store_true", help="minibatch updates in the matrix-core kernels (qr_ppo_minibatch)")
+ap.add_argument("--precision", default="f16-operands", choices=("f16-operands", "f32-collect", "f32"),
+                help="f32: the reference-precision kernels for collect, values and update (needs --fused --native-update); f32-collect: collect only")
 ap.add_argument("--ent-coef", type=float, default=0.0)
 ap.add_argument("--gamma", type=float, default=0.999)
 ap.add_argument("--seed", type=int, default=0)
@@ -56,7 +58,8 @@ if a.variant == "e2e":
     env.disturbance_ranges = TRAIN_DISTURBANCE_RANGES
 model = PPO(env, seed=a.seed, ent_coef=a.ent_coef, gamma=a.gamma, n_steps=a.n_steps, n_epochs=a.epochs, batch_size=a.envs * a.n_steps // a.minibatches, learning_rate=a.lr,
             target_kl=a.target_kl, lr_final_frac=a.lr_final, total_timesteps_hint=int(a.steps) // world, fused_collect=a.fused,
-            native_update=a.native_update, truncation_bootstrap=not a.no_trunc_bootstrap)
+            native_update=a.native_update, truncation_bootstrap=not a.no_trunc_bootstrap,
+            policy_forward="f32class" if a.precision != "f16-operands" else "torch", update_precision="f32" if a.precision == "f32" else "f16-operands")
 if "RANK" in os.environ:
     model._updater.broadcast_parameters(0)   # identical start on every rank (the seed already makes it so; this guarantees it)
     model.noise_seed = a.seed                 # same key, different global env ids -> independent action noise per rank
