@@ -628,3 +628,45 @@ def test_sb3_precision_f32_checkpoint_resumes_in_that_precision_bit_for_bit(tmp_
         assert torch.equal(sd_a[k], sd_b[k]), k
     assert torch.equal(tr._updater.m, loaded._trainer._updater.m) and torch.equal(tr._updater.v, loaded._trainer._updater.v)
     assert tr._updater.step == loaded._trainer._updater.step and tr.stats["skipped_nonfinite"] == 0
+
+
+def test_f32class_update_honours_target_kl_and_the_nonfinite_guard():
+    """precision='f32' reaches the device-side decisions of qr_ppo_apply through another call sequence (qr_ppo_grad_f32class, then apply, the
+    minibatch statistics riding behind the gradient): SB3's target-KL rule -- no step, stop flag, later launches no-ops, the breaking
+    minibatch's KL recorded once, training resumes after control(clear=True) -- and the non-finite guard (a NaN advantage leaves parameters
+    and Adam moments untouched and is counted) behave as on the f16-operand path."""
+    from optimal_quad_control_rl_amd.ppo import MfmaPpoUpdater
+
+    L, rows, B = 17, 8192, 2048
+    pol, ref, up16, obs, act, old_lp, adv, ret = _setup(L, rows, seed=33)
+    up = MfmaPpoUpdater(pol, L, obs.device, 4096, precision="f32")
+    perm = torch.randperm(rows, device=obs.device).to(torch.int32)
+    up.control(None, clear=True)
+    for k in range(2):
+        up.minibatch(obs, act, old_lp, adv, ret, perm[k * B:(k + 1) * B], lr=3e-4)
+    assert up.status() == (False, 2, 0, 0)
+    theta2 = up.theta.clone()
+    with torch.no_grad():
+        lp, _ = pol.log_prob_entropy(obs, act)
+        kl = float(((lp - old_lp).exp() - 1 - (lp - old_lp)).mean())
+    assert kl > 1e-3
+    up.control(1e-6, clear=True)
+    up.stats.zero_()
+    up.minibatch(obs, act, old_lp, adv, ret, perm[2 * B:3 * B], lr=3e-4)      # exceeds the limit: no step, stop flag set
+    up.minibatch(obs, act, old_lp, adv, ret, perm[3 * B:4 * B], lr=3e-4)      # a no-op
+    assert up.status() == (True, 0, 0, 0)
+    assert torch.equal(up.theta, theta2)
+    assert abs(float(up.stats[2]) / B - kl) < 0.3 * kl                         # recorded once
+    up.control(10.0 * kl, clear=True)
+    up.minibatch(obs, act, old_lp, adv, ret, perm[2 * B:3 * B], lr=3e-4)
+    assert up.status() == (False, 1, 0, 0) and not torch.equal(up.theta, theta2)
+    # non-finite guard
+    before, m_before = up.theta.clone(), up.m.clone()
+    bad_adv = adv.clone(); bad_adv[perm[0].long()] = float("nan")
+    up.control(None, clear=True)
+    up.minibatch(obs, act, old_lp, bad_adv, ret, perm[:B], lr=3e-4)
+    assert up.status() == (False, 0, 1, 0)
+    assert torch.equal(up.theta, before) and torch.equal(up.m, m_before)
+    up.minibatch(obs, act, old_lp, adv, ret, perm[:B], lr=3e-4)               # and training continues afterwards
+    assert up.status() == (False, 1, 1, 0) and torch.isfinite(up.theta).all()
+    up.close()
