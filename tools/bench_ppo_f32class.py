@@ -1,5 +1,7 @@
-import sys, time, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+"""Time one PPO minibatch update (gradient + clip / Adam) at 5 000 ... 131 072 rows: the reference-precision path (precision="f32":
+qr_ppo_grad_f32class + qr_ppo_apply) next to the f16-operand kernels (qr_ppo_minibatch), stream launches as a training loop issues them."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from optimal_quad_control_rl_amd.ppo import ActorCritic, MfmaPpoUpdater
 dev = torch.device("cuda", 0)
 L = 24
